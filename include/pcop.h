@@ -1,0 +1,155 @@
+/*
+ * pcop.h — C ABI of the MI355X-native obstacle hot path
+ * (VoxelGrid downsample -> fixed-radius neighbour graph -> Euclidean clusters).
+ *
+ * This is the drop-in boundary for the three call clusters of the reference
+ * node minibot_cr18/src/obstacle_detection.cpp ("od.cpp"):
+ *
+ *   od.cpp:271-296  downsample_cloud()            -> pcop_voxel_downsample()
+ *   od.cpp:791-792  search::KdTree + setInputCloud -> (internal: device cell grid, no entry point)
+ *   od.cpp:430-455  extract_euclidian_clusters()   -> pcop_euclidean_clusters()
+ *   od.cpp:688-689  PointCloud2 -> PointXYZ        -> pcop_process_pointcloud2()
+ *   od.cpp:740-797  the chain inside cloud_cb()    -> pcop_process_pointcloud2() / pcop_process_xyz()
+ *   od.cpp:806-814  (commented) centroids msg      -> pcop_cluster_summaries()
+ *
+ * Everything behind these entry points is hand-written HIP for gfx950; there
+ * is no CPU backend in this library.  All functions return 0 on success or a
+ * negative pcop_status; nothing throws across the ABI.  All buffers are owned
+ * by the caller unless stated.  A context is bound to one GPU and one HIP
+ * stream, is not thread-safe, and different contexts are independent.
+ */
+#ifndef PCOP_H
+#define PCOP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCOP_VERSION_MAJOR 0
+#define PCOP_VERSION_MINOR 1
+
+/* ---- status codes -------------------------------------------------------- */
+typedef enum pcop_status {
+    PCOP_OK              =  0,
+    PCOP_ERR_ARG         = -1,  /* null pointer / bad layout / bad size                     */
+    PCOP_ERR_PARAM       = -2,  /* leaf or tolerance not finite-positive, min>max ...       */
+    PCOP_ERR_NO_DEVICE   = -3,  /* no HIP device / bad device id (there is no CPU fallback) */
+    PCOP_ERR_HIP         = -4,  /* a HIP runtime call failed (see pcop_last_error)          */
+    PCOP_ERR_CAPACITY    = -5,  /* n > max_points given to pcop_create                      */
+    PCOP_ERR_NONFINITE   = -6,  /* NaN/Inf where the reference would be undefined           */
+    PCOP_ERR_RANGE       = -7,  /* coarse neighbour grid would exceed 2^32 cells            */
+    PCOP_ERR_STATE       = -8   /* call order (e.g. summaries before a frame)               */
+} pcop_status;
+
+/* ---- point memory layouts ------------------------------------------------ */
+#define PCOP_LAYOUT_AOS16 0   /* pcl::PointXYZ in memory: float x,y,z,pad (16 B/pt)     */
+#define PCOP_LAYOUT_SOA   1   /* three planes x[n] y[n] z[n], plane stride = n floats   */
+#define PCOP_LAYOUT_AOS12 2   /* packed float x,y,z (12 B/pt)                           */
+
+/* ---- memory spaces for the *_dev entry points ---------------------------- */
+#define PCOP_MEM_HOST   0
+#define PCOP_MEM_DEVICE 1
+
+/* The parameters of od.cpp:105,113-115,118 (yaml keys downsample_size,
+ * euc_cluster_tolerance, euc_min_cluster_size, euc_max_cluster_size,
+ * publish_point_clouds).  POD, 32 bytes: this struct is the only thing that is
+ * broadcast between GPUs (RCCL) in a multi-GPU run. */
+typedef struct pcop_params {
+    float   leaf;            /* downsample_size          (od.cpp:964) */
+    float   tol;             /* euc_cluster_tolerance    (od.cpp:972) */
+    int32_t min_cluster;     /* euc_min_cluster_size     (od.cpp:973) */
+    int32_t max_cluster;     /* euc_max_cluster_size     (od.cpp:974) */
+    int32_t publish_clouds;  /* publish_point_clouds     (od.cpp:945) */
+    int32_t reserved[3];
+} pcop_params;
+
+/* Result of one frame.  Pointers refer to pinned host memory owned by the
+ * context; they stay valid until the next frame call on the same context. */
+typedef struct pcop_result {
+    int32_t        passthrough;   /* 1 = VoxelGrid overflow rule fired: voxel cloud == input cloud */
+    int32_t        num_voxels;    /* M: points in the downsampled cloud                            */
+    int32_t        num_clusters;  /* K: clusters kept, ordered as PCL orders them                  */
+    int32_t        num_indices;   /* offsets[K]                                                    */
+    const int32_t* offsets;       /* K+1 CSR offsets                                               */
+    const int32_t* indices;       /* indices into the downsampled cloud, ascending per cluster     */
+    const float*   voxel_xyz;     /* M x AOS12 centroids; NULL unless publish_clouds != 0          */
+} pcop_result;
+
+/* Per-stage device times of the last frame (milliseconds, HIP events on the
+ * context's stream).  Filled only when profiling was enabled on the context. */
+#define PCOP_MAX_STAGES 48
+typedef struct pcop_stage_times {
+    int32_t     count;
+    const char* name[PCOP_MAX_STAGES];
+    float       ms[PCOP_MAX_STAGES];
+} pcop_stage_times;
+
+typedef struct pcop_ctx pcop_ctx;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+/* device_id >= 0 selects a HIP device; anything else is PCOP_ERR_NO_DEVICE.
+ * max_points bounds n (and m) of every later call on this context. */
+int  pcop_create(pcop_ctx** ctx, int device_id, size_t max_points);
+void pcop_destroy(pcop_ctx* ctx);
+int  pcop_set_params(pcop_ctx* ctx, const pcop_params* p);
+int  pcop_get_params(const pcop_ctx* ctx, pcop_params* p);
+const char* pcop_last_error(const pcop_ctx* ctx);
+const char* pcop_status_string(int status);
+int  pcop_set_profiling(pcop_ctx* ctx, int enable);
+int  pcop_get_stage_times(const pcop_ctx* ctx, pcop_stage_times* out);
+/* The HIP stream (hipStream_t) the context launches on, as an opaque pointer. */
+void* pcop_stream(const pcop_ctx* ctx);
+
+/* ---- stage API: mirrors downsample_cloud / extract_euclidian_clusters ---- */
+/* VoxelGrid<PointXYZ>::filter with a cubic leaf (od.cpp:282-285).
+ * is_dense==0 drops non-finite points first, as PCL does.  Output has the
+ * layout of the input; for SOA the output plane stride is n.  *passthrough is
+ * set when PCL's "leaf size too small" rule copies the input unchanged. */
+int pcop_voxel_downsample(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int is_dense,
+                          float* out_xyz, size_t* out_m, int* passthrough);
+
+/* EuclideanClusterExtraction::extract (od.cpp:446-454) on an m-point cloud.
+ * offsets has room for m+1 entries, indices for m entries. */
+int pcop_euclidean_clusters(pcop_ctx* ctx, const float* xyz, int layout, size_t m,
+                            int32_t* offsets, int32_t* indices, int32_t* k);
+
+/* ---- fused frame API: what cloud_cb's replacement calls ------------------- */
+/* data/width/height/point_step/row_step/is_bigendian/is_dense are the fields of
+ * sensor_msgs/PointCloud2; off_x/off_y/off_z are the byte offsets of its
+ * FLOAT32 fields "x","y","z" (od.cpp:688-689 resolves them by name). */
+int pcop_process_pointcloud2(pcop_ctx* ctx, const uint8_t* data, uint32_t width, uint32_t height,
+                             uint32_t point_step, uint32_t row_step, uint32_t off_x, uint32_t off_y,
+                             uint32_t off_z, int is_bigendian, int is_dense, pcop_result* out);
+
+/* Same chain on an XYZ array; mem says where xyz lives (device pointers must
+ * belong to the context's GPU).  This is the entry the benchmark times with
+ * the cloud already resident in HBM. */
+int pcop_process_xyz(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int is_dense, int mem,
+                     pcop_result* out);
+
+/* Asynchronous split of pcop_process_xyz for several frames in flight (one
+ * context per frame): submit enqueues the whole frame on the context's stream
+ * and returns; wait blocks until it is done and fills *out. */
+int pcop_submit_xyz(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int is_dense, int mem);
+int pcop_wait(pcop_ctx* ctx, pcop_result* out);
+
+/* PointWithRad[] of the `centroids` topic (msg/PointWithRad.msg:1-4,
+ * msg/PointIndicesArray.msg:1) for the last frame / last cluster call:
+ * xyzr[4*c..] = centre x,y,z and radius r of cluster c (definition: DESIGN.md). */
+int pcop_cluster_summaries(pcop_ctx* ctx, float* xyzr, int32_t cap_clusters);
+
+/* Device-side allocation helpers so a host program without its own HIP code
+ * (e.g. a ctypes caller) can keep clouds resident in HBM. */
+int pcop_dev_alloc(pcop_ctx* ctx, size_t bytes, void** dev_ptr);
+int pcop_dev_free(pcop_ctx* ctx, void* dev_ptr);
+int pcop_dev_upload(pcop_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int pcop_dev_download(pcop_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+int pcop_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCOP_H */

@@ -1,0 +1,164 @@
+"""ctypes front-end of the CPU oracle (oracle/pcl_restatement.cpp).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpcop_oracle.so")
+
+LAYOUT_AOS16, LAYOUT_SOA, LAYOUT_AOS12 = 0, 1, 2
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with g++ (seconds)."""
+    src = os.path.join(_HERE, "pcl_restatement.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpcop_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        fp, ip, up = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+        L.pcop_oracle_r2.restype = C.c_float
+        L.pcop_oracle_r2.argtypes = [C.c_float]
+        L.pcop_oracle_voxel_keys.restype = C.c_int
+        L.pcop_oracle_voxel_keys.argtypes = [fp, C.c_int, C.c_size_t, C.c_float, C.c_int, up, ip]
+        L.pcop_oracle_voxel_downsample.restype = C.c_int
+        L.pcop_oracle_voxel_downsample.argtypes = [fp, C.c_int, C.c_size_t, C.c_float, C.c_int, fp,
+                                                   C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.pcop_oracle_euclidean_clusters_ex.restype = C.c_int
+        L.pcop_oracle_euclidean_clusters_ex.argtypes = [fp, C.c_int, C.c_size_t, C.c_float, C.c_int32, C.c_int32,
+                                                        C.c_int, ip, ip, ip]
+        L.pcop_oracle_cluster_order.restype = None
+        L.pcop_oracle_cluster_order.argtypes = [ip, C.c_int32, ip]
+        L.pcop_oracle_cluster_summaries.restype = C.c_int
+        L.pcop_oracle_cluster_summaries.argtypes = [fp, C.c_int, C.c_size_t, ip, ip, C.c_int32, fp]
+        L.pcop_oracle_knife_edge_pairs.restype = C.c_int64
+        L.pcop_oracle_knife_edge_pairs.argtypes = [fp, C.c_int, C.c_size_t, C.c_float, C.c_int]
+        L.pcop_oracle_process_xyz.restype = C.c_int
+        L.pcop_oracle_process_xyz.argtypes = [fp, C.c_int, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_int32,
+                                              C.c_int32, fp, C.POINTER(C.c_size_t), C.POINTER(C.c_int), ip, ip, ip]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _pack(xyz, layout):
+    """xyz: (n,3) float32 -> flat float32 array in `layout`."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    n = xyz.shape[0]
+    if layout == LAYOUT_AOS12:
+        return xyz.reshape(-1).copy(), n
+    if layout == LAYOUT_SOA:
+        return np.ascontiguousarray(xyz.T).reshape(-1).copy(), n
+    out = np.ones((n, 4), dtype=np.float32)
+    out[:, :3] = xyz
+    return out.reshape(-1), n
+
+
+def _unpack(flat, layout, m, stride):
+    if layout == LAYOUT_AOS12:
+        return flat[: 3 * m].reshape(m, 3).copy()
+    if layout == LAYOUT_SOA:
+        return np.stack([flat[0:m], flat[stride:stride + m], flat[2 * stride:2 * stride + m]], axis=1).copy()
+    return flat[: 4 * m].reshape(m, 4)[:, :3].copy()
+
+
+def r2(tol):
+    return np.float32(lib().pcop_oracle_r2(C.c_float(float(np.float32(tol)))))
+
+
+def voxel_keys(xyz, leaf, is_dense=True, layout=LAYOUT_AOS12):
+    flat, n = _pack(xyz, layout)
+    keys = np.zeros(max(n, 1), dtype=np.uint32)
+    grid = np.zeros(9, dtype=np.int32)
+    pt = lib().pcop_oracle_voxel_keys(_f(flat), layout, n, np.float32(leaf), int(is_dense),
+                                      keys.ctypes.data_as(C.POINTER(C.c_uint32)), _i(grid))
+    return keys[:n], grid, bool(pt)
+
+
+def voxel_downsample(xyz, leaf, is_dense=True, layout=LAYOUT_AOS12):
+    """-> (centroids (m,3) float32, passthrough bool)."""
+    flat, n = _pack(xyz, layout)
+    out = np.zeros(max(4 * n, 4), dtype=np.float32)
+    m = C.c_size_t(0)
+    pt = C.c_int(0)
+    rc = lib().pcop_oracle_voxel_downsample(_f(flat), layout, n, np.float32(leaf), int(is_dense), _f(out),
+                                            C.byref(m), C.byref(pt))
+    if rc:
+        raise ValueError("oracle voxel_downsample rc=%d" % rc)
+    return _unpack(out, layout, m.value, n), bool(pt.value)
+
+
+def euclidean_clusters(xyz, tol, min_cluster, max_cluster, use_tree=True, layout=LAYOUT_AOS12):
+    """-> (offsets int32[k+1], indices int32[offsets[k]])."""
+    flat, m = _pack(xyz, layout)
+    offsets = np.zeros(m + 1, dtype=np.int32)
+    indices = np.zeros(max(m, 1), dtype=np.int32)
+    k = C.c_int32(0)
+    rc = lib().pcop_oracle_euclidean_clusters_ex(_f(flat), layout, m, np.float32(tol), int(min_cluster),
+                                                 int(max_cluster), int(use_tree), _i(offsets), _i(indices),
+                                                 C.byref(k))
+    if rc:
+        raise ValueError("oracle euclidean_clusters rc=%d" % rc)
+    return offsets[: k.value + 1].copy(), indices[: offsets[k.value]].copy()
+
+
+def cluster_order(sizes):
+    sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+    order = np.zeros(len(sizes), dtype=np.int32)
+    lib().pcop_oracle_cluster_order(_i(sizes), len(sizes), _i(order))
+    return order
+
+
+def cluster_summaries(xyz, offsets, indices, layout=LAYOUT_AOS12):
+    flat, m = _pack(xyz, layout)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    k = len(offsets) - 1
+    out = np.zeros((max(k, 1), 4), dtype=np.float32)
+    lib().pcop_oracle_cluster_summaries(_f(flat), layout, m, _i(offsets), _i(indices), k, _f(out))
+    return out[:k]
+
+
+def knife_edge_pairs(xyz, tol, ulps=4):
+    flat, m = _pack(xyz, LAYOUT_AOS12)
+    return int(lib().pcop_oracle_knife_edge_pairs(_f(flat), LAYOUT_AOS12, m, np.float32(tol), int(ulps)))
+
+
+def process_xyz(xyz, leaf, tol, min_cluster, max_cluster, is_dense=True, layout=LAYOUT_AOS12):
+    """Whole chain -> dict(voxel_xyz, passthrough, offsets, indices)."""
+    flat, n = _pack(xyz, layout)
+    vox = np.zeros(max(3 * n, 3), dtype=np.float32)
+    offsets = np.zeros(n + 1, dtype=np.int32)
+    indices = np.zeros(max(n, 1), dtype=np.int32)
+    m = C.c_size_t(0)
+    pt = C.c_int(0)
+    k = C.c_int32(0)
+    rc = lib().pcop_oracle_process_xyz(_f(flat), layout, n, int(is_dense), np.float32(leaf), np.float32(tol),
+                                       int(min_cluster), int(max_cluster), _f(vox), C.byref(m), C.byref(pt),
+                                       _i(offsets), _i(indices), C.byref(k))
+    if rc:
+        raise ValueError("oracle process_xyz rc=%d" % rc)
+    return dict(voxel_xyz=vox[: 3 * m.value].reshape(-1, 3).copy(), passthrough=bool(pt.value),
+                offsets=offsets[: k.value + 1].copy(), indices=indices[: offsets[k.value]].copy())
