@@ -149,6 +149,11 @@ int pcop_dev_upload(pcop_ctx* ctx, void* dev_dst, const void* host_src, size_t b
 int pcop_dev_download(pcop_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
 int pcop_device_count(void);
 
+/* Test hook: device address and size of a named internal buffer of the last frame
+ * ("cen_x", "rec_a", "cell_key", "parent", "label", ... ; "state" = the frame's DevState).
+ * Used by the stage-wise parity tests only; not part of the drop-in surface. */
+int pcop_debug_buffer(pcop_ctx* ctx, const char* name, void** dev_ptr, size_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -389,8 +389,9 @@ int pcop_oracle_euclidean_clusters_ex(const float* xyz, int layout, size_t m, fl
             }
             ++sq_idx;
         }
-        if (static_cast<int64_t>(seed_queue.size()) >= min_cluster &&
-            static_cast<int64_t>(seed_queue.size()) <= max_cluster) {
+        // extractEuclideanClusters takes the limits as `unsigned int` (a negative int wraps)
+        if (seed_queue.size() >= static_cast<uint32_t>(min_cluster) &&
+            seed_queue.size() <= static_cast<uint32_t>(max_cluster)) {
             std::vector<int32_t> r(seed_queue);
             std::sort(r.begin(), r.end());
             r.erase(std::unique(r.begin(), r.end()), r.end());

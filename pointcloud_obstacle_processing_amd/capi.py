@@ -1,0 +1,293 @@
+"""ctypes binding of the C ABI in include/pcop.h (libpcop.so, HIP for gfx950).
+
+This is plumbing for tests and bench.py; the product is the shared library.
+There is no fallback: if libpcop.so is missing or no GPU is present, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpcop.so")
+
+LAYOUT_AOS16, LAYOUT_SOA, LAYOUT_AOS12 = 0, 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+MAX_STAGES = 48
+
+EXPORTS = [
+    "pcop_create", "pcop_destroy", "pcop_set_params", "pcop_get_params", "pcop_last_error", "pcop_status_string",
+    "pcop_set_profiling", "pcop_get_stage_times", "pcop_stream", "pcop_voxel_downsample", "pcop_euclidean_clusters",
+    "pcop_process_pointcloud2", "pcop_process_xyz", "pcop_submit_xyz", "pcop_wait", "pcop_cluster_summaries",
+    "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
+    "pcop_debug_buffer",
+]
+
+
+class PcopError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("pcop status %d: %s" % (status, msg))
+        self.status = status
+
+
+class Params(C.Structure):
+    _fields_ = [("leaf", C.c_float), ("tol", C.c_float), ("min_cluster", C.c_int32), ("max_cluster", C.c_int32),
+                ("publish_clouds", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class Result(C.Structure):
+    _fields_ = [("passthrough", C.c_int32), ("num_voxels", C.c_int32), ("num_clusters", C.c_int32),
+                ("num_indices", C.c_int32), ("offsets", C.POINTER(C.c_int32)), ("indices", C.POINTER(C.c_int32)),
+                ("voxel_xyz", C.POINTER(C.c_float))]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [("count", C.c_int32), ("name", C.c_char_p * MAX_STAGES), ("ms", C.c_float * MAX_STAGES)]
+
+
+class RadixPlan(C.Structure):
+    _fields_ = [("key_bits", C.c_uint32), ("npass", C.c_uint32), ("bits", C.c_uint32 * 3), ("shift", C.c_uint32 * 3)]
+
+
+class DevState(C.Structure):
+    """Mirror of pcop::DevState (csrc/pcop_device.hpp) for the stage-wise tests."""
+    _fields_ = [("err", C.c_uint32), ("n_in", C.c_uint32), ("is_dense", C.c_uint32), ("n_valid", C.c_uint32),
+                ("passthrough", C.c_uint32), ("m", C.c_uint32), ("inv_leaf", C.c_float), ("vmin", C.c_float * 3),
+                ("vmax", C.c_float * 3), ("min_b", C.c_int32 * 3), ("div_b", C.c_int32 * 3), ("mul", C.c_uint32 * 3),
+                ("plan_voxel", RadixPlan), ("c_n", C.c_uint32), ("c_from_input", C.c_uint32), ("r2", C.c_float),
+                ("min_cluster", C.c_uint32), ("max_cluster", C.c_uint32), ("inv_cell", C.c_double),
+                ("cmin", C.c_int64 * 3), ("cdim", C.c_uint32 * 3), ("plan_cell", RadixPlan), ("n_cells", C.c_uint32),
+                ("n_comp", C.c_uint32), ("n_kept", C.c_uint32), ("n_kept_pts", C.c_uint32), ("plan_csr", RadixPlan),
+                ("pad", C.c_uint32 * 3)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libpcop.so; raises if the HIP extension has not been built (no CPU stand-in exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libpcop.so not built: run `make -C %s` (or __graft_entry__.build())" %
+                           os.path.dirname(LIB_PATH))
+    try:  # a process that also uses torch must load torch's HIP runtime first (same soname)
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.pcop_create.restype = C.c_int
+    L.pcop_create.argtypes = [C.POINTER(vp), C.c_int, C.c_size_t]
+    L.pcop_destroy.restype = None
+    L.pcop_destroy.argtypes = [vp]
+    L.pcop_set_params.restype = C.c_int
+    L.pcop_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.pcop_get_params.restype = C.c_int
+    L.pcop_get_params.argtypes = [vp, C.POINTER(Params)]
+    L.pcop_last_error.restype = C.c_char_p
+    L.pcop_last_error.argtypes = [vp]
+    L.pcop_status_string.restype = C.c_char_p
+    L.pcop_status_string.argtypes = [C.c_int]
+    L.pcop_set_profiling.restype = C.c_int
+    L.pcop_set_profiling.argtypes = [vp, C.c_int]
+    L.pcop_get_stage_times.restype = C.c_int
+    L.pcop_get_stage_times.argtypes = [vp, C.POINTER(StageTimes)]
+    L.pcop_stream.restype = vp
+    L.pcop_stream.argtypes = [vp]
+    L.pcop_voxel_downsample.restype = C.c_int
+    L.pcop_voxel_downsample.argtypes = [vp, fp, C.c_int, C.c_size_t, C.c_int, fp, C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_int)]
+    L.pcop_euclidean_clusters.restype = C.c_int
+    L.pcop_euclidean_clusters.argtypes = [vp, fp, C.c_int, C.c_size_t, ip, ip, ip]
+    L.pcop_process_pointcloud2.restype = C.c_int
+    L.pcop_process_pointcloud2.argtypes = [vp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(Result)]
+    L.pcop_process_xyz.restype = C.c_int
+    L.pcop_process_xyz.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(Result)]
+    L.pcop_submit_xyz.restype = C.c_int
+    L.pcop_submit_xyz.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int]
+    L.pcop_wait.restype = C.c_int
+    L.pcop_wait.argtypes = [vp, C.POINTER(Result)]
+    L.pcop_cluster_summaries.restype = C.c_int
+    L.pcop_cluster_summaries.argtypes = [vp, fp, C.c_int32]
+    L.pcop_dev_alloc.restype = C.c_int
+    L.pcop_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.pcop_dev_free.restype = C.c_int
+    L.pcop_dev_free.argtypes = [vp, vp]
+    L.pcop_dev_upload.restype = C.c_int
+    L.pcop_dev_upload.argtypes = [vp, vp, C.c_void_p, C.c_size_t]
+    L.pcop_dev_download.restype = C.c_int
+    L.pcop_dev_download.argtypes = [vp, C.c_void_p, vp, C.c_size_t]
+    L.pcop_device_count.restype = C.c_int
+    L.pcop_device_count.argtypes = []
+    L.pcop_debug_buffer.restype = C.c_int
+    L.pcop_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    _lib = L
+    return L
+
+
+def pack_points(xyz, layout):
+    """(n,3) float32 -> flat float32 array in `layout`."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    n = xyz.shape[0]
+    if layout == LAYOUT_AOS12:
+        return xyz.reshape(-1).copy(), n
+    if layout == LAYOUT_SOA:
+        return np.ascontiguousarray(xyz.T).reshape(-1).copy(), n
+    out = np.ones((n, 4), dtype=np.float32)
+    out[:, :3] = xyz
+    return out.reshape(-1), n
+
+
+def unpack_points(flat, layout, m, stride):
+    if layout == LAYOUT_AOS12:
+        return flat[:3 * m].reshape(m, 3).copy()
+    if layout == LAYOUT_SOA:
+        return np.stack([flat[0:m], flat[stride:stride + m], flat[2 * stride:2 * stride + m]], axis=1).copy()
+    return flat[:4 * m].reshape(m, 4)[:, :3].copy()
+
+
+class Context:
+    """One GPU context (pcop_ctx)."""
+
+    def __init__(self, max_points, device=0, profiling=False):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.pcop_create(C.byref(self.h), int(device), int(max_points))
+        if rc:
+            raise PcopError(rc, self.lib.pcop_status_string(rc).decode())
+        self.max_points = int(max_points)
+        if profiling:
+            self.lib.pcop_set_profiling(self.h, 1)
+
+    def close(self):
+        if self.h:
+            self.lib.pcop_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise PcopError(rc, "%s (%s)" % (self.lib.pcop_status_string(rc).decode(),
+                                             self.lib.pcop_last_error(self.h).decode()))
+
+    def set_params(self, leaf=0.015, tol=0.4, min_cluster=5, max_cluster=20000, publish_clouds=1):
+        p = Params(np.float32(leaf), np.float32(tol), int(min_cluster), int(max_cluster), int(publish_clouds))
+        self._chk(self.lib.pcop_set_params(self.h, C.byref(p)))
+
+    def set_params_struct(self, p):
+        self._chk(self.lib.pcop_set_params(self.h, C.byref(p)))
+
+    # ---- stage API --------------------------------------------------------------------
+    def voxel_downsample(self, xyz, is_dense=True, layout=LAYOUT_AOS12):
+        flat, n = pack_points(xyz, layout)
+        out = np.zeros(max(4 * n, 4), dtype=np.float32)
+        m, pt = C.c_size_t(0), C.c_int(0)
+        self._chk(self.lib.pcop_voxel_downsample(self.h, flat.ctypes.data_as(C.POINTER(C.c_float)), layout, n,
+                                                 int(is_dense), out.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 C.byref(m), C.byref(pt)))
+        return unpack_points(out, layout, m.value, n), bool(pt.value)
+
+    def euclidean_clusters(self, xyz, layout=LAYOUT_AOS12):
+        flat, m = pack_points(xyz, layout)
+        offsets = np.zeros(m + 1, dtype=np.int32)
+        indices = np.zeros(max(m, 1), dtype=np.int32)
+        k = C.c_int32(0)
+        ip = C.POINTER(C.c_int32)
+        self._chk(self.lib.pcop_euclidean_clusters(self.h, flat.ctypes.data_as(C.POINTER(C.c_float)), layout, m,
+                                                   offsets.ctypes.data_as(ip), indices.ctypes.data_as(ip),
+                                                   C.byref(k)))
+        return offsets[:k.value + 1].copy(), indices[:offsets[k.value]].copy()
+
+    # ---- frame API --------------------------------------------------------------------
+    @staticmethod
+    def _result(r):
+        k, t, m = r.num_clusters, r.num_indices, r.num_voxels
+        offsets = np.ctypeslib.as_array(r.offsets, shape=(k + 1,)).copy()
+        indices = np.ctypeslib.as_array(r.indices, shape=(max(t, 1),))[:t].copy()
+        vox = None
+        if r.voxel_xyz:
+            vox = np.ctypeslib.as_array(r.voxel_xyz, shape=(max(m, 1) * 3,))[:3 * m].reshape(m, 3).copy()
+        return dict(passthrough=bool(r.passthrough), num_voxels=m, offsets=offsets, indices=indices, voxel_xyz=vox)
+
+    def process_xyz(self, xyz, is_dense=True, layout=LAYOUT_AOS12):
+        flat, n = pack_points(xyz, layout)
+        r = Result()
+        self._chk(self.lib.pcop_process_xyz(self.h, flat.ctypes.data, layout, n, int(is_dense), MEM_HOST, C.byref(r)))
+        return self._result(r)
+
+    def process_device(self, dev_ptr, n, is_dense=True, layout=LAYOUT_SOA):
+        r = Result()
+        self._chk(self.lib.pcop_process_xyz(self.h, C.c_void_p(dev_ptr), layout, int(n), int(is_dense), MEM_DEVICE,
+                                            C.byref(r)))
+        return self._result(r)
+
+    def submit_device(self, dev_ptr, n, is_dense=True, layout=LAYOUT_SOA):
+        self._chk(self.lib.pcop_submit_xyz(self.h, C.c_void_p(dev_ptr), layout, int(n), int(is_dense), MEM_DEVICE))
+
+    def wait(self, want_arrays=True):
+        r = Result()
+        self._chk(self.lib.pcop_wait(self.h, C.byref(r)))
+        if not want_arrays:
+            return dict(passthrough=bool(r.passthrough), num_voxels=r.num_voxels, num_clusters=r.num_clusters,
+                        num_indices=r.num_indices)
+        return self._result(r)
+
+    def process_pointcloud2(self, data, width, height, point_step, row_step, off_x, off_y, off_z,
+                            is_bigendian=False, is_dense=True):
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        r = Result()
+        self._chk(self.lib.pcop_process_pointcloud2(self.h, buf.ctypes.data, width, height, point_step, row_step,
+                                                    off_x, off_y, off_z, int(is_bigendian), int(is_dense),
+                                                    C.byref(r)))
+        return self._result(r)
+
+    def cluster_summaries(self, k):
+        out = np.zeros((max(k, 1), 4), dtype=np.float32)
+        self._chk(self.lib.pcop_cluster_summaries(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), int(k)))
+        return out[:k]
+
+    # ---- device memory helpers ----------------------------------------------------------
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.pcop_dev_alloc(self.h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        self._chk(self.lib.pcop_dev_free(self.h, C.c_void_p(ptr)))
+
+    def upload_soa(self, xyz):
+        """(n,3) float32 -> device pointer of SoA planes x[n] y[n] z[n]."""
+        flat, n = pack_points(xyz, LAYOUT_SOA)
+        ptr = self.dev_alloc(flat.nbytes)
+        self._chk(self.lib.pcop_dev_upload(self.h, C.c_void_p(ptr), flat.ctypes.data, flat.nbytes))
+        return ptr, n
+
+    def debug_buffer(self, name, dtype, count):
+        p, b = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.pcop_debug_buffer(self.h, name.encode(), C.byref(p), C.byref(b)))
+        out = np.zeros(count, dtype=dtype)
+        assert out.nbytes <= b.value
+        if out.nbytes:
+            self._chk(self.lib.pcop_dev_download(self.h, out.ctypes.data, p, out.nbytes))
+        return out
+
+    def debug_state(self):
+        p, b = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.pcop_debug_buffer(self.h, b"state", C.byref(p), C.byref(b)))
+        st = DevState()
+        assert C.sizeof(st) == b.value, (C.sizeof(st), b.value)
+        self._chk(self.lib.pcop_dev_download(self.h, C.addressof(st), p, b.value))
+        return st
+
+    def stage_times(self):
+        t = StageTimes()
+        self._chk(self.lib.pcop_get_stage_times(self.h, C.byref(t)))
+        return [(t.name[i].decode(), float(t.ms[i])) for i in range(t.count)]

@@ -1,0 +1,713 @@
+// pcop_capi.hip — the C ABI of include/pcop.h on top of the gfx950 kernels in pcop_device.hpp.
+//
+// One context = one GPU + one HIP stream + all the frame's buffers.  A frame is enqueued as a
+// fixed sequence of launches whose data-dependent sizes live in device memory (DevState); the
+// host syncs once to read the state, and once more after copying out exactly the bytes the
+// frame produced.  There is no CPU fallback: without a HIP device pcop_create fails.
+#include "../../include/pcop.h"
+#include "pcop_device.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace pcop;
+
+namespace {
+
+struct ClusterRef {
+    int32_t size;
+    int32_t id;   // discovery order
+};
+// pcl::comparePointClusters: a.indices.size() < b.indices.size()
+inline bool compare_clusters(const ClusterRef& a, const ClusterRef& b) { return a.size < b.size; }
+
+enum FrameKind { kFrameChain = 0, kFrameVoxelOnly = 1, kFrameClusterOnly = 2 };
+
+}  // namespace
+
+struct pcop_ctx {
+    int device = -1;
+    size_t cap = 0;               // max_points
+    hipStream_t stream = nullptr;
+    pcop_params params{};
+    bool params_set = false;
+    std::string err;
+
+    // device buffers
+    float *in_x = nullptr, *in_y = nullptr, *in_z = nullptr;      // staged input cloud (SoA)
+    float *cen_x = nullptr, *cen_y = nullptr, *cen_z = nullptr;   // voxel centroids (SoA)
+    float4 *rec_a = nullptr, *rec_b = nullptr;                    // partition ping-pong
+    uint32_t *table = nullptr, *table_x = nullptr, *seg_sum = nullptr, *bin_total = nullptr;
+    uint32_t *tile_heads = nullptr;
+    uint2* tile_sums = nullptr;
+    MinMaxPartial* partials = nullptr;
+    uint32_t *rec_cell = nullptr, *cell_key = nullptr, *cell_start = nullptr, *cell_minidx = nullptr;
+    uint32_t *parent = nullptr, *cell_root = nullptr, *comp_size = nullptr, *comp_min = nullptr;
+    uint32_t *kept_val = nullptr, *rank_at = nullptr, *label = nullptr;
+    uint32_t *idx_a = nullptr, *idx_b = nullptr, *d_offsets = nullptr;
+    float* d_pack = nullptr;      // packed output cloud (16 B/pt worst case)
+    float4* d_xyzr = nullptr;
+    uint8_t* d_raw = nullptr;     // raw input bytes (AoS / PointCloud2), grown on demand
+    size_t d_raw_bytes = 0;
+    DevState* d_state = nullptr;
+    std::vector<void*> user_allocs;
+
+    // pinned host buffers
+    DevState* h_state = nullptr;
+    int32_t *h_offsets_disc = nullptr, *h_indices_disc = nullptr;   // discovery order, as the GPU wrote them
+    int32_t *h_offsets = nullptr, *h_indices = nullptr;             // PCL order
+    float* h_vox = nullptr;
+    float* h_xyzr = nullptr;
+    std::vector<int32_t> order;   // order[c] = discovery id of output cluster c
+
+    // current frame
+    const float *src_x = nullptr, *src_y = nullptr, *src_z = nullptr;   // device planes the frame reads
+    uint32_t n = 0;
+    int is_dense = 1;
+    FrameKind kind = kFrameChain;
+    bool in_flight = false;
+    bool have_result = false;
+    bool result_trivial = false;  // r2 == 0: every point is its own component (built on the host)
+    uint32_t npass_voxel = kMaxPasses, npass_cell = kMaxPasses, npass_csr = kMaxPasses;
+    uint32_t* frame_csr_idx = nullptr;   // device CSR indices of the frame in flight / last frame
+    int radix_bits_target = 8;    // preferred digit width when choosing pass counts
+
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    std::vector<const char*> ev_names;
+    size_t ev_used = 0;
+    pcop_stage_times times{};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            char buf_[512];                                                                      \
+            snprintf(buf_, sizeof(buf_), "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            (ctx)->err = buf_;                                                                   \
+            return PCOP_ERR_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+template <class T>
+int dev_alloc(pcop_ctx* c, T** p, size_t count) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)));
+    return PCOP_OK;
+}
+template <class T>
+int host_alloc(pcop_ctx* c, T** p, size_t count) {
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+    return PCOP_OK;
+}
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// stage marker for profiling: an event after each named group of launches
+void mark(pcop_ctx* c, const char* name) {
+    if (!c->profiling) return;
+    if (c->ev_used >= c->events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->events.push_back(e);
+        c->ev_names.push_back(name);
+    }
+    c->ev_names[c->ev_used] = name;
+    hipEventRecord(c->events[c->ev_used], c->stream);
+    ++c->ev_used;
+}
+
+uint32_t partition_grid(uint32_t n) { return std::max(1u, div_up(n, kTile)); }
+uint32_t scan_grid(uint32_t n) { return std::max(1u, div_up(n, kScanTile)); }
+uint32_t stride_grid(uint32_t n) { return std::min(2048u, std::max(1u, div_up(n, kBlock))); }
+
+void launch_table_scan(pcop_ctx* c, int which, int pass) {
+    dim3 g(div_up(kMaxBins, kBlock), kSegs);
+    k_table_colsum<<<g, kBlock, 0, c->stream>>>(c->d_state, which, pass, c->table, c->seg_sum);
+    k_table_colscan<<<g, kBlock, 0, c->stream>>>(c->d_state, which, pass, c->table, c->seg_sum, c->table_x, c->bin_total);
+}
+
+// Stable LSD partition by the voxel (which=0) or cell (which=1) key; returns the sorted buffer.
+template <class KeyFn>
+float4* launch_partition(pcop_ctx* c, int which, uint32_t npass, uint32_t n_max, SoaSrc s_a, SoaSrc s_b,
+                         const char* const* names) {
+    const uint32_t g = partition_grid(n_max);
+    float4* bufs[2] = {c->rec_a, c->rec_b};
+    float4* out = nullptr;
+    for (uint32_t p = 0; p < npass; ++p) {
+        out = bufs[p & 1];
+        if (p == 0) {
+            k_radix_hist<SoaSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(s_a, s_b, c->d_state, which, (int)p, c->table);
+            launch_table_scan(c, which, (int)p);
+            k_radix_scatter<SoaSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(s_a, s_b, c->d_state, which, (int)p, c->table_x,
+                                                                        c->bin_total, out);
+        } else {
+            RecSrc r{bufs[(p - 1) & 1]};
+            k_radix_hist<RecSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(r, r, c->d_state, which, (int)p, c->table);
+            launch_table_scan(c, which, (int)p);
+            k_radix_scatter<RecSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(r, r, c->d_state, which, (int)p, c->table_x,
+                                                                        c->bin_total, out);
+        }
+        mark(c, names[p]);
+    }
+    return out;
+}
+
+const char* const kVoxelPassNames[kMaxPasses] = {"voxel_partition_0", "voxel_partition_1", "voxel_partition_2"};
+const char* const kCellPassNames[kMaxPasses] = {"cell_partition_0", "cell_partition_1", "cell_partition_2"};
+const char* const kCsrPassNames[kMaxPasses] = {"csr_partition_0", "csr_partition_1", "csr_partition_2"};
+
+void enqueue_voxel(pcop_ctx* c) {
+    const uint32_t n = c->n;
+    SoaPair src{nullptr, nullptr, nullptr, c->src_x, c->src_y, c->src_z};
+    k_minmax<<<kReduceBlocks, kBlock, 0, c->stream>>>(src, c->d_state, 0, c->partials);
+    k_voxel_setup<<<1, kBlock, 0, c->stream>>>(c->d_state, c->partials, kReduceBlocks, c->npass_voxel);
+    mark(c, "voxel_minmax_setup");
+    SoaSrc s{c->src_x, c->src_y, c->src_z};
+    float4* sorted = launch_partition<VoxelKey>(c, 0, c->npass_voxel, n, s, s, kVoxelPassNames);
+    const uint32_t sg = scan_grid(n);
+    k_heads_count<VoxelKey><<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, 0, c->tile_heads);
+    k_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_heads, c->d_state, 0, 0);
+    k_voxel_reduce<<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->tile_heads, c->cen_x, c->cen_y, c->cen_z);
+    k_voxel_passthrough<<<1, 64, 0, c->stream>>>(c->d_state);
+    mark(c, "voxel_heads_reduce");
+}
+
+void enqueue_cluster(pcop_ctx* c, int force_input) {
+    const uint32_t n = c->n;   // upper bound of c_n
+    k_cluster_source<<<1, 64, 0, c->stream>>>(c->d_state, force_input);
+    SoaPair src{c->cen_x, c->cen_y, c->cen_z, c->src_x, c->src_y, c->src_z};
+    k_minmax<<<kReduceBlocks, kBlock, 0, c->stream>>>(src, c->d_state, 1, c->partials);
+    k_cell_setup<<<1, kBlock, 0, c->stream>>>(c->d_state, c->partials, kReduceBlocks, c->npass_cell);
+    mark(c, "cell_minmax_setup");
+    SoaSrc s_a{c->cen_x, c->cen_y, c->cen_z}, s_b{c->src_x, c->src_y, c->src_z};
+    float4* sorted = launch_partition<CellKey>(c, 1, c->npass_cell, n, s_a, s_b, kCellPassNames);
+    const uint32_t sg = scan_grid(n);
+    k_heads_count<CellKey><<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, 1, c->tile_heads);
+    k_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_heads, c->d_state, 1, 1);
+    k_cells_build<<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->tile_heads, c->rec_cell, c->cell_key, c->cell_start,
+                                                 c->cell_minidx, c->parent, c->comp_size, c->comp_min, c->kept_val);
+    mark(c, "cell_heads_build");
+    const uint32_t ug = std::min(8192u, std::max(1u, div_up(n, kWavesPerBlock)));
+    k_cell_union<<<ug, kBlock, 0, c->stream>>>(sorted, c->d_state, c->cell_key, c->cell_start, c->parent);
+    mark(c, "cell_union");
+    const uint32_t tg = stride_grid(n);
+    k_cell_flatten<<<tg, kBlock, 0, c->stream>>>(c->d_state, c->cell_start, c->cell_minidx, c->parent, c->cell_root,
+                                                  c->comp_size, c->comp_min);
+    k_mark_kept<<<tg, kBlock, 0, c->stream>>>(c->d_state, c->cell_root, c->comp_size, c->comp_min, c->kept_val);
+    k_kept_count<<<sg, kBlock, 0, c->stream>>>(c->d_state, c->kept_val, c->tile_sums);
+    k_kept_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_sums, c->d_state, c->d_offsets, c->npass_csr);
+    k_kept_apply<<<sg, kBlock, 0, c->stream>>>(c->d_state, c->kept_val, c->tile_sums, c->rank_at, c->d_offsets);
+    k_label_points<<<tg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->rec_cell, c->cell_root, c->comp_size, c->comp_min,
+                                                  c->rank_at, c->label);
+    mark(c, "components_label");
+    const uint32_t g = partition_grid(n);
+    uint32_t* bufs[2] = {c->idx_a, c->idx_b};
+    for (uint32_t p = 0; p < c->npass_csr; ++p) {
+        const uint32_t* in = p == 0 ? nullptr : bufs[(p - 1) & 1];
+        k_csr_hist<<<g, kBlock, 0, c->stream>>>(in, c->label, c->d_state, (int)p, c->table);
+        launch_table_scan(c, 2, (int)p);
+        k_csr_scatter<<<g, kBlock, 0, c->stream>>>(in, c->label, c->d_state, (int)p, c->table_x, c->bin_total, bufs[p & 1]);
+        mark(c, kCsrPassNames[p]);
+    }
+    c->frame_csr_idx = bufs[(c->npass_csr - 1) & 1];
+}
+
+int enqueue_frame(pcop_ctx* c) {
+    const pcop_params& p = c->params;
+    const float inv_leaf = 1.0f / p.leaf;                         // Array4f::Ones() / leaf_size_
+    const double radius = (double)p.tol;
+    const float r2 = (float)(radius * radius);                    // KdTreeFLANN::radiusSearch
+    const double inv_cell = 1.99 / std::fabs((double)p.tol);
+    c->result_trivial = !(r2 > 0.0f);
+    c->ev_used = 0;
+    mark(c, "start");
+    k_frame_init<<<1, 64, 0, c->stream>>>(c->d_state, c->n, (uint32_t)(c->is_dense ? 1 : 0), inv_leaf, r2,
+                                          c->result_trivial ? 1.0 : inv_cell, (uint32_t)p.min_cluster,
+                                          (uint32_t)p.max_cluster);
+    if (c->kind != kFrameClusterOnly) enqueue_voxel(c);
+    if (c->kind != kFrameVoxelOnly && !c->result_trivial) enqueue_cluster(c, c->kind == kFrameClusterOnly ? 1 : 0);
+    else if (c->kind != kFrameVoxelOnly) k_cluster_source<<<1, 64, 0, c->stream>>>(c->d_state, c->kind == kFrameClusterOnly ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    mark(c, "state_d2h");
+    c->in_flight = true;
+    c->have_result = false;
+    return PCOP_OK;
+}
+
+uint32_t passes_for(uint32_t key_bits, int target_bits) {
+    uint32_t p = (key_bits + (uint32_t)target_bits - 1) / (uint32_t)target_bits;
+    const uint32_t pmin = (key_bits + kMaxBits - 1) / kMaxBits;
+    p = std::max(p, pmin);
+    return std::min<uint32_t>(std::max<uint32_t>(p, 1u), kMaxPasses);
+}
+
+void collect_times(pcop_ctx* c) {
+    c->times.count = 0;
+    if (!c->profiling || c->ev_used < 2) return;
+    for (size_t i = 1; i < c->ev_used && c->times.count < PCOP_MAX_STAGES; ++i) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->events[i - 1], c->events[i]) != hipSuccess) ms = -1.0f;
+        c->times.name[c->times.count] = c->ev_names[i];
+        c->times.ms[c->times.count] = ms;
+        ++c->times.count;
+    }
+}
+
+// Waits for the frame, re-running it when a radix plan was too short, then copies out exactly
+// what was produced and puts the clusters in PCL's order.
+int finish_frame(pcop_ctx* c, pcop_result* out) {
+    if (!c->in_flight) return PCOP_ERR_STATE;
+    DevState* hs = c->h_state;
+    for (int attempt = 0;; ++attempt) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint32_t e = hs->err;
+        if (e & kErrNonFinite) { c->in_flight = false; c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
+        if (e & kErrRange) { c->in_flight = false; c->err = "neighbour cell grid exceeds 2^32 cells (extent / tolerance too large)"; return PCOP_ERR_RANGE; }
+        if (e & (kErrReplanVoxel | kErrReplanCell | kErrReplanCsr)) {
+            if (attempt >= 4) { c->in_flight = false; c->err = "radix replanning did not converge"; return PCOP_ERR_STATE; }
+            if (e & kErrReplanVoxel) c->npass_voxel = passes_for(hs->plan_voxel.key_bits, c->radix_bits_target);
+            if (e & kErrReplanCell) c->npass_cell = passes_for(hs->plan_cell.key_bits, c->radix_bits_target);
+            if (e & kErrReplanCsr) c->npass_csr = passes_for(hs->plan_csr.key_bits, c->radix_bits_target);
+            int rc = enqueue_frame(c);
+            if (rc) return rc;
+            continue;
+        }
+        break;
+    }
+    collect_times(c);
+    c->in_flight = false;
+    // adapt the pass counts of the next frame to what this one needed
+    if (c->kind != kFrameClusterOnly && !hs->passthrough) c->npass_voxel = passes_for(hs->plan_voxel.key_bits, c->radix_bits_target);
+    const uint32_t m = hs->m;
+    const bool clustered = c->kind != kFrameVoxelOnly;
+    uint32_t k = 0, total = 0;
+    if (clustered && !c->result_trivial) {
+        c->npass_cell = passes_for(hs->plan_cell.key_bits, c->radix_bits_target);
+        k = hs->n_kept; total = hs->n_kept_pts;
+        // npass_csr is changed only after this frame's indices have been located
+        if (k) {
+            HIPCHK(c, hipMemcpyAsync(c->h_offsets_disc, c->d_offsets, (size_t)(k + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_indices_disc, c->frame_csr_idx, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    const bool want_cloud = c->kind == kFrameChain && c->params.publish_clouds != 0;
+    if (want_cloud && m) {
+        const float *px = hs->passthrough ? c->src_x : c->cen_x, *py = hs->passthrough ? c->src_y : c->cen_y,
+                    *pz = hs->passthrough ? c->src_z : c->cen_z;
+        k_pack_points<<<stride_grid(m), kBlock, 0, c->stream>>>(px, py, pz, &c->d_state->m, PCOP_LAYOUT_AOS12, 0, c->d_pack);
+        HIPCHK(c, hipMemcpyAsync(c->h_vox, c->d_pack, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (clustered && !c->result_trivial) c->npass_csr = passes_for(hs->plan_csr.key_bits, c->radix_bits_target);
+
+    // extract(): std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters)
+    const uint32_t c_n = clustered ? hs->c_n : 0;
+    if (clustered && c->result_trivial) {
+        // r2 == 0: radiusSearch returns nothing, every point is a cluster of one
+        const pcop_params& p = c->params;
+        const bool keep = (uint32_t)p.min_cluster <= 1u && 1u <= (uint32_t)p.max_cluster;
+        k = keep ? c_n : 0; total = k;
+        for (uint32_t i = 0; i < k; ++i) { c->h_offsets_disc[i] = (int32_t)i; c->h_indices_disc[i] = (int32_t)i; }
+        c->h_offsets_disc[k] = (int32_t)k;
+    }
+    std::vector<ClusterRef> refs(k);
+    for (uint32_t i = 0; i < k; ++i) refs[i] = {c->h_offsets_disc[i + 1] - c->h_offsets_disc[i], (int32_t)i};
+    std::sort(refs.rbegin(), refs.rend(), compare_clusters);
+    c->order.resize(k);
+    int32_t pos = 0;
+    c->h_offsets[0] = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        const int32_t id = refs[i].id;
+        c->order[i] = id;
+        const int32_t b = c->h_offsets_disc[id], sz = refs[i].size;
+        std::memcpy(c->h_indices + pos, c->h_indices_disc + b, (size_t)sz * 4);
+        pos += sz;
+        c->h_offsets[i + 1] = pos;
+    }
+    c->have_result = clustered;
+    if (out) {
+        out->passthrough = (int32_t)hs->passthrough;
+        out->num_voxels = (int32_t)m;
+        out->num_clusters = (int32_t)k;
+        out->num_indices = pos;
+        out->offsets = c->h_offsets;
+        out->indices = c->h_indices;
+        out->voxel_xyz = (want_cloud && m) ? c->h_vox : nullptr;
+    }
+    return PCOP_OK;
+}
+
+int check_params(pcop_ctx* c, bool need_leaf, bool need_tol) {
+    if (!c->params_set) { c->err = "pcop_set_params was not called"; return PCOP_ERR_STATE; }
+    const pcop_params& p = c->params;
+    if (need_leaf && !(p.leaf > 0.0f && std::isfinite(p.leaf))) { c->err = "downsample_size must be finite and > 0"; return PCOP_ERR_PARAM; }
+    if (need_tol && !(std::isfinite(p.tol) && std::fabs(p.tol) < 1e18f)) { c->err = "euc_cluster_tolerance must be finite"; return PCOP_ERR_PARAM; }
+    return PCOP_OK;
+}
+
+int ensure_raw(pcop_ctx* c, size_t bytes) {
+    if (bytes <= c->d_raw_bytes) return PCOP_OK;
+    if (c->d_raw) { HIPCHK(c, hipFree(c->d_raw)); c->d_raw = nullptr; c->d_raw_bytes = 0; }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_raw), bytes));
+    c->d_raw_bytes = bytes;
+    return PCOP_OK;
+}
+
+// Put an n-point cloud (host or device, any layout) where the kernels read it: SoA planes in HBM.
+int stage_input(pcop_ctx* c, const float* xyz, int layout, size_t n, int mem) {
+    if (n > c->cap) { c->err = "n exceeds max_points of the context"; return PCOP_ERR_CAPACITY; }
+    if (!xyz && n) return PCOP_ERR_ARG;
+    if (layout != PCOP_LAYOUT_AOS16 && layout != PCOP_LAYOUT_SOA && layout != PCOP_LAYOUT_AOS12) return PCOP_ERR_ARG;
+    c->n = (uint32_t)n;
+    if (mem == PCOP_MEM_DEVICE && layout == PCOP_LAYOUT_SOA) {   // read the caller's planes in place
+        c->src_x = xyz; c->src_y = xyz + n; c->src_z = xyz + 2 * n;
+        return PCOP_OK;
+    }
+    c->src_x = c->in_x; c->src_y = c->in_y; c->src_z = c->in_z;
+    if (n == 0) return PCOP_OK;
+    if (layout == PCOP_LAYOUT_SOA) {   // host planes
+        HIPCHK(c, hipMemcpyAsync(c->in_x, xyz, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->in_y, xyz + n, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->in_z, xyz + 2 * n, n * 4, hipMemcpyHostToDevice, c->stream));
+        return PCOP_OK;
+    }
+    const uint32_t step = layout == PCOP_LAYOUT_AOS16 ? 16u : 12u;
+    const uint8_t* raw = reinterpret_cast<const uint8_t*>(xyz);
+    if (mem == PCOP_MEM_HOST) {
+        int rc = ensure_raw(c, n * step);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->d_raw, xyz, n * step, hipMemcpyHostToDevice, c->stream));
+        raw = c->d_raw;
+    }
+    k_unpack_points<<<stride_grid((uint32_t)n), kBlock, 0, c->stream>>>(raw, (uint32_t)n, step, 0, 4, 8, 0, c->in_x, c->in_y, c->in_z);
+    HIPCHK(c, hipGetLastError());
+    return PCOP_OK;
+}
+
+int set_device(pcop_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    return PCOP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcop_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* pcop_status_string(int s) {
+    switch (s) {
+        case PCOP_OK: return "ok";
+        case PCOP_ERR_ARG: return "bad argument";
+        case PCOP_ERR_PARAM: return "bad parameter";
+        case PCOP_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+        case PCOP_ERR_HIP: return "HIP runtime error";
+        case PCOP_ERR_CAPACITY: return "cloud larger than the context's max_points";
+        case PCOP_ERR_NONFINITE: return "non-finite coordinates";
+        case PCOP_ERR_RANGE: return "neighbour grid too large";
+        case PCOP_ERR_STATE: return "bad call order";
+        default: return "unknown status";
+    }
+}
+
+int pcop_create(pcop_ctx** out, int device_id, size_t max_points) {
+    if (!out) return PCOP_ERR_ARG;
+    *out = nullptr;
+    if (max_points == 0 || max_points > 0x7FFFFFF0ull) return PCOP_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PCOP_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= ndev) return PCOP_ERR_NO_DEVICE;
+    pcop_ctx* c = new (std::nothrow) pcop_ctx();
+    if (!c) return PCOP_ERR_ARG;
+    c->device = device_id;
+    c->cap = max_points;
+    if (const char* e = getenv("PCOP_RADIX_BITS")) {
+        const int b = atoi(e);
+        if (b >= 4 && b <= kMaxBits) c->radix_bits_target = b;
+    }
+    int rc = PCOP_OK;
+    const size_t n = max_points;
+    const size_t ntiles = (n + kTile - 1) / kTile + 1;
+    const size_t nscan = (n + kScanTile - 1) / kScanTile + 1;
+#define TRY(x) do { rc = (x); if (rc) { std::string m_ = c->err; fprintf(stderr, "pcop_create: %s\n", m_.c_str()); pcop_destroy(c); return rc; } } while (0)
+    if (hipSetDevice(device_id) != hipSuccess) { delete c; return PCOP_ERR_NO_DEVICE; }
+    { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return PCOP_ERR_HIP; } }
+    TRY(dev_alloc(c, &c->in_x, n)); TRY(dev_alloc(c, &c->in_y, n)); TRY(dev_alloc(c, &c->in_z, n));
+    TRY(dev_alloc(c, &c->cen_x, n)); TRY(dev_alloc(c, &c->cen_y, n)); TRY(dev_alloc(c, &c->cen_z, n));
+    TRY(dev_alloc(c, &c->rec_a, n)); TRY(dev_alloc(c, &c->rec_b, n));
+    TRY(dev_alloc(c, &c->table, ntiles * kMaxBins)); TRY(dev_alloc(c, &c->table_x, ntiles * kMaxBins));
+    TRY(dev_alloc(c, &c->seg_sum, (size_t)kSegs * kMaxBins)); TRY(dev_alloc(c, &c->bin_total, (size_t)kMaxBins));
+    TRY(dev_alloc(c, &c->tile_heads, nscan)); TRY(dev_alloc(c, &c->tile_sums, nscan));
+    TRY(dev_alloc(c, &c->partials, (size_t)kReduceBlocks));
+    TRY(dev_alloc(c, &c->rec_cell, n)); TRY(dev_alloc(c, &c->cell_key, n + 1)); TRY(dev_alloc(c, &c->cell_start, n + 2));
+    TRY(dev_alloc(c, &c->cell_minidx, n + 1)); TRY(dev_alloc(c, &c->parent, n + 1)); TRY(dev_alloc(c, &c->cell_root, n + 1));
+    TRY(dev_alloc(c, &c->comp_size, n + 1)); TRY(dev_alloc(c, &c->comp_min, n + 1));
+    TRY(dev_alloc(c, &c->kept_val, n + 1)); TRY(dev_alloc(c, &c->rank_at, n + 1)); TRY(dev_alloc(c, &c->label, n + 1));
+    TRY(dev_alloc(c, &c->idx_a, n + 1)); TRY(dev_alloc(c, &c->idx_b, n + 1)); TRY(dev_alloc(c, &c->d_offsets, n + 2));
+    TRY(dev_alloc(c, &c->d_pack, 4 * n)); TRY(dev_alloc(c, &c->d_xyzr, n + 1));
+    TRY(dev_alloc(c, &c->d_state, 1));
+    TRY(host_alloc(c, &c->h_state, 1));
+    TRY(host_alloc(c, &c->h_offsets_disc, n + 2)); TRY(host_alloc(c, &c->h_indices_disc, n + 1));
+    TRY(host_alloc(c, &c->h_offsets, n + 2)); TRY(host_alloc(c, &c->h_indices, n + 1));
+    TRY(host_alloc(c, &c->h_vox, 3 * n)); TRY(host_alloc(c, &c->h_xyzr, 4 * (n + 1)));
+#undef TRY
+    std::memset(c->h_state, 0, sizeof(DevState));
+    *out = c;
+    return PCOP_OK;
+}
+
+void pcop_destroy(pcop_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void* dev[] = {c->in_x, c->in_y, c->in_z, c->cen_x, c->cen_y, c->cen_z, c->rec_a, c->rec_b, c->table, c->table_x,
+                   c->seg_sum, c->bin_total, c->tile_heads, c->tile_sums, c->partials, c->rec_cell, c->cell_key,
+                   c->cell_start, c->cell_minidx, c->parent, c->cell_root, c->comp_size, c->comp_min, c->kept_val,
+                   c->rank_at, c->label, c->idx_a, c->idx_b, c->d_offsets, c->d_pack, c->d_xyzr, c->d_raw, c->d_state};
+    for (void* p : dev) if (p) hipFree(p);
+    for (void* p : c->user_allocs) if (p) hipFree(p);
+    void* host[] = {c->h_state, c->h_offsets_disc, c->h_indices_disc, c->h_offsets, c->h_indices, c->h_vox, c->h_xyzr};
+    for (void* p : host) if (p) hipHostFree(p);
+    for (hipEvent_t e : c->events) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pcop_set_params(pcop_ctx* c, const pcop_params* p) {
+    if (!c || !p) return PCOP_ERR_ARG;
+    c->params = *p;
+    c->params_set = true;
+    return PCOP_OK;
+}
+
+int pcop_get_params(const pcop_ctx* c, pcop_params* p) {
+    if (!c || !p) return PCOP_ERR_ARG;
+    *p = c->params;
+    return PCOP_OK;
+}
+
+const char* pcop_last_error(const pcop_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int pcop_set_profiling(pcop_ctx* c, int enable) {
+    if (!c) return PCOP_ERR_ARG;
+    c->profiling = enable != 0;
+    return PCOP_OK;
+}
+
+int pcop_get_stage_times(const pcop_ctx* c, pcop_stage_times* out) {
+    if (!c || !out) return PCOP_ERR_ARG;
+    *out = c->times;
+    return PCOP_OK;
+}
+
+void* pcop_stream(const pcop_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int pcop_voxel_downsample(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, float* out_xyz,
+                          size_t* out_m, int* passthrough) {
+    if (!c || !out_m || !passthrough || (!out_xyz && n)) return PCOP_ERR_ARG;
+    int rc = check_params(c, true, false);
+    if (rc) return rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = stage_input(c, xyz, layout, n, PCOP_MEM_HOST))) return rc;
+    c->is_dense = is_dense; c->kind = kFrameVoxelOnly;
+    if ((rc = enqueue_frame(c))) return rc;
+    pcop_result r{};
+    if ((rc = finish_frame(c, &r))) return rc;
+    *out_m = (size_t)r.num_voxels;
+    *passthrough = r.passthrough;
+    if (r.num_voxels == 0) return PCOP_OK;
+    if (r.passthrough) {   // "output = *input_"
+        const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
+        std::memcpy(out_xyz, xyz, n * fl * sizeof(float));
+        return PCOP_OK;
+    }
+    const uint32_t m = (uint32_t)r.num_voxels;
+    k_pack_points<<<stride_grid(m), kBlock, 0, c->stream>>>(c->cen_x, c->cen_y, c->cen_z, &c->d_state->m, layout, (uint32_t)n, c->d_pack);
+    HIPCHK(c, hipGetLastError());
+    if (layout == PCOP_LAYOUT_SOA) {
+        for (int a = 0; a < 3; ++a)
+            HIPCHK(c, hipMemcpyAsync(out_xyz + (size_t)a * n, c->d_pack + (size_t)a * n, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
+        HIPCHK(c, hipMemcpyAsync(out_xyz, c->d_pack, (size_t)m * fl * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PCOP_OK;
+}
+
+int pcop_euclidean_clusters(pcop_ctx* c, const float* xyz, int layout, size_t m, int32_t* offsets, int32_t* indices,
+                            int32_t* k) {
+    if (!c || !offsets || !k || (!indices && m)) return PCOP_ERR_ARG;
+    int rc = check_params(c, false, true);
+    if (rc) return rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = stage_input(c, xyz, layout, m, PCOP_MEM_HOST))) return rc;
+    c->is_dense = 1; c->kind = kFrameClusterOnly;
+    if ((rc = enqueue_frame(c))) return rc;
+    pcop_result r{};
+    if ((rc = finish_frame(c, &r))) return rc;
+    *k = r.num_clusters;
+    std::memcpy(offsets, r.offsets, (size_t)(r.num_clusters + 1) * 4);
+    if (r.num_indices) std::memcpy(indices, r.indices, (size_t)r.num_indices * 4);
+    return PCOP_OK;
+}
+
+int pcop_submit_xyz(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem) {
+    if (!c) return PCOP_ERR_ARG;
+    if (c->in_flight) { c->err = "a frame is already in flight on this context"; return PCOP_ERR_STATE; }
+    int rc = check_params(c, true, true);
+    if (rc) return rc;
+    if (mem != PCOP_MEM_HOST && mem != PCOP_MEM_DEVICE) return PCOP_ERR_ARG;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = stage_input(c, xyz, layout, n, mem))) return rc;
+    c->is_dense = is_dense; c->kind = kFrameChain;
+    return enqueue_frame(c);
+}
+
+int pcop_wait(pcop_ctx* c, pcop_result* out) {
+    if (!c) return PCOP_ERR_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    return finish_frame(c, out);
+}
+
+int pcop_process_xyz(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem, pcop_result* out) {
+    int rc = pcop_submit_xyz(c, xyz, layout, n, is_dense, mem);
+    if (rc) return rc;
+    return pcop_wait(c, out);
+}
+
+int pcop_process_pointcloud2(pcop_ctx* c, const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step,
+                             uint32_t row_step, uint32_t off_x, uint32_t off_y, uint32_t off_z, int is_bigendian,
+                             int is_dense, pcop_result* out) {
+    if (!c) return PCOP_ERR_ARG;
+    if (c->in_flight) { c->err = "a frame is already in flight on this context"; return PCOP_ERR_STATE; }
+    int rc = check_params(c, true, true);
+    if (rc) return rc;
+    const size_t n = (size_t)width * height;
+    if (n > c->cap) { c->err = "n exceeds max_points of the context"; return PCOP_ERR_CAPACITY; }
+    if (n && !data) return PCOP_ERR_ARG;
+    if (point_step < 4 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step) return PCOP_ERR_ARG;
+    if (n && row_step < (size_t)width * point_step) return PCOP_ERR_ARG;
+    if ((rc = set_device(c))) return rc;
+    c->n = (uint32_t)n;
+    c->src_x = c->in_x; c->src_y = c->in_y; c->src_z = c->in_z;
+    if (n) {
+        const size_t row_bytes = (size_t)width * point_step;
+        if ((rc = ensure_raw(c, n * point_step))) return rc;
+        if (row_step == row_bytes) {
+            HIPCHK(c, hipMemcpyAsync(c->d_raw, data, n * point_step, hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIPCHK(c, hipMemcpy2DAsync(c->d_raw, row_bytes, data, row_step, row_bytes, height, hipMemcpyHostToDevice, c->stream));
+        }
+        k_unpack_points<<<stride_grid((uint32_t)n), kBlock, 0, c->stream>>>(c->d_raw, (uint32_t)n, point_step, off_x, off_y, off_z,
+                                                                           is_bigendian, c->in_x, c->in_y, c->in_z);
+        HIPCHK(c, hipGetLastError());
+    }
+    c->is_dense = is_dense; c->kind = kFrameChain;
+    if ((rc = enqueue_frame(c))) return rc;
+    return finish_frame(c, out);
+}
+
+int pcop_cluster_summaries(pcop_ctx* c, float* xyzr, int32_t cap_clusters) {
+    if (!c || (!xyzr && cap_clusters)) return PCOP_ERR_ARG;
+    if (!c->have_result) { c->err = "no clustered frame on this context"; return PCOP_ERR_STATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const uint32_t k = (uint32_t)c->order.size();
+    if (k == 0) return PCOP_OK;
+    if ((uint32_t)cap_clusters < k) return PCOP_ERR_ARG;
+    SoaPair src{c->cen_x, c->cen_y, c->cen_z, c->src_x, c->src_y, c->src_z};
+    if (c->result_trivial) {
+        // singletons: centre = the point, r = 0; read the points back through the packed buffer
+        const bool from_input = c->h_state->c_from_input != 0;
+        const float *px = from_input ? c->src_x : c->cen_x, *py = from_input ? c->src_y : c->cen_y, *pz = from_input ? c->src_z : c->cen_z;
+        k_pack_points<<<stride_grid(k), kBlock, 0, c->stream>>>(px, py, pz, &c->d_state->c_n, PCOP_LAYOUT_AOS16, 0, c->d_pack);
+        HIPCHK(c, hipMemcpyAsync(c->h_xyzr, c->d_pack, (size_t)k * 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < k; ++i) {
+            const float* s = c->h_xyzr + 4 * (size_t)c->order[i];
+            xyzr[4 * i] = s[0]; xyzr[4 * i + 1] = s[1]; xyzr[4 * i + 2] = s[2]; xyzr[4 * i + 3] = 0.0f;
+        }
+        return PCOP_OK;
+    }
+    k_cluster_summaries<<<std::min(2048u, std::max(1u, div_up(k, kWavesPerBlock))), kBlock, 0, c->stream>>>(
+        src, c->d_state, c->d_offsets, c->frame_csr_idx, c->d_xyzr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_xyzr, c->d_xyzr, (size_t)k * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < k; ++i) std::memcpy(xyzr + 4 * (size_t)i, c->h_xyzr + 4 * (size_t)c->order[i], 16);
+    return PCOP_OK;
+}
+
+int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* bytes) {
+    if (!c || !name || !dev_ptr || !bytes) return PCOP_ERR_ARG;
+    const size_t n = c->cap;
+    struct Ent { const char* nm; void* p; size_t b; };
+    const Ent tab[] = {
+        {"state", c->d_state, sizeof(DevState)},
+        {"cen_x", c->cen_x, n * 4}, {"cen_y", c->cen_y, n * 4}, {"cen_z", c->cen_z, n * 4},
+        {"rec_a", c->rec_a, n * 16}, {"rec_b", c->rec_b, n * 16},
+        {"cell_key", c->cell_key, n * 4}, {"cell_start", c->cell_start, (n + 1) * 4}, {"cell_minidx", c->cell_minidx, n * 4},
+        {"parent", c->parent, n * 4}, {"cell_root", c->cell_root, n * 4}, {"comp_size", c->comp_size, n * 4},
+        {"comp_min", c->comp_min, n * 4}, {"kept_val", c->kept_val, n * 4}, {"rank_at", c->rank_at, n * 4},
+        {"label", c->label, n * 4}, {"rec_cell", c->rec_cell, n * 4}, {"idx_a", c->idx_a, n * 4}, {"idx_b", c->idx_b, n * 4},
+        {"d_offsets", c->d_offsets, (n + 1) * 4}, {"bin_total", c->bin_total, (size_t)kMaxBins * 4},
+    };
+    for (const Ent& e : tab) {
+        if (std::strcmp(e.nm, name) == 0) { *dev_ptr = e.p; *bytes = e.b; return PCOP_OK; }
+    }
+    return PCOP_ERR_ARG;
+}
+
+int pcop_dev_alloc(pcop_ctx* c, size_t bytes, void** dev_ptr) {
+    if (!c || !dev_ptr) return PCOP_ERR_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, std::max<size_t>(bytes, 1)));
+    c->user_allocs.push_back(p);
+    *dev_ptr = p;
+    return PCOP_OK;
+}
+
+int pcop_dev_free(pcop_ctx* c, void* p) {
+    if (!c) return PCOP_ERR_ARG;
+    for (auto& q : c->user_allocs) {
+        if (q == p && p) { hipSetDevice(c->device); hipFree(p); q = nullptr; return PCOP_OK; }
+    }
+    return PCOP_ERR_ARG;
+}
+
+int pcop_dev_upload(pcop_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return PCOP_ERR_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return PCOP_OK;
+}
+
+int pcop_dev_download(pcop_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return PCOP_ERR_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return PCOP_OK;
+}
+
+}  // extern "C"

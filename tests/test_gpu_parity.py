@@ -1,0 +1,365 @@
+"""Parity of the HIP path (through the C ABI, libpcop.so) against the CPU oracle.
+
+Integer/index results must be bit-exact; voxel centroids are compared bit-exactly too
+(north star allows 1e-4; the canonical summation order makes them equal by construction).
+"""
+import numpy as np
+import pytest
+
+from pointcloud_obstacle_processing_amd import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pointcloud_obstacle_processing_amd import capi as m
+    m.load_library()
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(1_100_000)
+    yield c
+    c.close()
+
+
+def assert_same_cloud(got, ref):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if got.tobytes() != ref.tobytes():
+        bad = np.flatnonzero((got.view(np.uint32) != ref.view(np.uint32)).any(axis=1))
+        raise AssertionError("centroids differ at %d rows, first %s: %s vs %s" %
+                             (len(bad), bad[:5], got[bad[0]], ref[bad[0]]))
+    # the looser bound the north star states, written out
+    assert np.max(np.abs(got - ref), initial=0.0) <= 1e-4
+
+
+def assert_same_clusters(got_off, got_idx, ref_off, ref_idx):
+    assert np.array_equal(got_off, ref_off), (np.diff(got_off)[:10], np.diff(ref_off)[:10])
+    assert np.array_equal(got_idx, ref_idx)
+
+
+# ---------------------------------------------------------------------------------------------
+# known-answer tests of SURVEY.md §8c, through the GPU
+# ---------------------------------------------------------------------------------------------
+def test_kat1_strict_radius(ctx):
+    pts = np.array([[0, 0, 0], [0.5, 0, 0]], dtype=f32)
+    ctx.set_params(leaf=0.05, tol=0.5, min_cluster=1, max_cluster=10)
+    off, idx = ctx.euclidean_clusters(pts)
+    assert list(np.diff(off)) == [1, 1]
+    ctx.set_params(leaf=0.05, tol=np.nextafter(f32(0.5), f32(1)), min_cluster=1, max_cluster=10)
+    off, idx = ctx.euclidean_clusters(pts)
+    assert list(np.diff(off)) == [2] and list(idx) == [0, 1]
+
+
+def test_kat2_kat3_order_and_negative(ctx, oracle):
+    ctx.set_params(leaf=0.05, tol=0.1)
+    pts = np.array([[0.01, 0.01, 0.11], [0.01, 0.06, 0.01], [0.06, 0.01, 0.01], [0.01, 0.01, 0.01]], dtype=f32)
+    vox, pt = ctx.voxel_downsample(pts)
+    assert not pt and np.array_equal(vox, pts[[3, 2, 1, 0]])
+    st = ctx.debug_state()
+    assert list(st.div_b) == [2, 2, 3] and list(st.mul) == [1, 2, 4]
+    pts = np.array([[-0.01, 0, 0], [0.01, 0, 0]], dtype=f32)
+    vox, _ = ctx.voxel_downsample(pts)
+    assert vox.shape[0] == 2 and ctx.debug_state().min_b[0] == -1
+
+
+def test_kat4_centroid_order(ctx):
+    ctx.set_params(leaf=0.05, tol=0.1)
+    pts = np.array([[0.01, 0, 0], [0.02, 0, 0], [0.04, 0, 0]], dtype=f32)
+    vox, _ = ctx.voxel_downsample(pts)
+    expect = ((f32(0) + f32(0.01)) + f32(0.02) + f32(0.04)) / f32(3.0)
+    assert vox.shape == (1, 3) and vox[0, 0].tobytes() == f32(expect).tobytes()
+    ctx.set_params(leaf=1e9, tol=0.1)
+    pts2 = np.array([[16777216.0, 0, 0], [1.0, 0, 0], [1.0, 0, 0]], dtype=f32)
+    vox2, _ = ctx.voxel_downsample(pts2)
+    assert vox2[0, 0] == f32(16777216.0) / f32(3.0)
+
+
+def test_kat5_overflow_passthrough(ctx):
+    ctx.set_params(leaf=0.001, tol=0.1, min_cluster=1, max_cluster=10)
+    pts = np.array([[0, 0, 0], [3000, 0, 0], [0, 3000, 0], [0, 0, 3000]], dtype=f32)
+    vox, pt = ctx.voxel_downsample(pts)
+    assert pt and np.array_equal(vox, pts)
+    res = ctx.process_xyz(pts)                       # chain: clustering then runs on the input cloud
+    assert res["passthrough"] and res["num_voxels"] == 4
+    assert list(np.diff(res["offsets"])) == [1, 1, 1, 1]
+    assert np.array_equal(res["voxel_xyz"], pts)
+    pts1 = np.array([[0, 0, 0], [3000, 0, 0]], dtype=f32)
+    vox1, pt1 = ctx.voxel_downsample(pts1)
+    assert not pt1 and vox1.shape[0] == 2
+
+
+def test_kat6_kat7_filter_and_order(ctx, oracle):
+    tol = f32(0.1)
+    chain = np.zeros((7, 3), dtype=f32)
+    chain[:, 0] = np.arange(7, dtype=f32) * f32(0.09)
+    ctx.set_params(leaf=0.05, tol=tol, min_cluster=5, max_cluster=6)
+    off, idx = ctx.euclidean_clusters(chain)
+    assert len(off) - 1 == 0
+    ctx.set_params(leaf=0.05, tol=tol, min_cluster=5, max_cluster=7)
+    off, idx = ctx.euclidean_clusters(chain)
+    assert list(np.diff(off)) == [7] and list(idx) == list(range(7))
+    pts = []
+    for c, s in enumerate([5, 9, 5, 7]):
+        for j in range(s):
+            pts.append([j * 0.05, c * 1.0, 0.0])
+    pts = np.array(pts, dtype=f32)
+    ctx.set_params(leaf=0.05, tol=tol, min_cluster=5, max_cluster=100)
+    assert_same_clusters(*ctx.euclidean_clusters(pts), *oracle.euclidean_clusters(pts, tol, 5, 100))
+
+
+def test_kat8_r2_bits(ctx):
+    ctx.set_params(leaf=0.05, tol=0.1, min_cluster=1, max_cluster=10)
+    ctx.euclidean_clusters(np.zeros((3, 3), dtype=f32))
+    assert np.float32(ctx.debug_state().r2).view(np.uint32) == np.uint32(0x3C23D70B)
+
+
+def test_empty_single_and_duplicates(ctx, oracle):
+    ctx.set_params(leaf=0.05, tol=0.1, min_cluster=1, max_cluster=10)
+    vox, pt = ctx.voxel_downsample(np.zeros((0, 3), dtype=f32))
+    assert vox.shape == (0, 3) and not pt
+    off, idx = ctx.euclidean_clusters(np.zeros((0, 3), dtype=f32))
+    assert list(off) == [0]
+    off, idx = ctx.euclidean_clusters(np.array([[1, 2, 3]], dtype=f32))
+    assert list(off) == [0, 1] and list(idx) == [0]
+    res = ctx.process_xyz(np.zeros((0, 3), dtype=f32))
+    assert res["num_voxels"] == 0 and list(res["offsets"]) == [0]
+    dup = np.array([[0, 0, 0], [0, 0, 0], [0, 0, 0], [5, 5, 5]], dtype=f32)
+    assert_same_clusters(*ctx.euclidean_clusters(dup), *oracle.euclidean_clusters(dup, 0.1, 1, 10))
+
+
+def test_zero_tolerance_gives_singletons(ctx, oracle):
+    pts = synth.uniform_field(50, 11)
+    ctx.set_params(leaf=0.05, tol=0.0, min_cluster=1, max_cluster=10)
+    assert_same_clusters(*ctx.euclidean_clusters(pts), *oracle.euclidean_clusters(pts, 0.0, 1, 10))
+
+
+def test_nan_handling(ctx, oracle, capi):
+    pts = synth.uniform_field(5000, 5)
+    pts[::7, 0] = np.nan
+    pts[3::11, 2] = np.inf
+    ctx.set_params(leaf=0.05, tol=0.1, min_cluster=5, max_cluster=20000)
+    vox, _ = ctx.voxel_downsample(pts, is_dense=False)
+    ref, _ = oracle.voxel_downsample(pts, 0.05, is_dense=False)
+    assert_same_cloud(vox, ref)
+    with pytest.raises(capi.PcopError) as e:        # dense cloud with NaN: undefined in PCL, loud error here
+        ctx.voxel_downsample(pts, is_dense=True)
+    assert e.value.status == -6
+    with pytest.raises(capi.PcopError):
+        ctx.euclidean_clusters(pts)
+
+
+def test_bad_params_fail_loudly(ctx, capi):
+    ctx.set_params(leaf=0.0, tol=0.1)
+    with pytest.raises(capi.PcopError) as e:
+        ctx.voxel_downsample(np.zeros((3, 3), dtype=f32))
+    assert e.value.status == -2
+    ctx.set_params(leaf=0.05, tol=np.inf)
+    with pytest.raises(capi.PcopError):
+        ctx.euclidean_clusters(np.zeros((3, 3), dtype=f32))
+    small = capi.Context(10)
+    small.set_params(leaf=0.05, tol=0.1)
+    with pytest.raises(capi.PcopError) as e:
+        small.voxel_downsample(np.zeros((11, 3), dtype=f32))
+    assert e.value.status == -5
+    small.close()
+    with pytest.raises(capi.PcopError) as e:        # no CPU fallback: a missing device is an error
+        capi.Context(10, device=-1)
+    assert e.value.status == -3
+
+
+# ---------------------------------------------------------------------------------------------
+# stage parity on seeded clouds
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("seed,n,leaf", [(1, 10_000, 0.05), (2, 50_000, 0.2), (3, 70_001, 0.013), (4, 4097, 1.0)])
+def test_voxel_stage_matches_oracle(ctx, oracle, layout, seed, n, leaf):
+    pts = synth.uniform_field(n, seed)
+    ctx.set_params(leaf=leaf, tol=0.1)
+    got, pt = ctx.voxel_downsample(pts, layout=layout)
+    ref, pt_ref = oracle.voxel_downsample(pts, leaf)
+    assert pt == pt_ref
+    assert_same_cloud(got, ref)
+
+
+def test_voxel_stage_sorted_records_are_stable(ctx, oracle):
+    """Stage-wise: after the partition passes the records are ordered by (voxel key, point index)."""
+    pts = synth.uniform_field(30_000, 9)
+    ctx.set_params(leaf=0.1, tol=0.1)
+    ctx.voxel_downsample(pts)
+    st = ctx.debug_state()
+    npass = st.plan_voxel.npass
+    rec = ctx.debug_buffer("rec_a" if npass % 2 == 1 else "rec_b", np.float32, 4 * len(pts)).reshape(-1, 4)
+    idx = rec[:, 3].view(np.uint32)
+    keys, grid, _ = oracle.voxel_keys(pts, 0.1)
+    assert list(grid[:3]) == list(st.min_b) and list(grid[3:6]) == list(st.div_b)
+    assert sorted(idx.tolist()) == list(range(len(pts)))
+    k_sorted = keys[idx].astype(np.int64)
+    order = np.lexsort((idx, k_sorted))
+    assert np.array_equal(order, np.arange(len(pts)))          # already sorted by (key, idx)
+    assert np.array_equal(rec[:, :3], pts[idx])
+
+
+@pytest.mark.parametrize("cfg,n,mn,mx", [("C1", 10_000, 5, 20000), ("C1", 10_000, 1, 10**9), ("C2", 30_000, 5, 10**9),
+                                         ("C3", 120_000, 5, 20000), ("C3L10", 150_000, 2, 20000)])
+def test_cluster_stage_matches_oracle(ctx, oracle, cfg, n, mn, mx):
+    p = synth.params_of(cfg)
+    pts = synth.make_cloud(cfg, n=n)
+    vox, _ = oracle.voxel_downsample(pts, p["leaf"])
+    ctx.set_params(leaf=p["leaf"], tol=p["tol"], min_cluster=mn, max_cluster=mx)
+    for layout in (2, 0):
+        assert_same_clusters(*ctx.euclidean_clusters(vox, layout=layout),
+                             *oracle.euclidean_clusters(vox, p["tol"], mn, mx))
+
+
+def test_cluster_stage_large_tolerance_ratio(ctx, oracle):
+    """The reference's deployed parameters (params.yaml:16,26): tol/leaf = 26.7, hundreds of points per cell."""
+    pts = synth.make_cloud("C3", n=200_000)
+    vox, _ = oracle.voxel_downsample(pts, 0.015)
+    ctx.set_params(leaf=0.015, tol=0.4, min_cluster=5, max_cluster=20000)
+    assert_same_clusters(*ctx.euclidean_clusters(vox), *oracle.euclidean_clusters(vox, 0.4, 5, 20000))
+    ctx.set_params(leaf=0.015, tol=0.4, min_cluster=5, max_cluster=10**9)
+    assert_same_clusters(*ctx.euclidean_clusters(vox), *oracle.euclidean_clusters(vox, 0.4, 5, 10**9))
+
+
+def test_cluster_stage_sparse_points(ctx, oracle):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-50, 50, (20_000, 3)).astype(f32)
+    ctx.set_params(leaf=0.05, tol=2.0, min_cluster=2, max_cluster=10**9)
+    assert_same_clusters(*ctx.euclidean_clusters(pts), *oracle.euclidean_clusters(pts, 2.0, 2, 10**9))
+
+
+# ---------------------------------------------------------------------------------------------
+# whole chain at the BASELINE configs
+# ---------------------------------------------------------------------------------------------
+def run_chain(ctx, oracle, pts, p):
+    ctx.set_params(publish_clouds=1, **p)
+    got = ctx.process_xyz(pts)
+    ref = oracle.process_xyz(pts, **p)
+    assert got["passthrough"] == ref["passthrough"]
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    return got, ref
+
+
+def test_chain_c1(ctx, oracle):
+    got, _ = run_chain(ctx, oracle, synth.make_cloud("C1"), synth.params_of("C1"))
+    assert 100 < len(got["offsets"]) - 1 < 300
+
+
+def test_chain_c2(ctx, oracle):
+    p = synth.params_of("C2")
+    pts = synth.make_cloud("C2")
+    got, _ = run_chain(ctx, oracle, pts, p)
+    assert len(got["offsets"]) - 1 == 0                    # one giant component, dropped by max=20000
+    p["max_cluster"] = 10**9
+    got, _ = run_chain(ctx, oracle, pts, p)
+    assert len(got["offsets"]) - 1 >= 1
+
+
+def test_chain_c3_full_size(ctx, oracle):
+    """BASELINE config 2 at its full size: 1M points, 20 box clusters, ground dropped by max=20000."""
+    got, _ = run_chain(ctx, oracle, synth.make_cloud("C3"), synth.params_of("C3"))
+    assert len(got["offsets"]) - 1 == 20
+
+
+def test_chain_c3_l10(ctx, oracle):
+    run_chain(ctx, oracle, synth.make_cloud("C3L10", n=400_000), synth.params_of("C3L10"))
+
+
+def test_chain_device_resident_and_repeatable(ctx, oracle):
+    """The benchmark path: cloud resident in HBM as SoA planes; repeated frames give identical output."""
+    p = synth.params_of("C3")
+    pts = synth.make_cloud("C3", n=300_000, seed=31)
+    ref = oracle.process_xyz(pts, **p)
+    ctx.set_params(publish_clouds=1, **p)
+    ptr, n = ctx.upload_soa(pts)
+    for _ in range(3):
+        got = ctx.process_device(ptr, n)
+        assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    ctx.dev_free(ptr)
+
+
+def test_frames_in_flight_on_several_contexts(capi, oracle):
+    p = synth.params_of("C3")
+    clouds = [synth.make_cloud("C3", n=100_000, seed=100 + i) for i in range(4)]
+    refs = [oracle.process_xyz(c, **p) for c in clouds]
+    ctxs = [capi.Context(100_000) for _ in clouds]
+    ptrs = []
+    for c, pts in zip(ctxs, clouds):
+        c.set_params(publish_clouds=0, **p)
+        ptrs.append(c.upload_soa(pts))
+    for rep in range(2):
+        for c, (ptr, n) in zip(ctxs, ptrs):
+            c.submit_device(ptr, n)
+        for c, ref in zip(ctxs, refs):
+            got = c.wait()
+            assert got["voxel_xyz"] is None
+            assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    for c in ctxs:
+        c.close()
+
+
+def test_pointcloud2_entry(ctx, oracle):
+    """sensor_msgs/PointCloud2 with extra fields (Kinect: xyz + pad + rgb, point_step 32) and row padding."""
+    p = synth.params_of("C1")
+    pts = synth.make_cloud("C1", n=6000)
+    pts[5] = np.nan
+    width, height, step = 100, 60, 32
+    row_step = width * step + 64
+    buf = np.zeros(height * row_step, dtype=np.uint8)
+    rows = buf.reshape(height, row_step)[:, :width * step].reshape(height, width, step)
+    rows[:, :, 4:8] = pts[:, 1].reshape(height, width).copy().view(np.uint8).reshape(height, width, 4)    # y @4
+    rows[:, :, 8:12] = pts[:, 0].reshape(height, width).copy().view(np.uint8).reshape(height, width, 4)   # x @8
+    rows[:, :, 16:20] = pts[:, 2].reshape(height, width).copy().view(np.uint8).reshape(height, width, 4)  # z @16
+    ctx.set_params(publish_clouds=1, **p)
+    got = ctx.process_pointcloud2(buf, width, height, step, row_step, 8, 4, 16, is_bigendian=False, is_dense=False)
+    ref = oracle.process_xyz(pts, is_dense=False, **p)
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    # big-endian payload
+    be = buf.copy()
+    r2 = be.reshape(height, row_step)[:, :width * step].reshape(height, width, step)
+    for o in (4, 8, 16):
+        r2[:, :, o:o + 4] = r2[:, :, o:o + 4][:, :, ::-1]
+    got2 = ctx.process_pointcloud2(be, width, height, step, row_step, 8, 4, 16, is_bigendian=True, is_dense=False)
+    assert_same_clusters(got2["offsets"], got2["indices"], ref["offsets"], ref["indices"])
+
+
+def test_cluster_summaries(ctx, oracle):
+    p = synth.params_of("C3")
+    pts = synth.make_cloud("C3", n=200_000)
+    ctx.set_params(publish_clouds=1, **p)
+    got = ctx.process_xyz(pts)
+    k = len(got["offsets"]) - 1
+    assert k > 0
+    xyzr = ctx.cluster_summaries(k)
+    ref = oracle.cluster_summaries(got["voxel_xyz"], got["offsets"], got["indices"])
+    assert np.max(np.abs(xyzr - ref)) <= 1e-5              # PointWithRad floats (centre: double mean; r: float chain)
+
+
+def test_radix_replanning_and_digit_widths(capi, oracle, monkeypatch):
+    """Pass counts adapt after the first frame; every digit width gives the same answer."""
+    p = synth.params_of("C3")
+    pts = synth.make_cloud("C3", n=150_000, seed=77)
+    ref = oracle.process_xyz(pts, **p)
+    for bits in ("5", "8", "11"):
+        monkeypatch.setenv("PCOP_RADIX_BITS", bits)
+        c = capi.Context(len(pts))
+        c.set_params(publish_clouds=1, **p)
+        for rep in range(3):
+            got = c.process_xyz(pts)
+            assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+            assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+        # a different cloud on the same context, with a much larger key space, forces a re-plan
+        big = synth.uniform_field(100_000, 5) * f32(20.0)
+        c.set_params(publish_clouds=1, leaf=0.02, tol=0.1, min_cluster=2, max_cluster=20000)
+        got = c.process_xyz(big)
+        refb = oracle.process_xyz(big, leaf=0.02, tol=0.1, min_cluster=2, max_cluster=20000)
+        assert_same_cloud(got["voxel_xyz"], refb["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], refb["offsets"], refb["indices"])
+        c.close()

@@ -1,0 +1,76 @@
+"""GPU diagnostic: runs a few clouds through libpcop.so and prints where it diverges from the oracle.
+Usage on the GPU box: python tools/gpu_diag.py [config] [n]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from pointcloud_obstacle_processing_amd import capi, synth  # noqa: E402
+
+
+def show_state(st):
+    print("  state: err=%d n_in=%d n_valid=%d pt=%d m=%d min_b=%s div_b=%s mul=%s kb=%d bits=%s" % (
+        st.err, st.n_in, st.n_valid, st.passthrough, st.m, list(st.min_b), list(st.div_b), list(st.mul),
+        st.plan_voxel.key_bits, list(st.plan_voxel.bits)))
+    print("         c_n=%d from_input=%d r2=%g cdim=%s ckb=%d cbits=%s cells=%d kept=%d kept_pts=%d csr_bits=%s" % (
+        st.c_n, st.c_from_input, st.r2, list(st.cdim), st.plan_cell.key_bits, list(st.plan_cell.bits), st.n_cells,
+        st.n_kept, st.n_kept_pts, list(st.plan_csr.bits)))
+
+
+def run(cfg, n):
+    p = synth.params_of(cfg)
+    pts = synth.make_cloud(cfg, n=n)
+    print("== %s n=%d leaf=%g tol=%g" % (cfg, len(pts), p["leaf"], p["tol"]))
+    ctx = capi.Context(len(pts), profiling=True)
+    ctx.set_params(publish_clouds=1, **p)
+    t = time.time()
+    ref = O.process_xyz(pts, **p)
+    t_or = time.time() - t
+    for rep in range(3):
+        t = time.time()
+        got = ctx.process_xyz(pts)
+        t_gpu = time.time() - t
+        st = ctx.debug_state()
+        if rep == 0:
+            show_state(st)
+    print("  oracle %.3fs gpu(last, host-inclusive) %.4fs" % (t_or, t_gpu))
+    for nm, ms in ctx.stage_times():
+        print("    %-22s %8.3f ms" % (nm, ms))
+    ok = True
+    if got["num_voxels"] != len(ref["voxel_xyz"]):
+        print("  M mismatch gpu %d oracle %d" % (got["num_voxels"], len(ref["voxel_xyz"])))
+        ok = False
+    else:
+        same = got["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes()
+        print("  centroids bit-exact:", same)
+        if not same:
+            d = np.flatnonzero((got["voxel_xyz"].view(np.uint32) != ref["voxel_xyz"].view(np.uint32)).any(axis=1))
+            print("   first diffs at", d[:10], "count", len(d))
+            for i in d[:3]:
+                print("    ", i, got["voxel_xyz"][i], ref["voxel_xyz"][i])
+            ok = False
+    same_off = np.array_equal(got["offsets"], ref["offsets"])
+    same_idx = np.array_equal(got["indices"], ref["indices"])
+    print("  K gpu %d oracle %d offsets equal %s indices equal %s" % (len(got["offsets"]) - 1, len(ref["offsets"]) - 1,
+                                                                     same_off, same_idx))
+    if not (same_off and same_idx):
+        print("   gpu sizes", np.diff(got["offsets"])[:20], "oracle sizes", np.diff(ref["offsets"])[:20])
+        ok = False
+    ctx.close()
+    return ok
+
+
+if __name__ == "__main__":
+    print("devices:", capi.load_library().pcop_device_count())
+    if len(sys.argv) > 1:
+        ok = run(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else None)
+    else:
+        ok = True
+        for cfg, n in [("C1", 2000), ("C1", None), ("C2", 30000), ("C3", 100000), ("C3", None)]:
+            ok = run(cfg, n) and ok
+    print("DIAG", "OK" if ok else "FAILED")
+    sys.exit(0 if ok else 1)
