@@ -78,11 +78,12 @@ def test_kat4_centroid_order(ctx):
     assert vox2[0, 0] == f32(16777216.0) / f32(3.0)
 
 
-def test_kat5_overflow_passthrough(ctx):
+def test_kat5_overflow_passthrough(ctx, capi):
     ctx.set_params(leaf=0.001, tol=0.1, min_cluster=1, max_cluster=10)
     pts = np.array([[0, 0, 0], [3000, 0, 0], [0, 3000, 0], [0, 0, 3000]], dtype=f32)
     vox, pt = ctx.voxel_downsample(pts)
     assert pt and np.array_equal(vox, pts)
+    ctx.set_params(leaf=0.001, tol=10.0, min_cluster=1, max_cluster=10)
     res = ctx.process_xyz(pts)                       # chain: clustering then runs on the input cloud
     assert res["passthrough"] and res["num_voxels"] == 4
     assert list(np.diff(res["offsets"])) == [1, 1, 1, 1]
@@ -90,6 +91,11 @@ def test_kat5_overflow_passthrough(ctx):
     pts1 = np.array([[0, 0, 0], [3000, 0, 0]], dtype=f32)
     vox1, pt1 = ctx.voxel_downsample(pts1)
     assert not pt1 and vox1.shape[0] == 2
+    # documented limit of the neighbour grid: extent/tolerance beyond 2^32 cells is a loud error
+    ctx.set_params(leaf=0.001, tol=0.1, min_cluster=1, max_cluster=10)
+    with pytest.raises(capi.PcopError) as e:
+        ctx.process_xyz(pts)
+    assert e.value.status == -7
 
 
 def test_kat6_kat7_filter_and_order(ctx, oracle):
