@@ -80,7 +80,7 @@ typedef struct pcop_result {
 
 /* Per-stage device times of the last frame (milliseconds, HIP events on the
  * context's stream).  Filled only when profiling was enabled on the context. */
-#define PCOP_MAX_STAGES 48
+#define PCOP_MAX_STAGES 128
 typedef struct pcop_stage_times {
     int32_t     count;
     const char* name[PCOP_MAX_STAGES];

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpcop.so")
 
 LAYOUT_AOS16, LAYOUT_SOA, LAYOUT_AOS12 = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
-MAX_STAGES = 48
+MAX_STAGES = 128
 
 EXPORTS = [
     "pcop_create", "pcop_destroy", "pcop_set_params", "pcop_get_params", "pcop_last_error", "pcop_status_string",

@@ -133,13 +133,14 @@ uint32_t stride_grid(uint32_t n) { return std::min(2048u, std::max(1u, div_up(n,
 void launch_table_scan(pcop_ctx* c, int which, int pass) {
     dim3 g(div_up(kMaxBins, kBlock), kSegs);
     k_table_colsum<<<g, kBlock, 0, c->stream>>>(c->d_state, which, pass, c->table, c->seg_sum);
+    mark(c, "k_table_colsum");
     k_table_colscan<<<g, kBlock, 0, c->stream>>>(c->d_state, which, pass, c->table, c->seg_sum, c->table_x, c->bin_total);
+    mark(c, "k_table_colscan");
 }
 
 // Stable LSD partition by the voxel (which=0) or cell (which=1) key; returns the sorted buffer.
 template <class KeyFn>
-float4* launch_partition(pcop_ctx* c, int which, uint32_t npass, uint32_t n_max, SoaSrc s_a, SoaSrc s_b,
-                         const char* const* names) {
+float4* launch_partition(pcop_ctx* c, int which, uint32_t npass, uint32_t n_max, SoaSrc s_a, SoaSrc s_b) {
     const uint32_t g = partition_grid(n_max);
     float4* bufs[2] = {c->rec_a, c->rec_b};
     float4* out = nullptr;
@@ -147,77 +148,91 @@ float4* launch_partition(pcop_ctx* c, int which, uint32_t npass, uint32_t n_max,
         out = bufs[p & 1];
         if (p == 0) {
             k_radix_hist<SoaSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(s_a, s_b, c->d_state, which, (int)p, c->table);
+            mark(c, "k_radix_hist");
             launch_table_scan(c, which, (int)p);
             k_radix_scatter<SoaSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(s_a, s_b, c->d_state, which, (int)p, c->table_x,
                                                                         c->bin_total, out);
+            mark(c, "k_radix_scatter");
         } else {
             RecSrc r{bufs[(p - 1) & 1]};
             k_radix_hist<RecSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(r, r, c->d_state, which, (int)p, c->table);
+            mark(c, "k_radix_hist");
             launch_table_scan(c, which, (int)p);
             k_radix_scatter<RecSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(r, r, c->d_state, which, (int)p, c->table_x,
                                                                         c->bin_total, out);
+            mark(c, "k_radix_scatter");
         }
-        mark(c, names[p]);
     }
     return out;
 }
 
-const char* const kVoxelPassNames[kMaxPasses] = {"voxel_partition_0", "voxel_partition_1", "voxel_partition_2"};
-const char* const kCellPassNames[kMaxPasses] = {"cell_partition_0", "cell_partition_1", "cell_partition_2"};
-const char* const kCsrPassNames[kMaxPasses] = {"csr_partition_0", "csr_partition_1", "csr_partition_2"};
 
 void enqueue_voxel(pcop_ctx* c) {
     const uint32_t n = c->n;
     SoaPair src{nullptr, nullptr, nullptr, c->src_x, c->src_y, c->src_z};
     k_minmax<<<kReduceBlocks, kBlock, 0, c->stream>>>(src, c->d_state, 0, c->partials);
+    mark(c, "k_minmax");
     k_voxel_setup<<<1, kBlock, 0, c->stream>>>(c->d_state, c->partials, kReduceBlocks, c->npass_voxel);
-    mark(c, "voxel_minmax_setup");
+    mark(c, "k_voxel_setup");
     SoaSrc s{c->src_x, c->src_y, c->src_z};
-    float4* sorted = launch_partition<VoxelKey>(c, 0, c->npass_voxel, n, s, s, kVoxelPassNames);
+    float4* sorted = launch_partition<VoxelKey>(c, 0, c->npass_voxel, n, s, s);
     const uint32_t sg = scan_grid(n);
     k_heads_count<VoxelKey><<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, 0, c->tile_heads);
+    mark(c, "k_heads_count");
     k_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_heads, c->d_state, 0, 0);
+    mark(c, "k_scan_tiles");
     k_voxel_reduce<<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->tile_heads, c->cen_x, c->cen_y, c->cen_z);
+    mark(c, "k_voxel_reduce");
     k_voxel_passthrough<<<1, 64, 0, c->stream>>>(c->d_state);
-    mark(c, "voxel_heads_reduce");
+    mark(c, "k_voxel_passthrough");
 }
 
 void enqueue_cluster(pcop_ctx* c, int force_input) {
     const uint32_t n = c->n;   // upper bound of c_n
     k_cluster_source<<<1, 64, 0, c->stream>>>(c->d_state, force_input);
+    mark(c, "k_cluster_source");
     SoaPair src{c->cen_x, c->cen_y, c->cen_z, c->src_x, c->src_y, c->src_z};
     k_minmax<<<kReduceBlocks, kBlock, 0, c->stream>>>(src, c->d_state, 1, c->partials);
+    mark(c, "k_minmax");
     k_cell_setup<<<1, kBlock, 0, c->stream>>>(c->d_state, c->partials, kReduceBlocks, c->npass_cell);
-    mark(c, "cell_minmax_setup");
+    mark(c, "k_cell_setup");
     SoaSrc s_a{c->cen_x, c->cen_y, c->cen_z}, s_b{c->src_x, c->src_y, c->src_z};
-    float4* sorted = launch_partition<CellKey>(c, 1, c->npass_cell, n, s_a, s_b, kCellPassNames);
+    float4* sorted = launch_partition<CellKey>(c, 1, c->npass_cell, n, s_a, s_b);
     const uint32_t sg = scan_grid(n);
     k_heads_count<CellKey><<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, 1, c->tile_heads);
+    mark(c, "k_heads_count");
     k_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_heads, c->d_state, 1, 1);
+    mark(c, "k_scan_tiles");
     k_cells_build<<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->tile_heads, c->rec_cell, c->cell_key, c->cell_start,
                                                  c->cell_minidx, c->parent, c->comp_size, c->comp_min, c->kept_val);
-    mark(c, "cell_heads_build");
+    mark(c, "k_cells_build");
     const uint32_t ug = std::min(8192u, std::max(1u, div_up(n, kWavesPerBlock)));
     k_cell_union<<<ug, kBlock, 0, c->stream>>>(sorted, c->d_state, c->cell_key, c->cell_start, c->parent);
-    mark(c, "cell_union");
+    mark(c, "k_cell_union");
     const uint32_t tg = stride_grid(n);
     k_cell_flatten<<<tg, kBlock, 0, c->stream>>>(c->d_state, c->cell_start, c->cell_minidx, c->parent, c->cell_root,
                                                   c->comp_size, c->comp_min);
+    mark(c, "k_cell_flatten");
     k_mark_kept<<<tg, kBlock, 0, c->stream>>>(c->d_state, c->cell_root, c->comp_size, c->comp_min, c->kept_val);
+    mark(c, "k_mark_kept");
     k_kept_count<<<sg, kBlock, 0, c->stream>>>(c->d_state, c->kept_val, c->tile_sums);
+    mark(c, "k_kept_count");
     k_kept_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_sums, c->d_state, c->d_offsets, c->npass_csr);
+    mark(c, "k_kept_scan_tiles");
     k_kept_apply<<<sg, kBlock, 0, c->stream>>>(c->d_state, c->kept_val, c->tile_sums, c->rank_at, c->d_offsets);
+    mark(c, "k_kept_apply");
     k_label_points<<<tg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->rec_cell, c->cell_root, c->comp_size, c->comp_min,
                                                   c->rank_at, c->label);
-    mark(c, "components_label");
+    mark(c, "k_label_points");
     const uint32_t g = partition_grid(n);
     uint32_t* bufs[2] = {c->idx_a, c->idx_b};
     for (uint32_t p = 0; p < c->npass_csr; ++p) {
         const uint32_t* in = p == 0 ? nullptr : bufs[(p - 1) & 1];
         k_csr_hist<<<g, kBlock, 0, c->stream>>>(in, c->label, c->d_state, (int)p, c->table);
+        mark(c, "k_csr_hist");
         launch_table_scan(c, 2, (int)p);
         k_csr_scatter<<<g, kBlock, 0, c->stream>>>(in, c->label, c->d_state, (int)p, c->table_x, c->bin_total, bufs[p & 1]);
-        mark(c, kCsrPassNames[p]);
+        mark(c, "k_csr_scatter");
     }
     c->frame_csr_idx = bufs[(c->npass_csr - 1) & 1];
 }
@@ -234,12 +249,12 @@ int enqueue_frame(pcop_ctx* c) {
     k_frame_init<<<1, 64, 0, c->stream>>>(c->d_state, c->n, (uint32_t)(c->is_dense ? 1 : 0), inv_leaf, r2,
                                           c->result_trivial ? 1.0 : inv_cell, (uint32_t)p.min_cluster,
                                           (uint32_t)p.max_cluster);
+    mark(c, "k_frame_init");
     if (c->kind != kFrameClusterOnly) enqueue_voxel(c);
     if (c->kind != kFrameVoxelOnly && !c->result_trivial) enqueue_cluster(c, c->kind == kFrameClusterOnly ? 1 : 0);
     else if (c->kind != kFrameVoxelOnly) k_cluster_source<<<1, 64, 0, c->stream>>>(c->d_state, c->kind == kFrameClusterOnly ? 1 : 0);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
-    mark(c, "state_d2h");
     c->in_flight = true;
     c->have_result = false;
     return PCOP_OK;
