@@ -46,7 +46,7 @@ def kernel_alg_bytes(name, occurrence, n, m, n_cells):
         return 16 * n + 12 * m
     if name == "k_cells_build":
         return 16 * m + 4 * m + 16 * n_cells
-    if name == "k_cell_union":
+    if name in ("k_cell_union", "k_cell_hook"):
         return 12 * m + 4 * m          # neighbour + cluster pass reads 12·M, writes 4·M
     if name == "k_label_points":
         return 16 * m + 4 * m
@@ -54,6 +54,8 @@ def kernel_alg_bytes(name, occurrence, n, m, n_cells):
         return 8 * m
     if name in ("k_kept_count", "k_kept_apply"):
         return 4 * m
+    if name == "k_table_scan":
+        return 0
     if name in ("k_cell_flatten", "k_mark_kept"):
         return 16 * n_cells
     return 0

@@ -57,7 +57,7 @@ class DevState(C.Structure):
                 ("plan_voxel", RadixPlan), ("c_n", C.c_uint32), ("c_from_input", C.c_uint32), ("r2", C.c_float),
                 ("min_cluster", C.c_uint32), ("max_cluster", C.c_uint32), ("inv_cell", C.c_double),
                 ("cmin", C.c_int64 * 3), ("cdim", C.c_uint32 * 3), ("plan_cell", RadixPlan), ("n_cells", C.c_uint32),
-                ("n_comp", C.c_uint32), ("n_kept", C.c_uint32), ("n_kept_pts", C.c_uint32), ("plan_csr", RadixPlan),
+                ("hash_mask", C.c_uint32), ("n_kept", C.c_uint32), ("n_kept_pts", C.c_uint32), ("plan_csr", RadixPlan),
                 ("pad", C.c_uint32 * 3)]
 
 

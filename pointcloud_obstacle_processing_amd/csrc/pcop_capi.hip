@@ -51,6 +51,7 @@ struct pcop_ctx {
     uint32_t *parent = nullptr, *cell_root = nullptr, *comp_size = nullptr, *comp_min = nullptr;
     uint32_t *kept_val = nullptr, *rank_at = nullptr, *label = nullptr;
     uint32_t *idx_a = nullptr, *idx_b = nullptr, *d_offsets = nullptr;
+    unsigned long long* hash_tab = nullptr;   // cell key -> cell id
     float* d_pack = nullptr;      // packed output cloud (16 B/pt worst case)
     float4* d_xyzr = nullptr;
     uint8_t* d_raw = nullptr;     // raw input bytes (AoS / PointCloud2), grown on demand
@@ -131,11 +132,8 @@ uint32_t scan_grid(uint32_t n) { return std::max(1u, div_up(n, kScanTile)); }
 uint32_t stride_grid(uint32_t n) { return std::min(2048u, std::max(1u, div_up(n, kBlock))); }
 
 void launch_table_scan(pcop_ctx* c, int which, int pass) {
-    dim3 g(div_up(kMaxBins, kBlock), kSegs);
-    k_table_colsum<<<g, kBlock, 0, c->stream>>>(c->d_state, which, pass, c->table, c->seg_sum);
-    mark(c, "k_table_colsum");
-    k_table_colscan<<<g, kBlock, 0, c->stream>>>(c->d_state, which, pass, c->table, c->seg_sum, c->table_x, c->bin_total);
-    mark(c, "k_table_colscan");
+    k_table_scan<<<kMaxBins, kBlock, 0, c->stream>>>(c->d_state, which, pass, c->table, c->table_x, c->bin_total);
+    mark(c, "k_table_scan");
 }
 
 // Stable LSD partition by the voxel (which=0) or cell (which=1) key; returns the sorted buffer.
@@ -203,11 +201,18 @@ void enqueue_cluster(pcop_ctx* c, int force_input) {
     mark(c, "k_heads_count");
     k_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_heads, c->d_state, 1, 1);
     mark(c, "k_scan_tiles");
+    k_hash_clear<<<stride_grid(2 * n + 1024), kBlock, 0, c->stream>>>(c->d_state, c->hash_tab);
+    mark(c, "k_hash_clear");
     k_cells_build<<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->tile_heads, c->rec_cell, c->cell_key, c->cell_start,
-                                                 c->cell_minidx, c->parent, c->comp_size, c->comp_min, c->kept_val);
+                                                 c->cell_minidx, c->parent, c->comp_size, c->comp_min, c->kept_val,
+                                                 c->hash_tab);
     mark(c, "k_cells_build");
     const uint32_t ug = std::min(8192u, std::max(1u, div_up(n, kWavesPerBlock)));
-    k_cell_union<<<ug, kBlock, 0, c->stream>>>(sorted, c->d_state, c->cell_key, c->cell_start, c->parent);
+    k_cell_hook<<<ug, kBlock, 0, c->stream>>>(sorted, c->d_state, c->cell_key, c->cell_start, c->hash_tab, c->parent);
+    mark(c, "k_cell_hook");
+    k_cell_compress<<<stride_grid(n), kBlock, 0, c->stream>>>(c->d_state, c->parent);
+    mark(c, "k_cell_compress");
+    k_cell_union<<<ug, kBlock, 0, c->stream>>>(sorted, c->d_state, c->cell_key, c->cell_start, c->hash_tab, c->parent);
     mark(c, "k_cell_union");
     const uint32_t tg = stride_grid(n);
     k_cell_flatten<<<tg, kBlock, 0, c->stream>>>(c->d_state, c->cell_start, c->cell_minidx, c->parent, c->cell_root,
@@ -475,6 +480,11 @@ int pcop_create(pcop_ctx** out, int device_id, size_t max_points) {
     TRY(dev_alloc(c, &c->kept_val, n + 1)); TRY(dev_alloc(c, &c->rank_at, n + 1)); TRY(dev_alloc(c, &c->label, n + 1));
     TRY(dev_alloc(c, &c->idx_a, n + 1)); TRY(dev_alloc(c, &c->idx_b, n + 1)); TRY(dev_alloc(c, &c->d_offsets, n + 2));
     TRY(dev_alloc(c, &c->d_pack, 4 * n)); TRY(dev_alloc(c, &c->d_xyzr, n + 1));
+    {
+        size_t hcap = 1024;
+        while (hcap < 2 * (n + 1)) hcap <<= 1;
+        TRY(dev_alloc(c, &c->hash_tab, hcap));
+    }
     TRY(dev_alloc(c, &c->d_state, 1));
     TRY(host_alloc(c, &c->h_state, 1));
     TRY(host_alloc(c, &c->h_offsets_disc, n + 2)); TRY(host_alloc(c, &c->h_indices_disc, n + 1));
@@ -493,7 +503,7 @@ void pcop_destroy(pcop_ctx* c) {
     void* dev[] = {c->in_x, c->in_y, c->in_z, c->cen_x, c->cen_y, c->cen_z, c->rec_a, c->rec_b, c->table, c->table_x,
                    c->seg_sum, c->bin_total, c->tile_heads, c->tile_sums, c->partials, c->rec_cell, c->cell_key,
                    c->cell_start, c->cell_minidx, c->parent, c->cell_root, c->comp_size, c->comp_min, c->kept_val,
-                   c->rank_at, c->label, c->idx_a, c->idx_b, c->d_offsets, c->d_pack, c->d_xyzr, c->d_raw, c->d_state};
+                   c->rank_at, c->label, c->idx_a, c->idx_b, c->d_offsets, c->d_pack, c->d_xyzr, c->d_raw, c->d_state, c->hash_tab};
     for (void* p : dev) if (p) hipFree(p);
     for (void* p : c->user_allocs) if (p) hipFree(p);
     void* host[] = {c->h_state, c->h_offsets_disc, c->h_indices_disc, c->h_offsets, c->h_indices, c->h_vox, c->h_xyzr};

@@ -75,7 +75,7 @@ struct DevState {
     uint32_t cdim[3];
     RadixPlan plan_cell;
     uint32_t n_cells;
-    uint32_t n_comp;        // connected components (all sizes)
+    uint32_t hash_mask;     // cell hash table has hash_mask+1 slots (power of two >= 2*n_cells)
     uint32_t n_kept;        // clusters with min <= size <= max
     uint32_t n_kept_pts;    // sum of their sizes
     RadixPlan plan_csr;
@@ -432,8 +432,7 @@ __global__ void k_cluster_source(DevState* st, int force_input) {
 // ------------------------------------------------------------------------------------------
 // stable LSD radix partition of records by a digit of their key
 //   k_radix_hist    : per-tile digit counts            -> table[tile][bin]
-//   k_table_colsum  : per-segment column sums          -> seg_sum[seg][bin]
-//   k_table_colscan : exclusive scan down each column  -> table_x[tile][bin], bin_total[bin]
+//   k_table_scan    : exclusive scan down each column  -> table_x[tile][bin], bin_total[bin]
 //   k_radix_scatter : stable ranks (wave match-any) + scatter
 // which selects the key/count: 0 = voxel keys over n_in/n_valid, 1 = cell keys over c_n.
 // ------------------------------------------------------------------------------------------
@@ -501,48 +500,28 @@ __device__ __forceinline__ bool table_dims(const DevState* st, int which, int pa
     return !(which == 0 && st->passthrough);
 }
 
-// grid = (ceil(kMaxBins/kBlock), kSegs)
-__global__ __launch_bounds__(kBlock) void k_table_colsum(const DevState* st, int which, int pass,
-                                                         const uint32_t* __restrict__ table,
-                                                         uint32_t* __restrict__ seg_sum) {
+// Exclusive scan down each column of the tile-count table: block b owns bin b.
+// grid = kMaxBins blocks (blocks past the pass's bin count exit at once).
+__global__ __launch_bounds__(kBlock) void k_table_scan(const DevState* st, int which, int pass,
+                                                       const uint32_t* __restrict__ table,
+                                                       uint32_t* __restrict__ table_x,
+                                                       uint32_t* __restrict__ bin_total) {
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
     if (st->err) return;
     uint32_t ntiles, nb;
     if (!table_dims(st, which, pass, &ntiles, &nb)) return;
-    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t b = blockIdx.x;
     if (b >= nb) return;
-    const uint32_t per = (ntiles + kSegs - 1) / kSegs;
-    const uint32_t t0 = blockIdx.y * per;
-    const uint32_t t1 = min(t0 + per, ntiles);
-    uint32_t s = 0;
-    for (uint32_t t = t0; t < t1; ++t) s += table[(size_t)t * nb + b];
-    seg_sum[blockIdx.y * kMaxBins + b] = s;
-}
-
-__global__ __launch_bounds__(kBlock) void k_table_colscan(const DevState* st, int which, int pass,
-                                                          const uint32_t* __restrict__ table,
-                                                          const uint32_t* __restrict__ seg_sum,
-                                                          uint32_t* __restrict__ table_x,
-                                                          uint32_t* __restrict__ bin_total) {
-    if (st->err) return;
-    uint32_t ntiles, nb;
-    if (!table_dims(st, which, pass, &ntiles, &nb)) return;
-    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= nb) return;
-    const uint32_t per = (ntiles + kSegs - 1) / kSegs;
-    const uint32_t t0 = blockIdx.y * per;
-    const uint32_t t1 = min(t0 + per, ntiles);
-    uint32_t run = 0, all = 0;
-    for (uint32_t s = 0; s < (uint32_t)kSegs; ++s) {
-        const uint32_t v = seg_sum[s * kMaxBins + b];
-        if (s < blockIdx.y) run += v;
-        all += v;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < ntiles; base += kBlock) {
+        const uint32_t t = base + threadIdx.x;
+        const uint32_t v = t < ntiles ? table[(size_t)t * nb + b] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, s_w, &tot);
+        if (t < ntiles) table_x[(size_t)t * nb + b] = carry + ex;
+        carry += tot;
     }
-    if (blockIdx.y == 0) bin_total[b] = all;
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t v = table[(size_t)t * nb + b];
-        table_x[(size_t)t * nb + b] = run;
-        run += v;
-    }
+    if (threadIdx.x == 0) bin_total[b] = carry;
 }
 
 // Exclusive scan of bin_total[0..nb) into LDS s_base[0..nb); every thread of the block calls.
@@ -696,7 +675,46 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(uint32_t* __restrict__ va
         carry += tot;
     }
     if (threadIdx.x == 0) {
-        if (dst == 0) st->m = carry; else st->n_cells = carry;
+        if (dst == 0) {
+            st->m = carry;
+        } else {
+            st->n_cells = carry;
+            uint32_t cap = 1024;
+            while (cap < 2u * carry && cap < 0x80000000u) cap <<= 1;
+            st->hash_mask = cap - 1u;
+        }
+    }
+}
+
+// Cell hash table: slot = (key+1) | cell_id << 32, 0 = empty.  Open addressing, linear probing.
+__device__ __forceinline__ uint32_t cell_hash(uint32_t key) {
+    uint32_t h = key * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return h;
+}
+
+__global__ __launch_bounds__(kBlock) void k_hash_clear(const DevState* st, unsigned long long* __restrict__ tab) {
+    if (st->err) return;
+    const uint32_t cap = st->hash_mask + 1u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) tab[i] = 0ull;
+}
+
+__device__ __forceinline__ void hash_insert(unsigned long long* tab, uint32_t mask, uint32_t key, uint32_t id) {
+    const unsigned long long v = (unsigned long long)(key + 1u) | ((unsigned long long)id << 32);
+    uint32_t slot = cell_hash(key) & mask;
+    while (atomicCAS(tab + slot, 0ull, v) != 0ull) slot = (slot + 1u) & mask;
+}
+
+// returns the cell id or 0xFFFFFFFF
+__device__ __forceinline__ uint32_t hash_lookup(const unsigned long long* __restrict__ tab, uint32_t mask, uint32_t key) {
+    uint32_t slot = cell_hash(key) & mask;
+    while (true) {
+        const unsigned long long v = tab[slot];
+        if (v == 0ull) return 0xFFFFFFFFu;
+        if ((uint32_t)v == key + 1u) return (uint32_t)(v >> 32);
+        slot = (slot + 1u) & mask;
     }
 }
 
@@ -767,10 +785,12 @@ __global__ __launch_bounds__(kBlock) void k_cells_build(const float4* __restrict
                                                         uint32_t* __restrict__ rec_cell, uint32_t* __restrict__ cell_key,
                                                         uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_minidx,
                                                         uint32_t* __restrict__ parent, uint32_t* __restrict__ comp_size,
-                                                        uint32_t* __restrict__ comp_min, uint32_t* __restrict__ kept_val) {
+                                                        uint32_t* __restrict__ comp_min, uint32_t* __restrict__ kept_val,
+                                                        unsigned long long* __restrict__ hash_tab) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     if (st->err) return;
     const uint32_t n = st->c_n;
+    const uint32_t hmask = st->hash_mask;
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= n) return;
     CellKey key; key.init(st);
@@ -803,6 +823,7 @@ __global__ __launch_bounds__(kBlock) void k_cells_build(const float4* __restrict
                 parent[rank] = rank;
                 comp_size[rank] = 0u;
                 comp_min[rank] = 0xFFFFFFFFu;
+                hash_insert(hash_tab, hmask, kcur[k], rank);
                 ++rank;
             }
             rec_cell[i] = rank - 1;
@@ -856,90 +877,212 @@ __device__ __forceinline__ float l2_simple(const float4& a, const float4& b) {
     return result;
 }
 
-// One wave per cell A.  Points of one cell are mutually within the radius (clique), and a
+// ------------------------------------------------------------------------------------------
+// cell graph -> components.  Points of one cell are mutually within the radius (clique), and a
 // neighbour of a point of A lies in a cell at most 2 away per axis, so the components of the
 // point graph {d2 < r2} are the components of the cell graph whose edges are "some cross
-// pair satisfies d2 < r2".  Each unordered cell pair is visited once (forward half of the
-// 5x5x5 stencil).  Lanes 0..11 binary-search the 12 forward rows, lane 12 covers the own row.
-__global__ __launch_bounds__(kBlock) void k_cell_union(const float4* __restrict__ rec, const DevState* st,
-                                                       const uint32_t* __restrict__ cell_key,
-                                                       const uint32_t* __restrict__ cell_start,
-                                                       uint32_t* __restrict__ parent) {
-    __shared__ uint32_t s_cand[kWavesPerBlock][kWave];
+// pair satisfies d2 < r2".  One wave per cell; lane t owns stencil offset t of one half of the
+// 5x5x5 stencil (62 offsets, ascending in cell key), found through the cell hash table.
+//   k_cell_hook    : backward half, no atomics: parent[c] = smallest adjacent cell id (or c)
+//   k_cell_compress: pointer jumping, parent[c] = root
+//   k_cell_union   : forward half: pairs whose roots already agree are skipped without a
+//                    distance test; the rest are tested and united by CAS (few survive the hook)
+// ------------------------------------------------------------------------------------------
+constexpr int kCellPtsCap = 64;
+constexpr int kStencil = 62;
+
+// forward offset number t (0..61), ascending in key: (0,0,+1..2) ; (0,+1..2,*) ; (+1..2,*,*)
+__device__ __forceinline__ void stencil_offset(uint32_t t, int* dx, int* dy, int* dz) {
+    if (t < 2) { *dz = 0; *dy = 0; *dx = (int)t + 1; return; }
+    const uint32_t u = t - 2;
+    if (u < 10) { *dz = 0; *dy = 1 + (int)(u / 5); *dx = (int)(u % 5) - 2; return; }
+    const uint32_t v = u - 10;
+    *dz = 1 + (int)(v / 25); *dy = (int)((v % 25) / 5) - 2; *dx = (int)(v % 5) - 2;
+}
+
+struct CellGrid {
+    uint32_t dimx, dimy, dimz, hmask;
+    const unsigned long long* tab;
+    // cell id at (rx,ry,rz) + lane's offset of the forward (sign=+1) or backward (-1) half-stencil
+    __device__ __forceinline__ uint32_t neighbour(uint32_t rx, uint32_t ry, uint32_t rz, uint32_t lane, int sign) const {
+        if (lane >= (uint32_t)kStencil) return 0xFFFFFFFFu;
+        int dx, dy, dz;
+        // backward candidates in ascending key order = negated forward offsets in reverse order
+        stencil_offset(sign > 0 ? lane : (uint32_t)(kStencil - 1) - lane, &dx, &dy, &dz);
+        const long long nx = (long long)rx + sign * dx, ny = (long long)ry + sign * dy, nz = (long long)rz + sign * dz;
+        if (nx < 0 || ny < 0 || nz < 0 || nx >= (long long)dimx || ny >= (long long)dimy || nz >= (long long)dimz)
+            return 0xFFFFFFFFu;
+        const uint32_t key = (uint32_t)nx + dimx * ((uint32_t)ny + dimy * (uint32_t)nz);
+        return hash_lookup(tab, hmask, key);
+    }
+};
+
+// does some point of B (this lane's cell) lie within the radius of some point of A (in LDS)?
+__device__ __forceinline__ bool lane_pair_hit(const float4* s_pa, uint32_t an, const float4* __restrict__ rec,
+                                              uint32_t b0, uint32_t bn, float r2) {
+    for (uint32_t ib = 0; ib < bn; ++ib) {
+        const float4 pb = rec[b0 + ib];
+        for (uint32_t ia = 0; ia < an; ++ia)
+            if (l2_simple(s_pa[ia], pb) < r2) return true;
+    }
+    return false;
+}
+
+// whole wave on one cell pair: lanes spread over B's points
+__device__ __forceinline__ bool wave_pair_hit(const float4* __restrict__ rec, uint32_t a0, uint32_t an, uint32_t b0,
+                                              uint32_t bn, float r2) {
+    bool hit = false;
+    const uint32_t lane = lane_id();
+    for (uint32_t ia = 0; ia < an && !hit; ++ia) {
+        const float4 pa = rec[a0 + ia];
+        for (uint32_t jb = 0; jb < bn && !hit; jb += kWave) {
+            const uint32_t ib = jb + lane;
+            bool h = false;
+            if (ib < bn) h = l2_simple(pa, rec[b0 + ib]) < r2;
+            hit = __any(h);
+        }
+    }
+    return hit;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cell_hook(const float4* __restrict__ rec, const DevState* st,
+                                                      const uint32_t* __restrict__ cell_key,
+                                                      const uint32_t* __restrict__ cell_start,
+                                                      const unsigned long long* __restrict__ hash_tab,
+                                                      uint32_t* __restrict__ parent) {
+    __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
     if (st->err) return;
     const uint32_t ncell = st->n_cells;
-    const uint32_t dimx = st->cdim[0], dimy = st->cdim[1], dimz = st->cdim[2];
+    CellGrid g{st->cdim[0], st->cdim[1], st->cdim[2], st->hash_mask, hash_tab};
     const float r2 = st->r2;
     const uint32_t w = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
     for (uint32_t a = blockIdx.x * kWavesPerBlock + w; a < ncell; a += nwaves) {
         const uint32_t ka = cell_key[a];
-        const uint32_t rx = ka % dimx, ry = (ka / dimx) % dimy, rz = ka / (dimx * dimy);
-        // candidate neighbour cells: (first index, count) per lane
-        uint32_t first = 0, cnt = 0;
-        if (lane < 12) {
-            int dy, dz;
-            if (lane < 2) { dz = 0; dy = (int)lane + 1; }
-            else { dz = 1 + (int)(lane - 2) / 5; dy = (int)((lane - 2) % 5) - 2; }
-            const long long ny = (long long)ry + dy, nz = (long long)rz + dz;
-            if (ny >= 0 && ny < (long long)dimy && nz < (long long)dimz) {
-                const uint32_t xlo = rx >= 2 ? rx - 2 : 0u;
-                const uint32_t xhi = min(rx + 2, dimx - 1);
-                const uint32_t rowbase = dimx * ((uint32_t)ny + dimy * (uint32_t)nz);
-                const uint32_t klo = rowbase + xlo, khi = rowbase + xhi;
-                first = lower_bound_u32(cell_key, ncell, klo);
-                while (cnt < 5 && first + cnt < ncell && cell_key[first + cnt] <= khi) ++cnt;
-            }
-        } else if (lane == 12) {
-            first = a + 1;
-            const uint32_t xhi = min(rx + 2, dimx - 1);
-            const uint32_t khi = ka - rx + xhi;
-            while (cnt < 2 && first + cnt < ncell && cell_key[first + cnt] <= khi) ++cnt;
-        }
-        // wave prefix sum -> flat candidate list in LDS
-        const uint32_t incl = wave_incl_scan(cnt);
-        const uint32_t total = __shfl(incl, kWave - 1, kWave);
-        const uint32_t excl = incl - cnt;
-        for (uint32_t t = 0; t < cnt; ++t) s_cand[w][excl + t] = first + t;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t a0 = cell_start[a], an = cell_start[a + 1] - a0;
-        for (uint32_t t = 0; t < total; ++t) {
-            const uint32_t b = s_cand[w][t];
-            uint32_t ra = 0, rb = 1;
-            if (lane == 0) { ra = uf_find(parent, a); rb = uf_find(parent, b); }
-            ra = __shfl(ra, 0, kWave); rb = __shfl(rb, 0, kWave);
-            if (ra == rb) continue;                       // already one component
-            const uint32_t b0 = cell_start[b], bn = cell_start[b + 1] - b0;
-            bool hit = false;
-            // lanes cover 64 points of B at a time against one point of A
-            for (uint32_t ia = 0; ia < an && !hit; ++ia) {
-                const float4 pa = rec[a0 + ia];
-                for (uint32_t jb = 0; jb < bn && !hit; jb += kWave) {
-                    const uint32_t ib = jb + lane;
-                    bool h = false;
-                    if (ib < bn) h = l2_simple(pa, rec[b0 + ib]) < r2;
-                    hit = __any(h);
+        const uint32_t rx = ka % g.dimx, ry = (ka / g.dimx) % g.dimy, rz = ka / (g.dimx * g.dimy);
+        const uint32_t b = g.neighbour(rx, ry, rz, lane, -1);
+        const bool found = b != 0xFFFFFFFFu;
+        uint64_t found_mask = __ballot(found);
+        uint32_t target = a;
+        if (found_mask != 0) {
+            const uint32_t a0 = cell_start[a], an = cell_start[a + 1] - a0;
+            uint32_t b0 = 0, bn = 0;
+            if (found) { b0 = cell_start[b]; bn = cell_start[b + 1] - b0; }
+            uint32_t bn_max = bn;
+#pragma unroll
+            for (int d = kWave / 2; d > 0; d >>= 1) bn_max = max(bn_max, (uint32_t)__shfl_xor(bn_max, d, kWave));
+            if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
+                if (lane < an) s_pa[w][lane] = rec[a0 + lane];
+                __builtin_amdgcn_wave_barrier();
+                const bool hit = found && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2);
+                const uint64_t hits = __ballot(hit);
+                if (hits) target = __shfl(b, __ffsll((unsigned long long)hits) - 1, kWave);   // lanes ascend in key
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                while (found_mask) {   // ascending key: the first hit is the smallest adjacent id
+                    const int t = __ffsll((unsigned long long)found_mask) - 1;
+                    found_mask &= found_mask - 1;
+                    const uint32_t cb = __shfl(b, t, kWave), cb0 = __shfl(b0, t, kWave), cbn = __shfl(bn, t, kWave);
+                    if (wave_pair_hit(rec, a0, an, cb0, cbn, r2)) { target = cb; break; }
                 }
             }
-            if (hit && lane == 0) uf_union(parent, a, b);
         }
-        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) parent[a] = target;   // target <= a: a forest, no cycles
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cell_compress(const DevState* st, uint32_t* __restrict__ parent) {
+    if (st->err) return;
+    const uint32_t ncell = st->n_cells;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
+        const uint32_t r = uf_find(parent, c);
+        st_agent(parent + c, r);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cell_union(const float4* __restrict__ rec, const DevState* st,
+                                                       const uint32_t* __restrict__ cell_key,
+                                                       const uint32_t* __restrict__ cell_start,
+                                                       const unsigned long long* __restrict__ hash_tab,
+                                                       uint32_t* __restrict__ parent) {
+    __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
+    if (st->err) return;
+    const uint32_t ncell = st->n_cells;
+    CellGrid g{st->cdim[0], st->cdim[1], st->cdim[2], st->hash_mask, hash_tab};
+    const float r2 = st->r2;
+    const uint32_t w = threadIdx.x / kWave;
+    const uint32_t lane = lane_id();
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    for (uint32_t a = blockIdx.x * kWavesPerBlock + w; a < ncell; a += nwaves) {
+        const uint32_t ka = cell_key[a];
+        const uint32_t rx = ka % g.dimx, ry = (ka / g.dimx) % g.dimy, rz = ka / (g.dimx * g.dimy);
+        const uint32_t b = g.neighbour(rx, ry, rz, lane, +1);
+        bool need = false;
+        if (b != 0xFFFFFFFFu) need = uf_find(parent, a) != uf_find(parent, b);
+        uint64_t need_mask = __ballot(need);
+        if (need_mask == 0) continue;
+        const uint32_t a0 = cell_start[a], an = cell_start[a + 1] - a0;
+        uint32_t b0 = 0, bn = 0;
+        if (need) { b0 = cell_start[b]; bn = cell_start[b + 1] - b0; }
+        uint32_t bn_max = bn;
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) bn_max = max(bn_max, (uint32_t)__shfl_xor(bn_max, d, kWave));
+        if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
+            if (lane < an) s_pa[w][lane] = rec[a0 + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (need && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2)) uf_union(parent, a, b);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            while (need_mask) {
+                const int t = __ffsll((unsigned long long)need_mask) - 1;
+                need_mask &= need_mask - 1;
+                const uint32_t cb = __shfl(b, t, kWave), cb0 = __shfl(b0, t, kWave), cbn = __shfl(bn, t, kWave);
+                uint32_t ra = 0, rb = 1;
+                if (lane == 0) { ra = uf_find(parent, a); rb = uf_find(parent, cb); }
+                ra = __shfl(ra, 0, kWave); rb = __shfl(rb, 0, kWave);
+                if (ra == rb) continue;
+                if (wave_pair_hit(rec, a0, an, cb0, cbn, r2) && lane == 0) uf_union(parent, a, cb);
+            }
+        }
     }
 }
 
 // Component of every cell; component size and smallest point index (its discovery key).
+// Cells are handled 64 at a time; lanes whose cells share a root combine their contribution
+// in registers first, so a component costs one atomic pair per wave, not per cell.
 __global__ __launch_bounds__(kBlock) void k_cell_flatten(const DevState* st, const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ cell_minidx,
                                                          uint32_t* __restrict__ parent, uint32_t* __restrict__ cell_root,
                                                          uint32_t* __restrict__ comp_size, uint32_t* __restrict__ comp_min) {
     if (st->err) return;
     const uint32_t ncell = st->n_cells;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
-        const uint32_t r = uf_find(parent, c);
-        cell_root[c] = r;
-        atomicAdd(comp_size + r, cell_start[c + 1] - cell_start[c]);
-        atomicMin(comp_min + r, cell_minidx[c]);
+    const uint32_t lane = lane_id();
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < ncell; base += nthreads) {
+        const uint32_t c = base + lane;
+        const bool valid = c < ncell;
+        uint32_t r = 0xFFFFFFFFu, cnt = 0, mn = 0xFFFFFFFFu;
+        if (valid) {
+            r = uf_find(parent, c);
+            cell_root[c] = r;
+            cnt = cell_start[c + 1] - cell_start[c];
+            mn = cell_minidx[c];
+        }
+        uint64_t todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t rl = __shfl(r, leader, kWave);
+            const bool mine = valid && r == rl;
+            uint32_t c2 = mine ? cnt : 0u, m2 = mine ? mn : 0xFFFFFFFFu;
+#pragma unroll
+            for (int d = kWave / 2; d > 0; d >>= 1) {
+                c2 += __shfl_xor(c2, d, kWave);
+                m2 = min(m2, (uint32_t)__shfl_xor(m2, d, kWave));
+            }
+            if ((int)lane == leader) { atomicAdd(comp_size + rl, c2); atomicMin(comp_min + rl, m2); }
+            todo &= ~__ballot(mine);
+        }
     }
 }
 
