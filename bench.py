@@ -29,35 +29,32 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/
 def kernel_alg_bytes(name, occurrence, n, m, n_cells):
     """Algorithmic (compulsory) bytes of one launch of a kernel of the frame; DESIGN.md §Roofline.
     n = input points, m = voxels.  `occurrence` = index of this launch among launches of the same name."""
-    voxel_passes = kernel_alg_bytes.voxel_passes
-    if name == "k_minmax":
-        return 12 * (n if occurrence == 0 else m)
+    if name == "k_minmax_voxel_setup":
+        return 12 * n
     if name == "k_radix_hist":
-        if occurrence < voxel_passes:
-            return (12 if occurrence == 0 else 16) * n
-        return (12 if occurrence == voxel_passes else 16) * m
+        return (12 if occurrence == 0 else 16) * n
     if name == "k_radix_scatter":
-        if occurrence < voxel_passes:
-            return ((12 if occurrence == 0 else 16) + 16) * n
-        return ((12 if occurrence == voxel_passes else 16) + 16) * m
+        return ((12 if occurrence == 0 else 16) + 16) * n
     if name == "k_heads_count":
-        return 16 * (n if occurrence == 0 else m)
+        return 16 * n
     if name == "k_voxel_reduce":
         return 16 * n + 12 * m
-    if name == "k_cells_build":
-        return 16 * m + 4 * m + 16 * n_cells
+    if name == "k_cell_insert":
+        return 12 * m + 8 * m
+    if name == "k_cell_place":
+        return 12 * m + 8 * m + 16 * m
     if name in ("k_cell_union", "k_cell_hook"):
         return 12 * m + 4 * m          # SURVEY §8d: neighbour + cluster pass reads 12·M, writes 4·M
-    if name == "k_label_points":
-        return 16 * m + 4 * m
+    if name == "k_cell_flatten":
+        return 8 * m
     if name in ("k_csr_hist", "k_csr_scatter"):
         return 8 * m
     if name in ("k_kept_count", "k_kept_apply"):
         return 4 * m
-    if name == "k_table_scan":
-        return 0
-    if name in ("k_cell_flatten", "k_mark_kept"):
+    if name in ("k_slot_count", "k_slot_apply", "k_cell_compress"):
         return 16 * n_cells
+    if name == "k_emit":
+        return 28 * m
     return 0
 
 
@@ -165,7 +162,6 @@ def main():
             prof.wait(want_arrays=False)
             st = prof.debug_state()
             n_cells = st.n_cells
-            kernel_alg_bytes.voxel_passes = st.plan_voxel.npass
             seen = {}
             for nm, ms in prof.stage_times():
                 occ = seen.get(nm, 0)

@@ -1,9 +1,11 @@
 // pcop_capi.hip — the C ABI of include/pcop.h on top of the gfx950 kernels in pcop_device.hpp.
 //
-// One context = one GPU + one HIP stream + all the frame's buffers.  A frame is enqueued as a
-// fixed sequence of launches whose data-dependent sizes live in device memory (DevState); the
-// host syncs once to read the state, and once more after copying out exactly the bytes the
-// frame produced.  There is no CPU fallback: without a HIP device pcop_create fails.
+// One context = one GPU + one HIP stream + all the frame's buffers.  A frame is a fixed
+// sequence of kernel launches whose data-dependent sizes live in device memory (DevState) and
+// whose per-frame inputs come through a pinned mailbox (FrameArgs), so the launch arguments are
+// constant: the sequence is captured once into a hipGraph and replayed per frame.  The last
+// kernel writes the results straight into pinned host memory; the host syncs once.
+// There is no CPU fallback: without a HIP device pcop_create fails.
 #include "../../include/pcop.h"
 #include "pcop_device.hpp"
 
@@ -12,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -27,13 +30,22 @@ struct ClusterRef {
 // pcl::comparePointClusters: a.indices.size() < b.indices.size()
 inline bool compare_clusters(const ClusterRef& a, const ClusterRef& b) { return a.size < b.size; }
 
-enum FrameKind { kFrameChain = 0, kFrameVoxelOnly = 1, kFrameClusterOnly = 2 };
+struct GraphKey {
+    uint32_t kind, bucket, npass_voxel, npass_csr;
+    bool operator<(const GraphKey& o) const {
+        if (kind != o.kind) return kind < o.kind;
+        if (bucket != o.bucket) return bucket < o.bucket;
+        if (npass_voxel != o.npass_voxel) return npass_voxel < o.npass_voxel;
+        return npass_csr < o.npass_csr;
+    }
+};
 
 }  // namespace
 
 struct pcop_ctx {
     int device = -1;
     size_t cap = 0;               // max_points
+    size_t hash_cap = 0;          // slots of the cell hash table
     hipStream_t stream = nullptr;
     pcop_params params{};
     bool params_set = false;
@@ -42,17 +54,15 @@ struct pcop_ctx {
     // device buffers
     float *in_x = nullptr, *in_y = nullptr, *in_z = nullptr;      // staged input cloud (SoA)
     float *cen_x = nullptr, *cen_y = nullptr, *cen_z = nullptr;   // voxel centroids (SoA)
-    float4 *rec_a = nullptr, *rec_b = nullptr;                    // partition ping-pong
-    uint32_t *table = nullptr, *table_x = nullptr, *seg_sum = nullptr, *bin_total = nullptr;
-    uint32_t *tile_heads = nullptr;
-    uint2* tile_sums = nullptr;
+    float4 *rec_a = nullptr, *rec_b = nullptr;                    // partition ping-pong / cell-sorted records
+    uint32_t *table = nullptr, *table_x = nullptr, *bin_total = nullptr;
+    uint32_t *tile_a = nullptr, *tile_b = nullptr;                // per-tile counts
     MinMaxPartial* partials = nullptr;
-    uint32_t *rec_cell = nullptr, *cell_key = nullptr, *cell_start = nullptr, *cell_minidx = nullptr;
-    uint32_t *parent = nullptr, *cell_root = nullptr, *comp_size = nullptr, *comp_min = nullptr;
-    uint32_t *kept_val = nullptr, *rank_at = nullptr, *label = nullptr;
+    unsigned long long* hkey = nullptr;                           // cell hash table
+    uint32_t *hcount = nullptr, *hmin = nullptr;
+    uint32_t *cell_start = nullptr, *parent = nullptr, *comp_size = nullptr, *comp_rank = nullptr;   // per slot
+    uint32_t *pt_slot = nullptr, *pt_rank = nullptr, *pt_root = nullptr;                            // per point
     uint32_t *idx_a = nullptr, *idx_b = nullptr, *d_offsets = nullptr;
-    unsigned long long* hash_tab = nullptr;   // cell key -> cell id
-    float* d_pack = nullptr;      // packed output cloud (16 B/pt worst case)
     float4* d_xyzr = nullptr;
     uint8_t* d_raw = nullptr;     // raw input bytes (AoS / PointCloud2), grown on demand
     size_t d_raw_bytes = 0;
@@ -60,6 +70,7 @@ struct pcop_ctx {
     std::vector<void*> user_allocs;
 
     // pinned host buffers
+    FrameArgs* h_args = nullptr;  // mailbox read by k_frame_init
     DevState* h_state = nullptr;
     int32_t *h_offsets_disc = nullptr, *h_indices_disc = nullptr;   // discovery order, as the GPU wrote them
     int32_t *h_offsets = nullptr, *h_indices = nullptr;             // PCL order
@@ -71,13 +82,17 @@ struct pcop_ctx {
     const float *src_x = nullptr, *src_y = nullptr, *src_z = nullptr;   // device planes the frame reads
     uint32_t n = 0;
     int is_dense = 1;
-    FrameKind kind = kFrameChain;
+    uint32_t kind = kFrameChain;
+    int out_layout = PCOP_LAYOUT_AOS12;
+    bool emit_cloud = false;
     bool in_flight = false;
     bool have_result = false;
     bool result_trivial = false;  // r2 == 0: every point is its own component (built on the host)
-    uint32_t npass_voxel = kMaxPasses, npass_cell = kMaxPasses, npass_csr = kMaxPasses;
+    uint32_t npass_voxel = kMaxPasses, npass_csr = kMaxPasses;
     uint32_t* frame_csr_idx = nullptr;   // device CSR indices of the frame in flight / last frame
     int radix_bits_target = 8;    // preferred digit width when choosing pass counts
+    bool use_graph = true;
+    std::map<GraphKey, hipGraphExec_t> graphs;
 
     // profiling
     bool profiling = false;
@@ -113,7 +128,7 @@ int host_alloc(pcop_ctx* c, T** p, size_t count) {
 
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// stage marker for profiling: an event after each named group of launches
+// profiling: an event after every launch (eager mode only)
 void mark(pcop_ctx* c, const char* name) {
     if (!c->profiling) return;
     if (c->ev_used >= c->events.size()) {
@@ -127,119 +142,101 @@ void mark(pcop_ctx* c, const char* name) {
     ++c->ev_used;
 }
 
-uint32_t partition_grid(uint32_t n) { return std::max(1u, div_up(n, kTile)); }
-uint32_t scan_grid(uint32_t n) { return std::max(1u, div_up(n, kScanTile)); }
 uint32_t stride_grid(uint32_t n) { return std::min(2048u, std::max(1u, div_up(n, kBlock))); }
 
-void launch_table_scan(pcop_ctx* c, int which, int pass) {
-    k_table_scan<<<kMaxBins, kBlock, 0, c->stream>>>(c->d_state, which, pass, c->table, c->table_x, c->bin_total);
-    mark(c, "k_table_scan");
+uint32_t bucket_of(const pcop_ctx* c, uint32_t n) {   // launch-size bucket: next power of two, at most cap
+    uint32_t b = 1024;
+    while (b < n) b <<= 1;
+    return (uint32_t)std::min<size_t>(b, std::max<size_t>(c->cap, 1024));
 }
 
-// Stable LSD partition by the voxel (which=0) or cell (which=1) key; returns the sorted buffer.
-template <class KeyFn>
-float4* launch_partition(pcop_ctx* c, int which, uint32_t npass, uint32_t n_max, SoaSrc s_a, SoaSrc s_b) {
-    const uint32_t g = partition_grid(n_max);
-    float4* bufs[2] = {c->rec_a, c->rec_b};
-    float4* out = nullptr;
-    for (uint32_t p = 0; p < npass; ++p) {
-        out = bufs[p & 1];
-        if (p == 0) {
-            k_radix_hist<SoaSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(s_a, s_b, c->d_state, which, (int)p, c->table);
-            mark(c, "k_radix_hist");
-            launch_table_scan(c, which, (int)p);
-            k_radix_scatter<SoaSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(s_a, s_b, c->d_state, which, (int)p, c->table_x,
-                                                                        c->bin_total, out);
-            mark(c, "k_radix_scatter");
-        } else {
-            RecSrc r{bufs[(p - 1) & 1]};
-            k_radix_hist<RecSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(r, r, c->d_state, which, (int)p, c->table);
-            mark(c, "k_radix_hist");
-            launch_table_scan(c, which, (int)p);
-            k_radix_scatter<RecSrc, KeyFn><<<g, kBlock, 0, c->stream>>>(r, r, c->d_state, which, (int)p, c->table_x,
-                                                                        c->bin_total, out);
-            mark(c, "k_radix_scatter");
+uint32_t hash_cap_for(uint32_t n) {
+    uint32_t cap = 1024;
+    while (cap < 2u * n && cap < 0x80000000u) cap <<= 1;
+    return cap;
+}
+
+CellTable cell_table(pcop_ctx* c) { return CellTable{c->hkey, c->hcount, c->hmin}; }
+
+// The launch sequence of one frame.  nb = launch-size bucket (>= the frame's point count); all
+// real counts are read on the device.  Everything here is capturable into a hipGraph.
+void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb) {
+    hipStream_t s = c->stream;
+    k_frame_init<<<1, 64, 0, s>>>(c->d_state, c->h_args);
+    mark(c, "k_frame_init");
+    const uint32_t pg = std::max(1u, div_up(nb, kTile));        // partition tiles
+    const uint32_t sg = std::max(1u, div_up(nb, kScanTile));    // scan tiles over points
+    const uint32_t tg = stride_grid(nb);
+    if (kind != kFrameClusterOnly) {
+        k_minmax_voxel_setup<<<kReduceBlocks, kBlock, 0, s>>>(c->d_state, c->partials, c->npass_voxel);
+        mark(c, "k_minmax_voxel_setup");
+        float4* bufs[2] = {c->rec_a, c->rec_b};
+        float4* sorted = nullptr;
+        for (uint32_t p = 0; p < c->npass_voxel; ++p) {
+            sorted = bufs[p & 1];
+            if (p == 0) {
+                k_radix_hist<SoaSrc><<<pg, kBlock, 0, s>>>(SoaSrc{}, c->d_state, (int)p, c->table);
+                mark(c, "k_radix_hist");
+                k_table_scan<<<kMaxBins, kBlock, 0, s>>>(c->d_state, 0, (int)p, c->table, c->table_x, c->bin_total);
+                mark(c, "k_table_scan");
+                k_radix_scatter<SoaSrc><<<pg, kBlock, 0, s>>>(SoaSrc{}, c->d_state, (int)p, c->table_x, c->bin_total, sorted);
+                mark(c, "k_radix_scatter");
+            } else {
+                RecSrc r{bufs[(p - 1) & 1]};
+                k_radix_hist<RecSrc><<<pg, kBlock, 0, s>>>(r, c->d_state, (int)p, c->table);
+                mark(c, "k_radix_hist");
+                k_table_scan<<<kMaxBins, kBlock, 0, s>>>(c->d_state, 0, (int)p, c->table, c->table_x, c->bin_total);
+                mark(c, "k_table_scan");
+                k_radix_scatter<RecSrc><<<pg, kBlock, 0, s>>>(r, c->d_state, (int)p, c->table_x, c->bin_total, sorted);
+                mark(c, "k_radix_scatter");
+            }
+        }
+        k_heads_count<<<sg, kBlock, 0, s>>>(sorted, c->d_state, c->tile_a);
+        mark(c, "k_heads_count");
+        k_voxel_reduce<<<sg, kBlock, 0, s>>>(sorted, c->d_state, c->tile_a, c->cen_x, c->cen_y, c->cen_z);
+        mark(c, "k_voxel_reduce");
+    }
+    if (kind != kFrameVoxelOnly) {
+        const CellTable tab = cell_table(c);
+        const uint32_t hcap = hash_cap_for(nb);
+        const uint32_t hg = std::max(1u, hcap / kScanTile);       // scan tiles over hash slots
+        const uint32_t wg = std::min(8192u, std::max(1u, hcap / kWavesPerBlock));   // one wave per slot, grid-strided
+        k_cell_insert<<<tg, kBlock, 0, s>>>(c->d_state, c->cen_x, c->cen_y, c->cen_z, tab, c->pt_slot, c->pt_rank);
+        mark(c, "k_cell_insert");
+        k_slot_count<<<hg, kBlock, 0, s>>>(c->d_state, c->hcount, c->tile_a);
+        mark(c, "k_slot_count");
+        k_slot_apply<<<hg, kBlock, 0, s>>>(c->d_state, c->hcount, c->tile_a, c->cell_start, c->parent, c->comp_size, c->comp_rank);
+        mark(c, "k_slot_apply");
+        k_cell_place<<<tg, kBlock, 0, s>>>(c->d_state, c->cen_x, c->cen_y, c->cen_z, c->pt_slot, c->pt_rank, c->cell_start, c->rec_a);
+        mark(c, "k_cell_place");
+        k_cell_hook<<<wg, kBlock, 0, s>>>(c->rec_a, c->d_state, tab, c->cell_start, c->parent);
+        mark(c, "k_cell_hook");
+        k_cell_compress<<<stride_grid(hcap), kBlock, 0, s>>>(c->d_state, c->hcount, c->parent);
+        mark(c, "k_cell_compress");
+        k_cell_union<<<wg, kBlock, 0, s>>>(c->rec_a, c->d_state, tab, c->cell_start, c->parent);
+        mark(c, "k_cell_union");
+        k_cell_flatten<<<tg, kBlock, 0, s>>>(c->d_state, c->pt_slot, c->parent, c->pt_root, c->comp_size);
+        mark(c, "k_cell_flatten");
+        k_kept_count<<<sg, kBlock, 0, s>>>(c->d_state, c->pt_root, c->hmin, c->comp_size, c->tile_a, c->tile_b);
+        mark(c, "k_kept_count");
+        k_kept_apply<<<sg, kBlock, 0, s>>>(c->d_state, c->pt_root, c->hmin, c->comp_size, c->tile_a, c->tile_b, c->comp_rank,
+                                           c->d_offsets, c->npass_csr);
+        mark(c, "k_kept_apply");
+        uint32_t* bufs[2] = {c->idx_a, c->idx_b};
+        for (uint32_t p = 0; p < c->npass_csr; ++p) {
+            const uint32_t* in = p == 0 ? nullptr : bufs[(p - 1) & 1];
+            k_csr_hist<<<pg, kBlock, 0, s>>>(in, c->pt_root, c->comp_rank, c->d_state, (int)p, c->table);
+            mark(c, "k_csr_hist");
+            k_table_scan<<<kMaxBins, kBlock, 0, s>>>(c->d_state, 2, (int)p, c->table, c->table_x, c->bin_total);
+            mark(c, "k_table_scan");
+            k_csr_scatter<<<pg, kBlock, 0, s>>>(in, c->pt_root, c->comp_rank, c->d_state, (int)p, c->table_x, c->bin_total, bufs[p & 1]);
+            mark(c, "k_csr_scatter");
         }
     }
-    return out;
-}
-
-
-void enqueue_voxel(pcop_ctx* c) {
-    const uint32_t n = c->n;
-    SoaPair src{nullptr, nullptr, nullptr, c->src_x, c->src_y, c->src_z};
-    k_minmax<<<kReduceBlocks, kBlock, 0, c->stream>>>(src, c->d_state, 0, c->partials);
-    mark(c, "k_minmax");
-    k_voxel_setup<<<1, kBlock, 0, c->stream>>>(c->d_state, c->partials, kReduceBlocks, c->npass_voxel);
-    mark(c, "k_voxel_setup");
-    SoaSrc s{c->src_x, c->src_y, c->src_z};
-    float4* sorted = launch_partition<VoxelKey>(c, 0, c->npass_voxel, n, s, s);
-    const uint32_t sg = scan_grid(n);
-    k_heads_count<VoxelKey><<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, 0, c->tile_heads);
-    mark(c, "k_heads_count");
-    k_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_heads, c->d_state, 0, 0);
-    mark(c, "k_scan_tiles");
-    k_voxel_reduce<<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->tile_heads, c->cen_x, c->cen_y, c->cen_z);
-    mark(c, "k_voxel_reduce");
-    k_voxel_passthrough<<<1, 64, 0, c->stream>>>(c->d_state);
-    mark(c, "k_voxel_passthrough");
-}
-
-void enqueue_cluster(pcop_ctx* c, int force_input) {
-    const uint32_t n = c->n;   // upper bound of c_n
-    k_cluster_source<<<1, 64, 0, c->stream>>>(c->d_state, force_input);
-    mark(c, "k_cluster_source");
-    SoaPair src{c->cen_x, c->cen_y, c->cen_z, c->src_x, c->src_y, c->src_z};
-    k_minmax<<<kReduceBlocks, kBlock, 0, c->stream>>>(src, c->d_state, 1, c->partials);
-    mark(c, "k_minmax");
-    k_cell_setup<<<1, kBlock, 0, c->stream>>>(c->d_state, c->partials, kReduceBlocks, c->npass_cell);
-    mark(c, "k_cell_setup");
-    SoaSrc s_a{c->cen_x, c->cen_y, c->cen_z}, s_b{c->src_x, c->src_y, c->src_z};
-    float4* sorted = launch_partition<CellKey>(c, 1, c->npass_cell, n, s_a, s_b);
-    const uint32_t sg = scan_grid(n);
-    k_heads_count<CellKey><<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, 1, c->tile_heads);
-    mark(c, "k_heads_count");
-    k_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_heads, c->d_state, 1, 1);
-    mark(c, "k_scan_tiles");
-    k_hash_clear<<<stride_grid(2 * n + 1024), kBlock, 0, c->stream>>>(c->d_state, c->hash_tab);
-    mark(c, "k_hash_clear");
-    k_cells_build<<<sg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->tile_heads, c->rec_cell, c->cell_key, c->cell_start,
-                                                 c->cell_minidx, c->parent, c->comp_size, c->comp_min, c->kept_val,
-                                                 c->hash_tab);
-    mark(c, "k_cells_build");
-    const uint32_t ug = std::min(8192u, std::max(1u, div_up(n, kWavesPerBlock)));
-    k_cell_hook<<<ug, kBlock, 0, c->stream>>>(sorted, c->d_state, c->cell_key, c->cell_start, c->hash_tab, c->parent);
-    mark(c, "k_cell_hook");
-    k_cell_compress<<<stride_grid(n), kBlock, 0, c->stream>>>(c->d_state, c->parent);
-    mark(c, "k_cell_compress");
-    k_cell_union<<<ug, kBlock, 0, c->stream>>>(sorted, c->d_state, c->cell_key, c->cell_start, c->hash_tab, c->parent);
-    mark(c, "k_cell_union");
-    const uint32_t tg = stride_grid(n);
-    k_cell_flatten<<<tg, kBlock, 0, c->stream>>>(c->d_state, c->cell_start, c->cell_minidx, c->parent, c->cell_root,
-                                                  c->comp_size, c->comp_min);
-    mark(c, "k_cell_flatten");
-    k_mark_kept<<<tg, kBlock, 0, c->stream>>>(c->d_state, c->cell_root, c->comp_size, c->comp_min, c->kept_val);
-    mark(c, "k_mark_kept");
-    k_kept_count<<<sg, kBlock, 0, c->stream>>>(c->d_state, c->kept_val, c->tile_sums);
-    mark(c, "k_kept_count");
-    k_kept_scan_tiles<<<1, kBlock, 0, c->stream>>>(c->tile_sums, c->d_state, c->d_offsets, c->npass_csr);
-    mark(c, "k_kept_scan_tiles");
-    k_kept_apply<<<sg, kBlock, 0, c->stream>>>(c->d_state, c->kept_val, c->tile_sums, c->rank_at, c->d_offsets);
-    mark(c, "k_kept_apply");
-    k_label_points<<<tg, kBlock, 0, c->stream>>>(sorted, c->d_state, c->rec_cell, c->cell_root, c->comp_size, c->comp_min,
-                                                  c->rank_at, c->label);
-    mark(c, "k_label_points");
-    const uint32_t g = partition_grid(n);
-    uint32_t* bufs[2] = {c->idx_a, c->idx_b};
-    for (uint32_t p = 0; p < c->npass_csr; ++p) {
-        const uint32_t* in = p == 0 ? nullptr : bufs[(p - 1) & 1];
-        k_csr_hist<<<g, kBlock, 0, c->stream>>>(in, c->label, c->d_state, (int)p, c->table);
-        mark(c, "k_csr_hist");
-        launch_table_scan(c, 2, (int)p);
-        k_csr_scatter<<<g, kBlock, 0, c->stream>>>(in, c->label, c->d_state, (int)p, c->table_x, c->bin_total, bufs[p & 1]);
-        mark(c, "k_csr_scatter");
-    }
-    c->frame_csr_idx = bufs[(c->npass_csr - 1) & 1];
+    uint32_t* csr = ((c->npass_csr - 1) & 1) ? c->idx_b : c->idx_a;
+    HostOut ho{c->h_state, reinterpret_cast<uint32_t*>(c->h_offsets_disc), reinterpret_cast<uint32_t*>(c->h_indices_disc), c->h_vox};
+    k_emit<<<tg, kBlock, 0, s>>>(c->d_state, ho, c->d_offsets, csr, c->cen_x, c->cen_y, c->cen_z, cell_table(c));
+    mark(c, "k_emit");
 }
 
 int enqueue_frame(pcop_ctx* c) {
@@ -247,19 +244,36 @@ int enqueue_frame(pcop_ctx* c) {
     const float inv_leaf = 1.0f / p.leaf;                         // Array4f::Ones() / leaf_size_
     const double radius = (double)p.tol;
     const float r2 = (float)(radius * radius);                    // KdTreeFLANN::radiusSearch
-    const double inv_cell = 1.99 / std::fabs((double)p.tol);
-    c->result_trivial = !(r2 > 0.0f);
+    c->result_trivial = c->kind != kFrameVoxelOnly && !(r2 > 0.0f);
+    FrameArgs& a = *c->h_args;
+    a.n = c->n; a.is_dense = c->is_dense ? 1u : 0u; a.kind = c->kind; a.trivial = c->result_trivial ? 1u : 0u;
+    a.inv_leaf = inv_leaf; a.r2 = r2;
+    a.inv_cell = c->result_trivial ? 1.0 : 1.99 / std::fabs((double)p.tol);
+    a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
+    a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = c->n; a.pad = 0;
+    a.src_x = c->src_x; a.src_y = c->src_y; a.src_z = c->src_z;
+    c->frame_csr_idx = ((c->npass_csr - 1) & 1) ? c->idx_b : c->idx_a;
+    const uint32_t nb = bucket_of(c, c->n);
     c->ev_used = 0;
-    mark(c, "start");
-    k_frame_init<<<1, 64, 0, c->stream>>>(c->d_state, c->n, (uint32_t)(c->is_dense ? 1 : 0), inv_leaf, r2,
-                                          c->result_trivial ? 1.0 : inv_cell, (uint32_t)p.min_cluster,
-                                          (uint32_t)p.max_cluster);
-    mark(c, "k_frame_init");
-    if (c->kind != kFrameClusterOnly) enqueue_voxel(c);
-    if (c->kind != kFrameVoxelOnly && !c->result_trivial) enqueue_cluster(c, c->kind == kFrameClusterOnly ? 1 : 0);
-    else if (c->kind != kFrameVoxelOnly) k_cluster_source<<<1, 64, 0, c->stream>>>(c->d_state, c->kind == kFrameClusterOnly ? 1 : 0);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    if (c->profiling || !c->use_graph) {
+        mark(c, "start");
+        enqueue_launches(c, c->kind, nb);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        const GraphKey key{c->kind, nb, c->npass_voxel, c->npass_csr};
+        auto it = c->graphs.find(key);
+        if (it == c->graphs.end()) {
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            enqueue_launches(c, c->kind, nb);
+            HIPCHK(c, hipStreamEndCapture(c->stream, &g));
+            HIPCHK(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+            it = c->graphs.emplace(key, ge).first;
+        }
+        HIPCHK(c, hipGraphLaunch(it->second, c->stream));
+    }
     c->in_flight = true;
     c->have_result = false;
     return PCOP_OK;
@@ -284,8 +298,8 @@ void collect_times(pcop_ctx* c) {
     }
 }
 
-// Waits for the frame, re-running it when a radix plan was too short, then copies out exactly
-// what was produced and puts the clusters in PCL's order.
+// Waits for the frame (re-running it when a radix plan was too short) and puts the clusters in
+// PCL's order.  The kernels have already written everything into pinned host memory.
 int finish_frame(pcop_ctx* c, pcop_result* out) {
     if (!c->in_flight) return PCOP_ERR_STATE;
     DevState* hs = c->h_state;
@@ -293,11 +307,10 @@ int finish_frame(pcop_ctx* c, pcop_result* out) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const uint32_t e = hs->err;
         if (e & kErrNonFinite) { c->in_flight = false; c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
-        if (e & kErrRange) { c->in_flight = false; c->err = "neighbour cell grid exceeds 2^32 cells (extent / tolerance too large)"; return PCOP_ERR_RANGE; }
-        if (e & (kErrReplanVoxel | kErrReplanCell | kErrReplanCsr)) {
+        if (e & kErrRange) { c->in_flight = false; c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
+        if (e & (kErrReplanVoxel | kErrReplanCsr)) {
             if (attempt >= 4) { c->in_flight = false; c->err = "radix replanning did not converge"; return PCOP_ERR_STATE; }
             if (e & kErrReplanVoxel) c->npass_voxel = passes_for(hs->plan_voxel.key_bits, c->radix_bits_target);
-            if (e & kErrReplanCell) c->npass_cell = passes_for(hs->plan_cell.key_bits, c->radix_bits_target);
             if (e & kErrReplanCsr) c->npass_csr = passes_for(hs->plan_csr.key_bits, c->radix_bits_target);
             int rc = enqueue_frame(c);
             if (rc) return rc;
@@ -308,36 +321,21 @@ int finish_frame(pcop_ctx* c, pcop_result* out) {
     collect_times(c);
     c->in_flight = false;
     // adapt the pass counts of the next frame to what this one needed
-    if (c->kind != kFrameClusterOnly && !hs->passthrough) c->npass_voxel = passes_for(hs->plan_voxel.key_bits, c->radix_bits_target);
+    if (c->kind != kFrameClusterOnly && !hs->passthrough && hs->n_valid) c->npass_voxel = passes_for(hs->plan_voxel.key_bits, c->radix_bits_target);
     const uint32_t m = hs->m;
     const bool clustered = c->kind != kFrameVoxelOnly;
-    uint32_t k = 0, total = 0;
+    uint32_t k = 0;
     if (clustered && !c->result_trivial) {
-        c->npass_cell = passes_for(hs->plan_cell.key_bits, c->radix_bits_target);
-        k = hs->n_kept; total = hs->n_kept_pts;
-        // npass_csr is changed only after this frame's indices have been located
-        if (k) {
-            HIPCHK(c, hipMemcpyAsync(c->h_offsets_disc, c->d_offsets, (size_t)(k + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_indices_disc, c->frame_csr_idx, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
-        }
+        k = hs->n_kept;
+        c->npass_csr = passes_for(hs->plan_csr.key_bits, c->radix_bits_target);
     }
-    const bool want_cloud = c->kind == kFrameChain && c->params.publish_clouds != 0;
-    if (want_cloud && m) {
-        const float *px = hs->passthrough ? c->src_x : c->cen_x, *py = hs->passthrough ? c->src_y : c->cen_y,
-                    *pz = hs->passthrough ? c->src_z : c->cen_z;
-        k_pack_points<<<stride_grid(m), kBlock, 0, c->stream>>>(px, py, pz, &c->d_state->m, PCOP_LAYOUT_AOS12, 0, c->d_pack);
-        HIPCHK(c, hipMemcpyAsync(c->h_vox, c->d_pack, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (clustered && !c->result_trivial) c->npass_csr = passes_for(hs->plan_csr.key_bits, c->radix_bits_target);
-
     // extract(): std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters)
-    const uint32_t c_n = clustered ? hs->c_n : 0;
     if (clustered && c->result_trivial) {
         // r2 == 0: radiusSearch returns nothing, every point is a cluster of one
         const pcop_params& p = c->params;
         const bool keep = (uint32_t)p.min_cluster <= 1u && 1u <= (uint32_t)p.max_cluster;
-        k = keep ? c_n : 0; total = k;
+        const uint32_t c_n = c->kind == kFrameClusterOnly ? c->n : m;
+        k = keep ? c_n : 0;
         for (uint32_t i = 0; i < k; ++i) { c->h_offsets_disc[i] = (int32_t)i; c->h_indices_disc[i] = (int32_t)i; }
         c->h_offsets_disc[k] = (int32_t)k;
     }
@@ -363,7 +361,7 @@ int finish_frame(pcop_ctx* c, pcop_result* out) {
         out->num_indices = pos;
         out->offsets = c->h_offsets;
         out->indices = c->h_indices;
-        out->voxel_xyz = (want_cloud && m) ? c->h_vox : nullptr;
+        out->voxel_xyz = (c->emit_cloud && m) ? c->h_vox : nullptr;
     }
     return PCOP_OK;
 }
@@ -448,7 +446,7 @@ const char* pcop_status_string(int s) {
 int pcop_create(pcop_ctx** out, int device_id, size_t max_points) {
     if (!out) return PCOP_ERR_ARG;
     *out = nullptr;
-    if (max_points == 0 || max_points > 0x7FFFFFF0ull) return PCOP_ERR_ARG;
+    if (max_points == 0 || max_points > 0x3FFFFFF0ull) return PCOP_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PCOP_ERR_NO_DEVICE;
     if (device_id < 0 || device_id >= ndev) return PCOP_ERR_NO_DEVICE;
@@ -460,10 +458,14 @@ int pcop_create(pcop_ctx** out, int device_id, size_t max_points) {
         const int b = atoi(e);
         if (b >= 4 && b <= kMaxBits) c->radix_bits_target = b;
     }
+    if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     int rc = PCOP_OK;
-    const size_t n = max_points;
+    const size_t nbk = bucket_of(c, (uint32_t)max_points);           // launch sizes round up to this
+    const size_t n = std::max<size_t>(max_points, nbk);
     const size_t ntiles = (n + kTile - 1) / kTile + 1;
-    const size_t nscan = (n + kScanTile - 1) / kScanTile + 1;
+    const size_t hcap = hash_cap_for((uint32_t)n);
+    c->hash_cap = hcap;
+    const size_t nscan = std::max((n + kScanTile - 1) / kScanTile, hcap / kScanTile) + 1;
 #define TRY(x) do { rc = (x); if (rc) { std::string m_ = c->err; fprintf(stderr, "pcop_create: %s\n", m_.c_str()); pcop_destroy(c); return rc; } } while (0)
     if (hipSetDevice(device_id) != hipSuccess) { delete c; return PCOP_ERR_NO_DEVICE; }
     { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return PCOP_ERR_HIP; } }
@@ -471,27 +473,30 @@ int pcop_create(pcop_ctx** out, int device_id, size_t max_points) {
     TRY(dev_alloc(c, &c->cen_x, n)); TRY(dev_alloc(c, &c->cen_y, n)); TRY(dev_alloc(c, &c->cen_z, n));
     TRY(dev_alloc(c, &c->rec_a, n)); TRY(dev_alloc(c, &c->rec_b, n));
     TRY(dev_alloc(c, &c->table, ntiles * kMaxBins)); TRY(dev_alloc(c, &c->table_x, ntiles * kMaxBins));
-    TRY(dev_alloc(c, &c->seg_sum, (size_t)kSegs * kMaxBins)); TRY(dev_alloc(c, &c->bin_total, (size_t)kMaxBins));
-    TRY(dev_alloc(c, &c->tile_heads, nscan)); TRY(dev_alloc(c, &c->tile_sums, nscan));
+    TRY(dev_alloc(c, &c->bin_total, (size_t)kMaxBins));
+    TRY(dev_alloc(c, &c->tile_a, nscan)); TRY(dev_alloc(c, &c->tile_b, nscan));
     TRY(dev_alloc(c, &c->partials, (size_t)kReduceBlocks));
-    TRY(dev_alloc(c, &c->rec_cell, n)); TRY(dev_alloc(c, &c->cell_key, n + 1)); TRY(dev_alloc(c, &c->cell_start, n + 2));
-    TRY(dev_alloc(c, &c->cell_minidx, n + 1)); TRY(dev_alloc(c, &c->parent, n + 1)); TRY(dev_alloc(c, &c->cell_root, n + 1));
-    TRY(dev_alloc(c, &c->comp_size, n + 1)); TRY(dev_alloc(c, &c->comp_min, n + 1));
-    TRY(dev_alloc(c, &c->kept_val, n + 1)); TRY(dev_alloc(c, &c->rank_at, n + 1)); TRY(dev_alloc(c, &c->label, n + 1));
+    TRY(dev_alloc(c, &c->hkey, hcap)); TRY(dev_alloc(c, &c->hcount, hcap)); TRY(dev_alloc(c, &c->hmin, hcap));
+    TRY(dev_alloc(c, &c->cell_start, hcap)); TRY(dev_alloc(c, &c->parent, hcap));
+    TRY(dev_alloc(c, &c->comp_size, hcap)); TRY(dev_alloc(c, &c->comp_rank, hcap));
+    TRY(dev_alloc(c, &c->pt_slot, n + 1)); TRY(dev_alloc(c, &c->pt_rank, n + 1)); TRY(dev_alloc(c, &c->pt_root, n + 1));
     TRY(dev_alloc(c, &c->idx_a, n + 1)); TRY(dev_alloc(c, &c->idx_b, n + 1)); TRY(dev_alloc(c, &c->d_offsets, n + 2));
-    TRY(dev_alloc(c, &c->d_pack, 4 * n)); TRY(dev_alloc(c, &c->d_xyzr, n + 1));
-    {
-        size_t hcap = 1024;
-        while (hcap < 2 * (n + 1)) hcap <<= 1;
-        TRY(dev_alloc(c, &c->hash_tab, hcap));
-    }
+    TRY(dev_alloc(c, &c->d_xyzr, n + 1));
     TRY(dev_alloc(c, &c->d_state, 1));
+    TRY(host_alloc(c, &c->h_args, 1));
     TRY(host_alloc(c, &c->h_state, 1));
     TRY(host_alloc(c, &c->h_offsets_disc, n + 2)); TRY(host_alloc(c, &c->h_indices_disc, n + 1));
     TRY(host_alloc(c, &c->h_offsets, n + 2)); TRY(host_alloc(c, &c->h_indices, n + 1));
-    TRY(host_alloc(c, &c->h_vox, 3 * n)); TRY(host_alloc(c, &c->h_xyzr, 4 * (n + 1)));
+    TRY(host_alloc(c, &c->h_vox, 4 * n)); TRY(host_alloc(c, &c->h_xyzr, 4 * (n + 1)));
+    // the cell table starts empty; afterwards every frame's k_emit leaves it empty again
+    if (hipMemset(c->hkey, 0, hcap * 8) != hipSuccess || hipMemset(c->hcount, 0, hcap * 4) != hipSuccess ||
+        hipMemset(c->hmin, 0xFF, hcap * 4) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        c->err = "hipMemset of the cell table failed";
+        TRY(PCOP_ERR_HIP);
+    }
 #undef TRY
     std::memset(c->h_state, 0, sizeof(DevState));
+    std::memset(c->h_args, 0, sizeof(FrameArgs));
     *out = c;
     return PCOP_OK;
 }
@@ -500,13 +505,14 @@ void pcop_destroy(pcop_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     void* dev[] = {c->in_x, c->in_y, c->in_z, c->cen_x, c->cen_y, c->cen_z, c->rec_a, c->rec_b, c->table, c->table_x,
-                   c->seg_sum, c->bin_total, c->tile_heads, c->tile_sums, c->partials, c->rec_cell, c->cell_key,
-                   c->cell_start, c->cell_minidx, c->parent, c->cell_root, c->comp_size, c->comp_min, c->kept_val,
-                   c->rank_at, c->label, c->idx_a, c->idx_b, c->d_offsets, c->d_pack, c->d_xyzr, c->d_raw, c->d_state, c->hash_tab};
+                   c->bin_total, c->tile_a, c->tile_b, c->partials, c->hkey, c->hcount, c->hmin, c->cell_start, c->parent,
+                   c->comp_size, c->comp_rank, c->pt_slot, c->pt_rank, c->pt_root, c->idx_a, c->idx_b, c->d_offsets,
+                   c->d_xyzr, c->d_raw, c->d_state};
     for (void* p : dev) if (p) hipFree(p);
     for (void* p : c->user_allocs) if (p) hipFree(p);
-    void* host[] = {c->h_state, c->h_offsets_disc, c->h_indices_disc, c->h_offsets, c->h_indices, c->h_vox, c->h_xyzr};
+    void* host[] = {c->h_args, c->h_state, c->h_offsets_disc, c->h_indices_disc, c->h_offsets, c->h_indices, c->h_vox, c->h_xyzr};
     for (void* p : host) if (p) hipHostFree(p);
     for (hipEvent_t e : c->events) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -545,44 +551,41 @@ void* pcop_stream(const pcop_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int pcop_voxel_downsample(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, float* out_xyz,
                           size_t* out_m, int* passthrough) {
     if (!c || !out_m || !passthrough || (!out_xyz && n)) return PCOP_ERR_ARG;
+    if (c->in_flight) { c->err = "a frame is already in flight on this context"; return PCOP_ERR_STATE; }
     int rc = check_params(c, true, false);
     if (rc) return rc;
     if ((rc = set_device(c))) return rc;
     if ((rc = stage_input(c, xyz, layout, n, PCOP_MEM_HOST))) return rc;
-    c->is_dense = is_dense; c->kind = kFrameVoxelOnly;
+    c->is_dense = is_dense; c->kind = kFrameVoxelOnly; c->emit_cloud = true; c->out_layout = layout;
     if ((rc = enqueue_frame(c))) return rc;
     pcop_result r{};
     if ((rc = finish_frame(c, &r))) return rc;
     *out_m = (size_t)r.num_voxels;
     *passthrough = r.passthrough;
     if (r.num_voxels == 0) return PCOP_OK;
+    const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
     if (r.passthrough) {   // "output = *input_"
-        const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
         std::memcpy(out_xyz, xyz, n * fl * sizeof(float));
         return PCOP_OK;
     }
-    const uint32_t m = (uint32_t)r.num_voxels;
-    k_pack_points<<<stride_grid(m), kBlock, 0, c->stream>>>(c->cen_x, c->cen_y, c->cen_z, &c->d_state->m, layout, (uint32_t)n, c->d_pack);
-    HIPCHK(c, hipGetLastError());
+    const size_t m = (size_t)r.num_voxels;
     if (layout == PCOP_LAYOUT_SOA) {
-        for (int a = 0; a < 3; ++a)
-            HIPCHK(c, hipMemcpyAsync(out_xyz + (size_t)a * n, c->d_pack + (size_t)a * n, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        for (int a = 0; a < 3; ++a) std::memcpy(out_xyz + (size_t)a * n, c->h_vox + (size_t)a * n, m * 4);
     } else {
-        const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
-        HIPCHK(c, hipMemcpyAsync(out_xyz, c->d_pack, (size_t)m * fl * 4, hipMemcpyDeviceToHost, c->stream));
+        std::memcpy(out_xyz, c->h_vox, m * fl * 4);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PCOP_OK;
 }
 
 int pcop_euclidean_clusters(pcop_ctx* c, const float* xyz, int layout, size_t m, int32_t* offsets, int32_t* indices,
                             int32_t* k) {
     if (!c || !offsets || !k || (!indices && m)) return PCOP_ERR_ARG;
+    if (c->in_flight) { c->err = "a frame is already in flight on this context"; return PCOP_ERR_STATE; }
     int rc = check_params(c, false, true);
     if (rc) return rc;
     if ((rc = set_device(c))) return rc;
     if ((rc = stage_input(c, xyz, layout, m, PCOP_MEM_HOST))) return rc;
-    c->is_dense = 1; c->kind = kFrameClusterOnly;
+    c->is_dense = 1; c->kind = kFrameClusterOnly; c->emit_cloud = false; c->out_layout = PCOP_LAYOUT_AOS12;
     if ((rc = enqueue_frame(c))) return rc;
     pcop_result r{};
     if ((rc = finish_frame(c, &r))) return rc;
@@ -600,7 +603,7 @@ int pcop_submit_xyz(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_
     if (mem != PCOP_MEM_HOST && mem != PCOP_MEM_DEVICE) return PCOP_ERR_ARG;
     if ((rc = set_device(c))) return rc;
     if ((rc = stage_input(c, xyz, layout, n, mem))) return rc;
-    c->is_dense = is_dense; c->kind = kFrameChain;
+    c->is_dense = is_dense; c->kind = kFrameChain; c->emit_cloud = c->params.publish_clouds != 0; c->out_layout = PCOP_LAYOUT_AOS12;
     return enqueue_frame(c);
 }
 
@@ -644,35 +647,38 @@ int pcop_process_pointcloud2(pcop_ctx* c, const uint8_t* data, uint32_t width, u
                                                                            is_bigendian, c->in_x, c->in_y, c->in_z);
         HIPCHK(c, hipGetLastError());
     }
-    c->is_dense = is_dense; c->kind = kFrameChain;
+    c->is_dense = is_dense; c->kind = kFrameChain; c->emit_cloud = c->params.publish_clouds != 0; c->out_layout = PCOP_LAYOUT_AOS12;
     if ((rc = enqueue_frame(c))) return rc;
     return finish_frame(c, out);
 }
 
 int pcop_cluster_summaries(pcop_ctx* c, float* xyzr, int32_t cap_clusters) {
     if (!c || (!xyzr && cap_clusters)) return PCOP_ERR_ARG;
-    if (!c->have_result) { c->err = "no clustered frame on this context"; return PCOP_ERR_STATE; }
+    if (!c->have_result || c->in_flight) { c->err = "no finished clustered frame on this context"; return PCOP_ERR_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
     const uint32_t k = (uint32_t)c->order.size();
     if (k == 0) return PCOP_OK;
     if ((uint32_t)cap_clusters < k) return PCOP_ERR_ARG;
-    SoaPair src{c->cen_x, c->cen_y, c->cen_z, c->src_x, c->src_y, c->src_z};
     if (c->result_trivial) {
-        // singletons: centre = the point, r = 0; read the points back through the packed buffer
-        const bool from_input = c->h_state->c_from_input != 0;
+        // singletons: centre = the point itself, r = 0
+        const bool from_input = c->kind == kFrameClusterOnly || c->h_state->passthrough;
         const float *px = from_input ? c->src_x : c->cen_x, *py = from_input ? c->src_y : c->cen_y, *pz = from_input ? c->src_z : c->cen_z;
-        k_pack_points<<<stride_grid(k), kBlock, 0, c->stream>>>(px, py, pz, &c->d_state->c_n, PCOP_LAYOUT_AOS16, 0, c->d_pack);
-        HIPCHK(c, hipMemcpyAsync(c->h_xyzr, c->d_pack, (size_t)k * 16, hipMemcpyDeviceToHost, c->stream));
+        float* tmp = c->h_xyzr;   // 3 planes of k floats
+        HIPCHK(c, hipMemcpyAsync(tmp, px, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tmp + k, py, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(tmp + 2 * (size_t)k, pz, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<float> o(4 * (size_t)k);
         for (uint32_t i = 0; i < k; ++i) {
-            const float* s = c->h_xyzr + 4 * (size_t)c->order[i];
-            xyzr[4 * i] = s[0]; xyzr[4 * i + 1] = s[1]; xyzr[4 * i + 2] = s[2]; xyzr[4 * i + 3] = 0.0f;
+            const uint32_t s = (uint32_t)c->order[i];
+            o[4 * (size_t)i] = tmp[s]; o[4 * (size_t)i + 1] = tmp[k + s]; o[4 * (size_t)i + 2] = tmp[2 * (size_t)k + s]; o[4 * (size_t)i + 3] = 0.0f;
         }
+        std::memcpy(xyzr, o.data(), o.size() * 4);
         return PCOP_OK;
     }
     k_cluster_summaries<<<std::min(2048u, std::max(1u, div_up(k, kWavesPerBlock))), kBlock, 0, c->stream>>>(
-        src, c->d_state, c->d_offsets, c->frame_csr_idx, c->d_xyzr);
+        c->d_state, c->cen_x, c->cen_y, c->cen_z, c->d_offsets, c->frame_csr_idx, c->d_xyzr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_xyzr, c->d_xyzr, (size_t)k * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -682,16 +688,16 @@ int pcop_cluster_summaries(pcop_ctx* c, float* xyzr, int32_t cap_clusters) {
 
 int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* bytes) {
     if (!c || !name || !dev_ptr || !bytes) return PCOP_ERR_ARG;
-    const size_t n = c->cap;
+    const size_t n = c->cap, h = c->hash_cap;
     struct Ent { const char* nm; void* p; size_t b; };
     const Ent tab[] = {
         {"state", c->d_state, sizeof(DevState)},
         {"cen_x", c->cen_x, n * 4}, {"cen_y", c->cen_y, n * 4}, {"cen_z", c->cen_z, n * 4},
         {"rec_a", c->rec_a, n * 16}, {"rec_b", c->rec_b, n * 16},
-        {"cell_key", c->cell_key, n * 4}, {"cell_start", c->cell_start, (n + 1) * 4}, {"cell_minidx", c->cell_minidx, n * 4},
-        {"parent", c->parent, n * 4}, {"cell_root", c->cell_root, n * 4}, {"comp_size", c->comp_size, n * 4},
-        {"comp_min", c->comp_min, n * 4}, {"kept_val", c->kept_val, n * 4}, {"rank_at", c->rank_at, n * 4},
-        {"label", c->label, n * 4}, {"rec_cell", c->rec_cell, n * 4}, {"idx_a", c->idx_a, n * 4}, {"idx_b", c->idx_b, n * 4},
+        {"hkey", c->hkey, h * 8}, {"hcount", c->hcount, h * 4}, {"hmin", c->hmin, h * 4},
+        {"cell_start", c->cell_start, h * 4}, {"parent", c->parent, h * 4}, {"comp_size", c->comp_size, h * 4},
+        {"comp_rank", c->comp_rank, h * 4}, {"pt_slot", c->pt_slot, n * 4}, {"pt_rank", c->pt_rank, n * 4},
+        {"pt_root", c->pt_root, n * 4}, {"idx_a", c->idx_a, n * 4}, {"idx_b", c->idx_b, n * 4},
         {"d_offsets", c->d_offsets, (n + 1) * 4}, {"bin_total", c->bin_total, (size_t)kMaxBins * 4},
     };
     for (const Ent& e : tab) {

@@ -1,18 +1,27 @@
 // pcop_device.hpp — gfx950 device code of the obstacle hot path.
 //
-// Three groups of kernels, all HBM/LDS index-and-scatter work (no MFMA):
-//   1. voxel grid     : min/max -> stable LSD radix partition of {x,y,z,idx} records by
-//                       PCL's linear voxel key -> run heads -> in-order centroid sums
-//                       (replaces pcl::VoxelGrid::applyFilter called at od.cpp:282-285)
-//   2. cell grid      : the same partition by a coarse cell key (cell edge = tol/1.99)
-//                       (replaces the FLANN kd-tree built at od.cpp:791-792)
-//   3. clusters       : wave-per-cell neighbour test + lock-free union-find, component
-//                       sizes / discovery order, stable partition of point indices by
-//                       cluster rank (replaces EuclideanClusterExtraction::extract, od.cpp:446-454)
+// All HBM/LDS index-and-scatter work (no MFMA).  One frame is a fixed sequence of launches:
+//
+//   voxel grid (replaces pcl::VoxelGrid::applyFilter, called at od.cpp:282-285)
+//     k_frame_init            mailbox -> DevState
+//     k_minmax_voxel_setup    pcl::getMinMax3D; the last block derives min_b/div_b/divb_mul,
+//                             the overflow rule and the radix plan
+//     k_radix_hist / k_table_scan / k_radix_scatter   (x passes) stable LSD radix partition of
+//                             {x,y,z,idx} records by PCL's linear voxel index
+//     k_heads_count, k_voxel_reduce   run heads -> rank; in-order float32 sums -> centroids
+//   cell grid (replaces the FLANN kd-tree built at od.cpp:791-792)
+//     k_cell_insert           points -> hash table of cells (edge tol/1.99), rank inside the cell
+//     k_slot_count, k_slot_apply, k_cell_place   counting sort of the points by cell
+//   clusters (replaces EuclideanClusterExtraction::extract, od.cpp:446-454)
+//     k_cell_hook, k_cell_compress, k_cell_union   connected components of the cell graph
+//     k_cell_flatten          root per point, component sizes
+//     k_kept_count, k_kept_apply   size filter, discovery order, CSR offsets
+//     k_csr_hist / k_table_scan / k_csr_scatter   stable partition of point indices by cluster
+//     k_emit                  results -> pinned host memory; hash table reset for the next frame
 //
 // Every count that depends on the data (valid points, voxels M, cells, clusters) lives in
-// DevState in device memory; kernels read it there, so a frame is one uninterrupted stream
-// of launches with no host round trip.
+// DevState in device memory and every per-frame input comes through a pinned mailbox, so the
+// kernel arguments of a frame are constant and the whole frame replays as one hipGraph.
 //
 // Built with -ffp-contract=off and correctly rounded f32 divide: the float arithmetic below
 // must match PCL/FLANN's x86-64 mul-then-add sequences bit for bit.
@@ -31,18 +40,20 @@ constexpr int kMaxBins = (1 << kMaxBits) + 1;    // + 1 trash bin (non-finite po
 constexpr int kItems = 8;                        // records per thread in the partition kernels
 constexpr int kTile = kBlock * kItems;           // records per partition block
 constexpr int kMaxPasses = 3;                    // 3 x 11 bits >= 32-bit keys
-constexpr int kSegs = 32;                        // row segments of the tile-count table scan
 constexpr int kScanItems = 4;                    // elements per thread in flag-scan kernels
 constexpr int kScanTile = kBlock * kScanItems;
-constexpr int kReduceBlocks = 1024;              // grid of the min/max kernel
+constexpr int kReduceBlocks = 512;               // grid of the min/max kernel
+constexpr int kCellBias = 1 << 20;               // cell coordinates are stored biased, 21 bits per axis
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
 enum ErrBits : uint32_t {
     kErrNonFinite = 1u,    // NaN/Inf where the reference is undefined
     kErrReplanVoxel = 2u,  // voxel key needs more radix passes than were launched
-    kErrReplanCell = 4u,   // cell key needs more radix passes than were launched
     kErrReplanCsr = 8u,    // cluster-rank key needs more radix passes than were launched
-    kErrRange = 16u,       // coarse cell grid >= 2^32 cells
+    kErrRange = 16u,       // a cell coordinate leaves +-2^20 cells (|p| / tol too large)
 };
+
+enum FrameKind : uint32_t { kFrameChain = 0, kFrameVoxelOnly = 1, kFrameClusterOnly = 2 };
 
 struct RadixPlan {
     uint32_t key_bits;
@@ -51,7 +62,17 @@ struct RadixPlan {
     uint32_t shift[kMaxPasses];
 };
 
-// Device-resident frame state.  Copied to pinned host memory at the end of a frame.
+// Per-frame inputs, written by the host into pinned memory before the graph is launched.
+struct FrameArgs {
+    uint32_t n, is_dense, kind, trivial;      // trivial: r2 == 0, clustering skipped (singletons)
+    float inv_leaf, r2;
+    double inv_cell;                          // 1.99 / |tol|
+    uint32_t min_cluster, max_cluster;
+    uint32_t emit_cloud, out_layout, out_soa_stride, pad;
+    const float* src_x; const float* src_y; const float* src_z;
+};
+
+// Device-resident frame state; k_emit copies it to pinned host memory at the end of a frame.
 struct DevState {
     uint32_t err;
     uint32_t n_in;          // points handed in
@@ -59,27 +80,27 @@ struct DevState {
     uint32_t n_valid;       // finite points (== n_in for dense clouds)
     uint32_t passthrough;   // VoxelGrid overflow rule fired
     uint32_t m;             // voxels (downsampled points)
+    uint32_t kind, trivial, emit_cloud, out_layout, out_soa_stride;
+    uint32_t ticket;        // arrival counter of k_minmax_voxel_setup
     // voxel grid (pcl::VoxelGrid members)
     float    inv_leaf;
     float    vmin[3], vmax[3];
     int32_t  min_b[3], div_b[3];
     uint32_t mul[3];
     RadixPlan plan_voxel;
+    const float* src_x; const float* src_y; const float* src_z;
     // cluster stage
+    double   inv_cell;
     uint32_t c_n;           // points entering clustering
     uint32_t c_from_input;  // 1: cluster the input cloud (passthrough / stage API), 0: the centroids
     float    r2;            // (float)((double)tol*(double)tol)
     uint32_t min_cluster, max_cluster;
-    double   inv_cell;      // 1.99 / tol
-    int64_t  cmin[3];
-    uint32_t cdim[3];
-    RadixPlan plan_cell;
+    uint32_t hash_mask;     // cell hash table has hash_mask+1 slots (power of two >= 2*c_n, >= 1024)
     uint32_t n_cells;
-    uint32_t hash_mask;     // cell hash table has hash_mask+1 slots (power of two >= 2*n_cells)
     uint32_t n_kept;        // clusters with min <= size <= max
     uint32_t n_kept_pts;    // sum of their sizes
     RadixPlan plan_csr;
-    uint32_t pad[3];
+    uint32_t pad[2];
 };
 
 // ------------------------------------------------------------------------------------------
@@ -109,6 +130,24 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     }
     return v;
 }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d, kWave));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d, kWave);
+        v = o < v ? o : v;
+    }
+    return v;
+}
 
 // Exclusive scan of one value per thread across a 256-thread block; *total = block sum.
 // s_w: kWavesPerBlock + 1 words of LDS.  Contains two barriers.
@@ -129,22 +168,59 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
     return base + incl - v;
 }
 
-// ------------------------------------------------------------------------------------------
-// record sources and key functors
-// ------------------------------------------------------------------------------------------
-// A source that is one of two SoA clouds, chosen on the device (passthrough decides whether
-// clustering reads the centroids or the input cloud).
-struct SoaPair {
-    const float* ax; const float* ay; const float* az;   // used when !sel
-    const float* bx; const float* by; const float* bz;   // used when sel
-};
+// Sum over the whole block, returned to every thread (two barriers).
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_w) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) s_w[threadIdx.x / kWave] = v;
+    __syncthreads();
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < kWavesPerBlock; ++i) t += s_w[i];
+    return t;
+}
 
-struct SoaSrc {   // pass 0: planes + implicit idx
+// Sum of per-tile values of all tiles before tile b: each block re-derives its own prefix
+// (b <= a few thousand L2-resident words) instead of paying a kernel boundary for a scan.
+__device__ __forceinline__ uint32_t tiles_before(const uint32_t* __restrict__ tile_vals, uint32_t b, uint32_t* s_w) {
+    uint32_t s = 0;
+    for (uint32_t t = threadIdx.x; t < b; t += kBlock) s += tile_vals[t];
+    return block_sum(s, s_w);
+}
+
+__device__ __forceinline__ uint32_t bits_for(uint64_t count) {   // bits to index `count` values (>= 1)
+    uint32_t b = 1;
+    while (b < 64 && (1ull << b) < count) ++b;
+    return b;
+}
+
+// Spread key_bits over the `npass` radix passes the host launched.  Returns false when a
+// digit would be wider than kMaxBits (the host then re-runs the frame with more passes).
+__device__ __forceinline__ bool make_plan(RadixPlan* pl, uint32_t key_bits, uint32_t npass) {
+    pl->key_bits = key_bits;
+    pl->npass = npass;
+    const uint32_t each = (key_bits + npass - 1) / npass;
+    uint32_t sh = 0;
+    for (uint32_t i = 0; i < (uint32_t)kMaxPasses; ++i) {
+        uint32_t b = 0;
+        if (i < npass && sh < key_bits) b = (key_bits - sh < each) ? key_bits - sh : each;
+        pl->bits[i] = b; pl->shift[i] = sh;
+        sh += b;
+    }
+    return each <= (uint32_t)kMaxBits;
+}
+
+// ------------------------------------------------------------------------------------------
+// record sources and the voxel key
+// ------------------------------------------------------------------------------------------
+struct SoaSrc {   // pass 0: the frame's input planes + implicit idx
     const float* x; const float* y; const float* z;
+    __device__ __forceinline__ void init(const DevState* st) { x = st->src_x; y = st->src_y; z = st->src_z; }
     __device__ __forceinline__ float4 load(uint32_t i) const { return make_float4(x[i], y[i], z[i], u2f(i)); }
 };
 struct RecSrc {   // later passes: 16-byte records
     const float4* r;
+    __device__ __forceinline__ void init(const DevState*) {}
     __device__ __forceinline__ float4 load(uint32_t i) const { return r[i]; }
 };
 
@@ -165,35 +241,25 @@ struct VoxelKey {
     }
 };
 
-// Coarse cell of edge g = 1/inv_cell.  (double)p * inv_cell is exact enough that the two
-// geometric guarantees hold with a 0.5 % margin: same cell => d2 < r2, and d2 < r2 => cell
-// offsets <= 2 per axis ("cell grid").
-struct CellKey {
-    double ig;
-    long long c0, c1, c2;
-    uint32_t dx, dy;
-    __device__ __forceinline__ void init(const DevState* st) {
-        ig = st->inv_cell; c0 = st->cmin[0]; c1 = st->cmin[1]; c2 = st->cmin[2];
-        dx = st->cdim[0]; dy = st->cdim[1];
-    }
-    __device__ __forceinline__ uint32_t operator()(const float4& p) const {
-        const uint32_t rx = (uint32_t)((long long)floor((double)p.x * ig) - c0);
-        const uint32_t ry = (uint32_t)((long long)floor((double)p.y * ig) - c1);
-        const uint32_t rz = (uint32_t)((long long)floor((double)p.z * ig) - c2);
-        return rx + dx * (ry + dy * rz);
-    }
-};
-
 // ------------------------------------------------------------------------------------------
 // frame init + layout conversion
 // ------------------------------------------------------------------------------------------
-__global__ void k_frame_init(DevState* st, uint32_t n, uint32_t is_dense, float inv_leaf, float r2,
-                             double inv_cell, uint32_t min_cluster, uint32_t max_cluster) {
+__global__ void k_frame_init(DevState* st, const FrameArgs* args) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const FrameArgs a = *args;
         DevState s;
         memset(&s, 0, sizeof(s));
-        s.n_in = n; s.is_dense = is_dense; s.inv_leaf = inv_leaf; s.r2 = r2; s.inv_cell = inv_cell;
-        s.min_cluster = min_cluster; s.max_cluster = max_cluster;
+        s.n_in = a.n; s.is_dense = a.is_dense; s.kind = a.kind; s.trivial = a.trivial;
+        s.emit_cloud = a.emit_cloud; s.out_layout = a.out_layout; s.out_soa_stride = a.out_soa_stride;
+        s.inv_leaf = a.inv_leaf; s.r2 = a.r2; s.inv_cell = a.inv_cell;
+        s.min_cluster = a.min_cluster; s.max_cluster = a.max_cluster;
+        s.src_x = a.src_x; s.src_y = a.src_y; s.src_z = a.src_z;
+        if (a.kind == kFrameClusterOnly) {   // no voxel stage: cluster the input cloud as it is
+            s.c_from_input = 1; s.c_n = a.n; s.n_valid = a.n;
+            uint32_t cap = 1024;
+            while (cap < 2u * a.n && cap < 0x80000000u) cap <<= 1;
+            s.hash_mask = cap - 1u;
+        }
         *st = s;
     }
 }
@@ -219,41 +285,72 @@ __global__ __launch_bounds__(kBlock) void k_unpack_points(const uint8_t* __restr
     }
 }
 
-// SoA planes -> packed output in the caller's layout (count read on the device).
-__global__ __launch_bounds__(kBlock) void k_pack_points(const float* __restrict__ x, const float* __restrict__ y,
-                                                        const float* __restrict__ z, const uint32_t* count,
-                                                        int layout, uint32_t soa_stride, float* __restrict__ out) {
-    const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (layout == 0) {
-            reinterpret_cast<float4*>(out)[i] = make_float4(x[i], y[i], z[i], 1.0f);
-        } else if (layout == 1) {
-            out[i] = x[i]; out[soa_stride + i] = y[i]; out[2 * (size_t)soa_stride + i] = z[i];
-        } else {
-            out[3 * (size_t)i] = x[i]; out[3 * (size_t)i + 1] = y[i]; out[3 * (size_t)i + 2] = z[i];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// min / max (pcl::getMinMax3D) — block partials, finished by the set-up kernels
+// min / max (pcl::getMinMax3D) + grid set-up by the last block to arrive
 // ------------------------------------------------------------------------------------------
 struct MinMaxPartial {
     float mn[3], mx[3];
     uint32_t valid, nonfinite;
 };
 
-// mode 0: voxel stage (source = input planes, count = n_in, honours is_dense)
-// mode 1: cluster stage (source selected by st->c_from_input, count = st->c_n)
-__global__ __launch_bounds__(kBlock) void k_minmax(SoaPair src, const DevState* st, int mode,
-                                                   MinMaxPartial* __restrict__ partials) {
-    __shared__ MinMaxPartial s_p[kWavesPerBlock];
-    if (st->err) return;
-    const bool sel = mode == 0 ? true : (st->c_from_input != 0);
-    const float* x = sel ? src.bx : src.ax;
-    const float* y = sel ? src.by : src.ay;
-    const float* z = sel ? src.bz : src.az;
-    const uint32_t n = mode == 0 ? st->n_in : st->c_n;
+// VoxelGrid::applyFilter up to "divb_mul_ = ..." (SURVEY.md §8a-1 steps 1-4).
+__device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p, uint32_t npass) {
+    if (st->is_dense && p.nonfinite) { atomicOr(&st->err, (uint32_t)kErrNonFinite); return; }
+    st->n_valid = p.valid;
+    for (int a = 0; a < 3; ++a) { st->vmin[a] = p.mn[a]; st->vmax[a] = p.mx[a]; }
+    for (int a = 0; a < 3; ++a) { st->min_b[a] = 0; st->div_b[a] = 1; st->mul[a] = 1; }
+    make_plan(&st->plan_voxel, 1, npass);
+    if (p.valid == 0) return;   // empty cloud -> empty output
+    const float inv = st->inv_leaf;
+    // dx = (int64)((max - min) * inv) + 1; overflow rule: dx*dy*dz > INT32_MAX -> output = input
+    long long d[3];
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+        const float e = (p.mx[a] - p.mn[a]) * inv;
+        if (!(e < 2147483648.0f) || e < 0.0f) { ok = false; d[a] = 1; } else d[a] = (long long)e + 1;
+    }
+    if (ok) {
+        const long long lim = 2147483647ll;
+        const long long dxy = d[0] * d[1];
+        if (dxy > lim || dxy * d[2] > lim) ok = false;
+    }
+    if (!ok) { st->passthrough = 1; return; }
+    int32_t div[3];
+    for (int a = 0; a < 3; ++a) {
+        const int32_t lo = (int32_t)floorf(p.mn[a] * inv);
+        const int32_t hi = (int32_t)floorf(p.mx[a] * inv);
+        st->min_b[a] = lo;
+        div[a] = hi - lo + 1;
+        st->div_b[a] = div[a];
+    }
+    st->mul[0] = 1u; st->mul[1] = (uint32_t)div[0]; st->mul[2] = (uint32_t)div[0] * (uint32_t)div[1];
+    const uint64_t cells = (uint64_t)(uint32_t)div[0] * (uint32_t)div[1] * (uint32_t)div[2];
+    const uint32_t kb = cells > 0xFFFFFFFFull ? 32u : bits_for(cells);
+    if (!make_plan(&st->plan_voxel, kb, npass)) atomicOr(&st->err, (uint32_t)kErrReplanVoxel);
+}
+
+__device__ __forceinline__ void reduce_partials_lds(MinMaxPartial* s_p) {   // kBlock entries -> s_p[0]
+    __syncthreads();
+    for (int d = kBlock / 2; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            MinMaxPartial a = s_p[threadIdx.x];
+            const MinMaxPartial b = s_p[threadIdx.x + d];
+            for (int k = 0; k < 3; ++k) { a.mn[k] = fminf(a.mn[k], b.mn[k]); a.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
+            a.valid += b.valid; a.nonfinite += b.nonfinite;
+            s_p[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(DevState* st, MinMaxPartial* partials, uint32_t npass) {
+    __shared__ MinMaxPartial s_p[kBlock];
+    __shared__ uint32_t s_last;
+    if (st->kind == kFrameClusterOnly) return;
+    const float* __restrict__ x = st->src_x;
+    const float* __restrict__ y = st->src_y;
+    const float* __restrict__ z = st->src_z;
+    const uint32_t n = st->n_in;
     const float fmax = 3.402823466e+38f;
     float mn0 = fmax, mn1 = fmax, mn2 = fmax, mx0 = -fmax, mx1 = -fmax, mx2 = -fmax;
     uint32_t valid = 0, bad = 0;
@@ -268,205 +365,73 @@ __global__ __launch_bounds__(kBlock) void k_minmax(SoaPair src, const DevState* 
             ++bad;
         }
     }
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        mn0 = fminf(mn0, __shfl_xor(mn0, d, kWave)); mx0 = fmaxf(mx0, __shfl_xor(mx0, d, kWave));
-        mn1 = fminf(mn1, __shfl_xor(mn1, d, kWave)); mx1 = fmaxf(mx1, __shfl_xor(mx1, d, kWave));
-        mn2 = fminf(mn2, __shfl_xor(mn2, d, kWave)); mx2 = fmaxf(mx2, __shfl_xor(mx2, d, kWave));
-        valid += __shfl_xor(valid, d, kWave); bad += __shfl_xor(bad, d, kWave);
-    }
-    const uint32_t w = threadIdx.x / kWave;
-    if (lane_id() == 0) {
-        MinMaxPartial p;
-        p.mn[0] = mn0; p.mn[1] = mn1; p.mn[2] = mn2; p.mx[0] = mx0; p.mx[1] = mx1; p.mx[2] = mx2;
-        p.valid = valid; p.nonfinite = bad;
-        s_p[w] = p;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        MinMaxPartial p = s_p[0];
-        for (int i = 1; i < kWavesPerBlock; ++i) {
-            for (int a = 0; a < 3; ++a) { p.mn[a] = fminf(p.mn[a], s_p[i].mn[a]); p.mx[a] = fmaxf(p.mx[a], s_p[i].mx[a]); }
-            p.valid += s_p[i].valid; p.nonfinite += s_p[i].nonfinite;
-        }
-        partials[blockIdx.x] = p;
-    }
-}
-
-__device__ __forceinline__ MinMaxPartial reduce_partials(const MinMaxPartial* partials, uint32_t nblocks,
-                                                         MinMaxPartial* s_p) {
-    // one block of kBlock threads
-    const float fmax = 3.402823466e+38f;
     MinMaxPartial p;
-    for (int a = 0; a < 3; ++a) { p.mn[a] = fmax; p.mx[a] = -fmax; }
-    p.valid = 0; p.nonfinite = 0;
-    for (uint32_t i = threadIdx.x; i < nblocks; i += blockDim.x) {
-        const MinMaxPartial q = partials[i];
-        for (int a = 0; a < 3; ++a) { p.mn[a] = fminf(p.mn[a], q.mn[a]); p.mx[a] = fmaxf(p.mx[a], q.mx[a]); }
-        p.valid += q.valid; p.nonfinite += q.nonfinite;
-    }
+    p.mn[0] = mn0; p.mn[1] = mn1; p.mn[2] = mn2; p.mx[0] = mx0; p.mx[1] = mx1; p.mx[2] = mx2;
+    p.valid = valid; p.nonfinite = bad;
     s_p[threadIdx.x] = p;
+    reduce_partials_lds(s_p);
+    // publish the block's partial, then take a ticket; the block that draws the last one finishes
+    if (threadIdx.x == 0) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(partials + blockIdx.x);
+        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(&s_p[0]);
+        for (int k = 0; k < 8; ++k) st_agent(dst + k, srcw[k]);
+        __threadfence();
+        const uint32_t t = atomicAdd(&st->ticket, 1u);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) __threadfence();
+    }
     __syncthreads();
-    for (int d = kBlock / 2; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) {
-            MinMaxPartial a = s_p[threadIdx.x];
-            const MinMaxPartial b = s_p[threadIdx.x + d];
-            for (int k = 0; k < 3; ++k) { a.mn[k] = fminf(a.mn[k], b.mn[k]); a.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
-            a.valid += b.valid; a.nonfinite += b.nonfinite;
-            s_p[threadIdx.x] = a;
-        }
-        __syncthreads();
+    if (!s_last) return;
+    MinMaxPartial q;
+    for (int a = 0; a < 3; ++a) { q.mn[a] = fmax; q.mx[a] = -fmax; }
+    q.valid = 0; q.nonfinite = 0;
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += kBlock) {
+        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(partials + i);
+        uint32_t wds[8];
+        for (int k = 0; k < 8; ++k) wds[k] = ld_agent(srcw + k);
+        for (int a = 0; a < 3; ++a) { q.mn[a] = fminf(q.mn[a], u2f(wds[a])); q.mx[a] = fmaxf(q.mx[a], u2f(wds[3 + a])); }
+        q.valid += wds[6]; q.nonfinite += wds[7];
     }
-    return s_p[0];
-}
-
-__device__ __forceinline__ uint32_t bits_for(uint64_t count) {   // bits to index `count` values (>= 1)
-    uint32_t b = 1;
-    while (b < 64 && (1ull << b) < count) ++b;
-    return b;
-}
-
-// Spread key_bits over the `npass` radix passes the host launched.  Returns false when a
-// digit would be wider than kMaxBits (the host then re-runs the frame with more passes).
-__device__ __forceinline__ bool make_plan(RadixPlan* pl, uint32_t key_bits, uint32_t npass) {
-    pl->key_bits = key_bits;
-    pl->npass = npass;
-    const uint32_t each = (key_bits + npass - 1) / npass;
-    uint32_t sh = 0;
-    for (uint32_t i = 0; i < (uint32_t)kMaxPasses; ++i) {
-        uint32_t b = 0;
-        if (i < npass && sh < key_bits) b = (key_bits - sh < each) ? key_bits - sh : each;
-        pl->bits[i] = b; pl->shift[i] = sh;
-        sh += b;
-    }
-    return each <= (uint32_t)kMaxBits;
-}
-
-// VoxelGrid::applyFilter up to "divb_mul_ = ..." (SURVEY.md §8a-1 steps 1-4), one block.
-__global__ __launch_bounds__(kBlock) void k_voxel_setup(DevState* st, const MinMaxPartial* partials,
-                                                        uint32_t nblocks, uint32_t npass) {
-    __shared__ MinMaxPartial s_p[kBlock];
-    if (st->err) return;
-    const MinMaxPartial p = reduce_partials(partials, nblocks, s_p);
-    if (threadIdx.x != 0) return;
-    if (st->is_dense && p.nonfinite) { st->err = kErrNonFinite; return; }
-    st->n_valid = p.valid;
-    for (int a = 0; a < 3; ++a) { st->vmin[a] = p.mn[a]; st->vmax[a] = p.mx[a]; }
-    if (p.valid == 0) {   // empty cloud -> empty output
-        for (int a = 0; a < 3; ++a) { st->min_b[a] = 0; st->div_b[a] = 1; st->mul[a] = 1; }
-        make_plan(&st->plan_voxel, 1, npass);
-        return;
-    }
-    const float inv = st->inv_leaf;
-    // dx = (int64)((max - min) * inv) + 1; overflow rule: dx*dy*dz > INT32_MAX -> output = input
-    long long d[3];
-    bool ok = true;
-    for (int a = 0; a < 3; ++a) {
-        const float e = (p.mx[a] - p.mn[a]) * inv;
-        if (!(e < 2147483648.0f) || e < 0.0f) { ok = false; d[a] = 1; } else d[a] = (long long)e + 1;
-    }
-    if (ok) {
-        const long long lim = 2147483647ll;
-        const long long dxy = d[0] * d[1];
-        if (dxy > lim || dxy * d[2] > lim) ok = false;
-    }
-    if (!ok) {
-        st->passthrough = 1;
-        for (int a = 0; a < 3; ++a) { st->min_b[a] = 0; st->div_b[a] = 1; st->mul[a] = 1; }
-        make_plan(&st->plan_voxel, 1, npass);
-        return;
-    }
-    int32_t div[3];
-    for (int a = 0; a < 3; ++a) {
-        const int32_t lo = (int32_t)floorf(p.mn[a] * inv);
-        const int32_t hi = (int32_t)floorf(p.mx[a] * inv);
-        st->min_b[a] = lo;
-        div[a] = hi - lo + 1;
-        st->div_b[a] = div[a];
-    }
-    st->mul[0] = 1u; st->mul[1] = (uint32_t)div[0]; st->mul[2] = (uint32_t)div[0] * (uint32_t)div[1];
-    const uint64_t cells = (uint64_t)(uint32_t)div[0] * (uint32_t)div[1] * (uint32_t)div[2];
-    const uint32_t kb = cells > 0xFFFFFFFFull ? 32u : bits_for(cells);
-    if (!make_plan(&st->plan_voxel, kb, npass)) st->err = kErrReplanVoxel;
-}
-
-// Cell grid for the neighbour search (stands in for KdTreeFLANN::setInputCloud).
-__global__ __launch_bounds__(kBlock) void k_cell_setup(DevState* st, const MinMaxPartial* partials,
-                                                       uint32_t nblocks, uint32_t npass) {
-    __shared__ MinMaxPartial s_p[kBlock];
-    if (st->err) return;
-    const MinMaxPartial p = reduce_partials(partials, nblocks, s_p);
-    if (threadIdx.x != 0) return;
-    if (p.nonfinite) { st->err = kErrNonFinite; return; }   // radiusSearch on NaN is undefined in PCL
-    if (st->c_n == 0) {
-        for (int a = 0; a < 3; ++a) { st->cmin[a] = 0; st->cdim[a] = 1; }
-        make_plan(&st->plan_cell, 1, npass);
-        return;
-    }
-    const double ig = st->inv_cell;
-    uint64_t cells = 1;
-    bool ok = true;
-    for (int a = 0; a < 3; ++a) {
-        const double lo = floor((double)p.mn[a] * ig), hi = floor((double)p.mx[a] * ig);
-        const double ext = hi - lo + 1.0;
-        if (!(ext < 4294967296.0) || !(fabs(lo) < 9.0e18) || !(fabs(hi) < 9.0e18)) { ok = false; break; }
-        st->cmin[a] = (long long)lo;
-        st->cdim[a] = (uint32_t)ext;
-        if (cells > 0xFFFFFFFFull / (uint64_t)ext) { ok = false; break; }
-        cells *= (uint64_t)ext;
-    }
-    if (!ok) { st->err = kErrRange; return; }
-    if (!make_plan(&st->plan_cell, bits_for(cells), npass)) st->err = kErrReplanCell;
-}
-
-// After the voxel stage: decide what the cluster stage reads.
-__global__ void k_cluster_source(DevState* st, int force_input) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (st->err) return;
-        if (force_input) { st->c_from_input = 1; st->c_n = st->n_in; }
-        else if (st->passthrough) { st->c_from_input = 1; st->c_n = st->n_in; }
-        else { st->c_from_input = 0; st->c_n = st->m; }
-    }
+    __syncthreads();
+    s_p[threadIdx.x] = q;
+    reduce_partials_lds(s_p);
+    if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass);
 }
 
 // ------------------------------------------------------------------------------------------
-// stable LSD radix partition of records by a digit of their key
+// stable LSD radix partition of records by a digit of their voxel key
 //   k_radix_hist    : per-tile digit counts            -> table[tile][bin]
 //   k_table_scan    : exclusive scan down each column  -> table_x[tile][bin], bin_total[bin]
 //   k_radix_scatter : stable ranks (wave match-any) + scatter
-// which selects the key/count: 0 = voxel keys over n_in/n_valid, 1 = cell keys over c_n.
 // ------------------------------------------------------------------------------------------
 struct PassInfo {
     uint32_t count, bits, shift, nb;   // nb = (1<<bits) + 1 bins (last = trash)
     bool drop_nonfinite;
 };
 
-__device__ __forceinline__ PassInfo pass_info(const DevState* st, int which, int pass) {
+__device__ __forceinline__ bool voxel_stage_off(const DevState* st) {
+    return st->err || st->passthrough || st->kind == kFrameClusterOnly;
+}
+
+__device__ __forceinline__ PassInfo pass_info(const DevState* st, int pass) {
     PassInfo pi;
-    const RadixPlan& pl = which == 0 ? st->plan_voxel : st->plan_cell;
-    pi.bits = pl.bits[pass]; pi.shift = pl.shift[pass];
+    pi.bits = st->plan_voxel.bits[pass]; pi.shift = st->plan_voxel.shift[pass];
     pi.nb = (1u << pi.bits) + 1u;
-    if (which == 0) {
-        pi.count = pass == 0 ? st->n_in : st->n_valid;
-        pi.drop_nonfinite = pass == 0 && st->is_dense == 0;
-    } else {
-        pi.count = st->c_n;
-        pi.drop_nonfinite = false;
-    }
+    pi.count = pass == 0 ? st->n_in : st->n_valid;
+    pi.drop_nonfinite = pass == 0 && st->is_dense == 0;
     return pi;
 }
 
-template <class Src, class KeyFn>
-__global__ __launch_bounds__(kBlock) void k_radix_hist(Src src_a, Src src_b, const DevState* st, int which, int pass,
+template <class Src>
+__global__ __launch_bounds__(kBlock) void k_radix_hist(Src src, const DevState* st, int pass,
                                                        uint32_t* __restrict__ table) {
     __shared__ uint32_t s_h[kMaxBins];
-    if (st->err || (which == 0 && st->passthrough)) return;
-    const PassInfo pi = pass_info(st, which, pass);
+    if (voxel_stage_off(st)) return;
+    const PassInfo pi = pass_info(st, pass);
     const uint32_t tile_base = blockIdx.x * kTile;
     if (tile_base >= pi.count) return;
-    const bool sel_b = which == 1 && st->c_from_input != 0;
-    const Src src = sel_b ? src_b : src_a;
-    KeyFn key; key.init(st);
+    src.init(st);
+    VoxelKey key; key.init(st);
     for (uint32_t b = threadIdx.x; b < pi.nb; b += kBlock) s_h[b] = 0;
     __syncthreads();
     const uint32_t mask = (1u << pi.bits) - 1u;
@@ -487,17 +452,20 @@ __global__ __launch_bounds__(kBlock) void k_radix_hist(Src src_a, Src src_b, con
     for (uint32_t b = threadIdx.x; b < pi.nb; b += kBlock) row[b] = s_h[b];
 }
 
-// which = 2: CSR partition (count = c_n, bits from plan_csr)
+// which = 0: voxel partition pass, 2: CSR partition pass
 __device__ __forceinline__ bool table_dims(const DevState* st, int which, int pass, uint32_t* ntiles, uint32_t* nb) {
+    if (st->err) return false;
     if (which == 2) {
+        if (st->trivial || st->kind == kFrameVoxelOnly) return false;
         *nb = (1u << st->plan_csr.bits[pass]) + 1u;
         *ntiles = (st->c_n + kTile - 1) / kTile;
         return st->n_kept != 0;
     }
-    const PassInfo pi = pass_info(st, which, pass);
+    if (voxel_stage_off(st)) return false;
+    const PassInfo pi = pass_info(st, pass);
     *nb = pi.nb;
     *ntiles = (pi.count + kTile - 1) / kTile;
-    return !(which == 0 && st->passthrough);
+    return true;
 }
 
 // Exclusive scan down each column of the tile-count table: block b owns bin b.
@@ -507,7 +475,6 @@ __global__ __launch_bounds__(kBlock) void k_table_scan(const DevState* st, int w
                                                        uint32_t* __restrict__ table_x,
                                                        uint32_t* __restrict__ bin_total) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    if (st->err) return;
     uint32_t ntiles, nb;
     if (!table_dims(st, which, pass, &ntiles, &nb)) return;
     const uint32_t b = blockIdx.x;
@@ -559,21 +526,20 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint32_t nbits, bool
     return m;
 }
 
-template <class Src, class KeyFn>
-__global__ __launch_bounds__(kBlock) void k_radix_scatter(Src src_a, Src src_b, const DevState* st, int which,
-                                                          int pass, const uint32_t* __restrict__ table_x,
+template <class Src>
+__global__ __launch_bounds__(kBlock) void k_radix_scatter(Src src, const DevState* st, int pass,
+                                                          const uint32_t* __restrict__ table_x,
                                                           const uint32_t* __restrict__ bin_total,
                                                           float4* __restrict__ out) {
     __shared__ uint32_t s_hist[kWavesPerBlock * kMaxBins];
     __shared__ uint32_t s_base[kMaxBins];
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    if (st->err || (which == 0 && st->passthrough)) return;
-    const PassInfo pi = pass_info(st, which, pass);
+    if (voxel_stage_off(st)) return;
+    const PassInfo pi = pass_info(st, pass);
     const uint32_t tile_base = blockIdx.x * kTile;
     if (tile_base >= pi.count) return;
-    const bool sel_b = which == 1 && st->c_from_input != 0;
-    const Src src = sel_b ? src_b : src_a;
-    KeyFn key; key.init(st);
+    src.init(st);
+    VoxelKey key; key.init(st);
     const uint32_t nb = pi.nb;
     for (uint32_t b = threadIdx.x; b < kWavesPerBlock * nb; b += kBlock) s_hist[b] = 0;
     scan_bins_to_lds(bin_total, nb, s_base, s_w);   // ends with a barrier
@@ -624,30 +590,23 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(Src src_a, Src src_b, 
 }
 
 // ------------------------------------------------------------------------------------------
-// run heads over sorted records: count per tile, scan of tile counts, then consumers
+// run heads over the sorted records -> voxel rank; centroids
 // ------------------------------------------------------------------------------------------
-// count of the sorted range: which 0 -> n_valid (voxel), 1 -> c_n (cells)
-__device__ __forceinline__ uint32_t sorted_count(const DevState* st, int which) {
-    return which == 0 ? st->n_valid : st->c_n;
-}
-
-template <class KeyFn>
-__global__ __launch_bounds__(kBlock) void k_heads_count(const float4* __restrict__ rec, const DevState* st, int which,
+__global__ __launch_bounds__(kBlock) void k_heads_count(const float4* __restrict__ rec, const DevState* st,
                                                         uint32_t* __restrict__ tile_heads) {
     __shared__ uint32_t s_w[kWavesPerBlock];
-    if (st->err || (which == 0 && st->passthrough)) return;
-    const uint32_t n = sorted_count(st, which);
+    if (voxel_stage_off(st)) return;
+    const uint32_t n = st->n_valid;
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= n) return;
-    KeyFn key; key.init(st);
+    VoxelKey key; key.init(st);
     uint32_t c = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t i = base + threadIdx.x * kScanItems + k;
         if (i < n) c += (i == 0 || key(rec[i]) != key(rec[i - 1])) ? 1u : 0u;
     }
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) c += __shfl_xor(c, d, kWave);
+    c = wave_sum(c);
     if (lane_id() == 0) s_w[threadIdx.x / kWave] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -657,79 +616,37 @@ __global__ __launch_bounds__(kBlock) void k_heads_count(const float4* __restrict
     }
 }
 
-// One block: exclusive scan of per-tile values (in place); total -> *total_out (device word).
-// ntiles_of: 0 -> ceil(n_valid/kScanTile), 1 -> ceil(c_n/kScanTile)
-__global__ __launch_bounds__(kBlock) void k_scan_tiles(uint32_t* __restrict__ vals, DevState* st, int which,
-                                                       int dst /*0: m, 1: n_cells*/) {
-    __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    if (st->err || (which == 0 && st->passthrough)) return;
-    const uint32_t n = sorted_count(st, which);
-    const uint32_t ntiles = (n + kScanTile - 1) / kScanTile;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < ntiles; base += kBlock) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < ntiles ? vals[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan(v, s_w, &tot);
-        if (i < ntiles) vals[i] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) {
-        if (dst == 0) {
-            st->m = carry;
-        } else {
-            st->n_cells = carry;
-            uint32_t cap = 1024;
-            while (cap < 2u * carry && cap < 0x80000000u) cap <<= 1;
-            st->hash_mask = cap - 1u;
-        }
-    }
-}
-
-// Cell hash table: slot = (key+1) | cell_id << 32, 0 = empty.  Open addressing, linear probing.
-__device__ __forceinline__ uint32_t cell_hash(uint32_t key) {
-    uint32_t h = key * 0x9E3779B1u;
-    h ^= h >> 15;
-    h *= 0x85EBCA77u;
-    h ^= h >> 13;
-    return h;
-}
-
-__global__ __launch_bounds__(kBlock) void k_hash_clear(const DevState* st, unsigned long long* __restrict__ tab) {
-    if (st->err) return;
-    const uint32_t cap = st->hash_mask + 1u;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) tab[i] = 0ull;
-}
-
-__device__ __forceinline__ void hash_insert(unsigned long long* tab, uint32_t mask, uint32_t key, uint32_t id) {
-    const unsigned long long v = (unsigned long long)(key + 1u) | ((unsigned long long)id << 32);
-    uint32_t slot = cell_hash(key) & mask;
-    while (atomicCAS(tab + slot, 0ull, v) != 0ull) slot = (slot + 1u) & mask;
-}
-
-// returns the cell id or 0xFFFFFFFF
-__device__ __forceinline__ uint32_t hash_lookup(const unsigned long long* __restrict__ tab, uint32_t mask, uint32_t key) {
-    uint32_t slot = cell_hash(key) & mask;
-    while (true) {
-        const unsigned long long v = tab[slot];
-        if (v == 0ull) return 0xFFFFFFFFu;
-        if ((uint32_t)v == key + 1u) return (uint32_t)(v >> 32);
-        slot = (slot + 1u) & mask;
-    }
+// End of the voxel stage: M, and what the cluster stage reads.
+__device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
+    st->m = m;
+    st->c_from_input = st->passthrough ? 1u : 0u;
+    st->c_n = m;
+    uint32_t cap = 1024;
+    while (cap < 2u * m && cap < 0x80000000u) cap <<= 1;
+    st->hash_mask = cap - 1u;
 }
 
 // Voxel centroids (voxel_grid.hpp "Fourth pass", PCL >= 1.8 CentroidPoint / AccumulatorXYZ):
 // the thread that owns a run head sums the run in order (= ascending point index, the
 // partition is stable) starting from 0.0f and divides by float(count).
-__global__ __launch_bounds__(kBlock) void k_voxel_reduce(const float4* __restrict__ rec, const DevState* st,
-                                                         const uint32_t* __restrict__ tile_heads_x,
+__global__ __launch_bounds__(kBlock) void k_voxel_reduce(const float4* __restrict__ rec, DevState* st,
+                                                         const uint32_t* __restrict__ tile_heads,
                                                          float* __restrict__ cx, float* __restrict__ cy,
                                                          float* __restrict__ cz) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    if (st->err || st->passthrough) return;
+    if (st->err || st->kind == kFrameClusterOnly) return;
+    if (st->passthrough) {   // "output = *input_": the voxel cloud is the input cloud, every point kept
+        if (blockIdx.x == 0 && threadIdx.x == 0) finish_voxel(st, st->n_in);
+        return;
+    }
     const uint32_t n = st->n_valid;
+    if (n == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) finish_voxel(st, 0);
+        return;
+    }
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= n) return;
+    const uint32_t before = tiles_before(tile_heads, blockIdx.x, s_w);
     VoxelKey key; key.init(st);
     uint32_t kcur[kScanItems];
     bool head[kScanItems];
@@ -748,7 +665,8 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(const float4* __restric
         }
     }
     uint32_t tot;
-    uint32_t rank = tile_heads_x[blockIdx.x] + block_excl_scan(c, s_w, &tot);
+    uint32_t rank = before + block_excl_scan(c, s_w, &tot);
+    if (threadIdx.x == 0 && base + kScanTile >= n) finish_voxel(st, before + tot);   // the last tile
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t i = i0 + k;
@@ -770,71 +688,183 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(const float4* __restric
     }
 }
 
-// Passthrough: "output = *input_" — the voxel cloud is the input cloud, every point kept.
-__global__ __launch_bounds__(kBlock) void k_voxel_passthrough(DevState* st) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (st->err) return;
-        if (st->passthrough) st->m = st->n_in;
+// ------------------------------------------------------------------------------------------
+// cell grid: hash table of occupied cells.  Cell edge g = 1/inv_cell = |tol|/1.99 and the cell
+// of a point is floor((double)p * inv_cell) per axis (the product of two floats widened to
+// double is exact up to 2^-53), which gives two guarantees with margin:
+//   same cell            =>  d2 < r2         (3 g^2 = 0.757 tol^2)
+//   d2 < r2              =>  cell offsets <= 2 per axis   (tol * inv_cell = 1.99 < 2)
+// Coordinates are biased by 2^20 and packed 21 bits per axis into a 64-bit key.
+// slot arrays: hkey (key+1, 0 = empty), hcount (points), hmin (smallest point index = priority)
+// ------------------------------------------------------------------------------------------
+struct CellTable {
+    unsigned long long* hkey;
+    uint32_t* hcount;
+    uint32_t* hmin;
+};
+
+__device__ __forceinline__ uint32_t cell_hash(unsigned long long key) {
+    unsigned long long h = key * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return (uint32_t)h;
+}
+
+__device__ __forceinline__ unsigned long long pack_cell(long long cx, long long cy, long long cz) {
+    return (unsigned long long)(cx + kCellBias) | ((unsigned long long)(cy + kCellBias) << 21) |
+           ((unsigned long long)(cz + kCellBias) << 42);
+}
+
+__device__ __forceinline__ uint32_t hash_find_or_insert(unsigned long long* hkey, uint32_t mask, unsigned long long key) {
+    const unsigned long long want = key + 1ull;
+    uint32_t slot = cell_hash(key) & mask;
+    while (true) {
+        unsigned long long k = hkey[slot];
+        if (k == 0ull) k = atomicCAS(hkey + slot, 0ull, want);
+        if (k == 0ull || k == want) return slot;
+        slot = (slot + 1u) & mask;
     }
 }
 
-// Cells: for every sorted record its cell id; for every cell its key, first record and the
-// smallest point index it holds (= the first record's idx: the partition is stable).
-__global__ __launch_bounds__(kBlock) void k_cells_build(const float4* __restrict__ rec, const DevState* st,
-                                                        const uint32_t* __restrict__ tile_heads_x,
-                                                        uint32_t* __restrict__ rec_cell, uint32_t* __restrict__ cell_key,
-                                                        uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_minidx,
-                                                        uint32_t* __restrict__ parent, uint32_t* __restrict__ comp_size,
-                                                        uint32_t* __restrict__ comp_min, uint32_t* __restrict__ kept_val,
-                                                        unsigned long long* __restrict__ hash_tab) {
-    __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    if (st->err) return;
+__device__ __forceinline__ uint32_t hash_lookup(const unsigned long long* __restrict__ hkey, uint32_t mask,
+                                                unsigned long long key) {
+    const unsigned long long want = key + 1ull;
+    uint32_t slot = cell_hash(key) & mask;
+    while (true) {
+        const unsigned long long k = hkey[slot];
+        if (k == want) return slot;
+        if (k == 0ull) return kNoSlot;
+        slot = (slot + 1u) & mask;
+    }
+}
+
+__device__ __forceinline__ bool cluster_stage_off(const DevState* st) {
+    return st->err || st->trivial || st->kind == kFrameVoxelOnly;
+}
+
+// Every point: its cell's slot and its rank inside the cell.  Runs of consecutive points that
+// fall in one cell (frequent: the points arrive in voxel order) share one set of atomics.
+__global__ __launch_bounds__(kBlock) void k_cell_insert(DevState* st, const float* __restrict__ cen_x,
+                                                        const float* __restrict__ cen_y, const float* __restrict__ cen_z,
+                                                        CellTable tab, uint32_t* __restrict__ pt_slot,
+                                                        uint32_t* __restrict__ pt_rank) {
+    if (cluster_stage_off(st)) return;
+    const bool from_in = st->c_from_input != 0;
+    const float* __restrict__ x = from_in ? st->src_x : cen_x;
+    const float* __restrict__ y = from_in ? st->src_y : cen_y;
+    const float* __restrict__ z = from_in ? st->src_z : cen_z;
     const uint32_t n = st->c_n;
-    const uint32_t hmask = st->hash_mask;
-    const uint32_t base = blockIdx.x * kScanTile;
-    if (base >= n) return;
-    CellKey key; key.init(st);
-    uint32_t kcur[kScanItems];
-    bool head[kScanItems];
-    uint32_t c = 0;
-    const uint32_t i0 = base + threadIdx.x * kScanItems;
-    uint32_t kprev = (i0 > 0 && i0 <= n) ? key(rec[i0 - 1]) : 0u;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const uint32_t i = i0 + k;
-        head[k] = false;
-        if (i < n) {
-            kcur[k] = key(rec[i]);
-            head[k] = (i == 0) || (kcur[k] != kprev);
-            kprev = kcur[k];
-            c += head[k] ? 1u : 0u;
-        }
-    }
-    uint32_t tot;
-    uint32_t rank = tile_heads_x[blockIdx.x] + block_excl_scan(c, s_w, &tot);   // heads before this thread
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const uint32_t i = i0 + k;
-        if (i < n) {
-            if (head[k]) {
-                cell_key[rank] = kcur[k];
-                cell_start[rank] = i;
-                cell_minidx[rank] = f2u(rec[i].w);
-                parent[rank] = rank;
-                comp_size[rank] = 0u;
-                comp_min[rank] = 0xFFFFFFFFu;
-                hash_insert(hash_tab, hmask, kcur[k], rank);
-                ++rank;
+    const uint32_t mask = st->hash_mask;
+    const double ig = st->inv_cell;
+    const uint32_t lane = lane_id();
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += nthreads) {
+        const uint32_t i = base + lane;
+        bool valid = i < n;
+        unsigned long long key = 0;
+        if (valid) {
+            const float px = x[i], py = y[i], pz = z[i];
+            if (!finite3(px, py, pz)) {   // radiusSearch on a non-finite point is undefined in PCL
+                atomicOr(&st->err, (uint32_t)kErrNonFinite);
+                valid = false;
+            } else {
+                const double fx = floor((double)px * ig), fy = floor((double)py * ig), fz = floor((double)pz * ig);
+                const double lim = (double)(kCellBias - 4);
+                if (!(fabs(fx) < lim && fabs(fy) < lim && fabs(fz) < lim)) {
+                    atomicOr(&st->err, (uint32_t)kErrRange);
+                    valid = false;
+                } else {
+                    key = pack_cell((long long)fx, (long long)fy, (long long)fz);
+                }
             }
-            rec_cell[i] = rank - 1;
-            kept_val[i] = 0u;
-            if (i == n - 1) cell_start[st->n_cells] = n;   // sentinel (n_cells set by k_scan_tiles)
         }
+        const unsigned long long kprev = __shfl_up(key, 1, kWave);
+        const uint32_t vprev = __shfl_up((uint32_t)valid, 1, kWave);
+        const bool leader = valid && (lane == 0 || !vprev || key != kprev);
+        const uint64_t leaders = __ballot(leader);
+        const uint64_t breaks = __ballot(leader || !valid);
+        uint32_t slot = 0, rank0 = 0;
+        if (leader) {
+            const uint64_t later = lane == 63 ? 0ull : (breaks >> (lane + 1));
+            const uint32_t runlen = later ? (uint32_t)__ffsll((unsigned long long)later) : (uint32_t)(kWave - lane);
+            slot = hash_find_or_insert(tab.hkey, mask, key);
+            rank0 = atomicAdd(tab.hcount + slot, runlen);
+            atomicMin(tab.hmin + slot, i);
+        }
+        // the run's leader is the highest leader at or below this lane
+        const uint64_t le = leaders & (lanemask_lt() | (1ull << lane));
+        const int ll = le ? 63 - __clzll((unsigned long long)le) : 0;
+        const uint32_t s = __shfl(slot, ll, kWave);
+        const uint32_t r = __shfl(rank0, ll, kWave);
+        if (valid) { pt_slot[i] = s; pt_rank[i] = r + (lane - (uint32_t)ll); }
     }
+}
+
+// points per tile of kScanTile slots
+__global__ __launch_bounds__(kBlock) void k_slot_count(const DevState* st, const uint32_t* __restrict__ hcount,
+                                                       uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t s_w[kWavesPerBlock];
+    if (cluster_stage_off(st)) return;
+    const uint32_t cap = st->hash_mask + 1u;
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= cap) return;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) c += hcount[base + threadIdx.x * kScanItems + k];   // cap is a multiple of 1024
+    const uint32_t t = block_sum(c, s_w);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = t;
+}
+
+// cell_start[slot] = number of points in slots before it; union-find init
+__global__ __launch_bounds__(kBlock) void k_slot_apply(DevState* st, const uint32_t* __restrict__ hcount,
+                                                       const uint32_t* __restrict__ tile_sums,
+                                                       uint32_t* __restrict__ cell_start, uint32_t* __restrict__ parent,
+                                                       uint32_t* __restrict__ comp_size, uint32_t* __restrict__ comp_rank) {
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    if (cluster_stage_off(st)) return;
+    const uint32_t cap = st->hash_mask + 1u;
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= cap) return;
+    const uint32_t before = tiles_before(tile_sums, blockIdx.x, s_w);
+    uint32_t v[kScanItems];
+    uint32_t c = 0, occ = 0;
+    const uint32_t s0 = base + threadIdx.x * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { v[k] = hcount[s0 + k]; c += v[k]; occ += v[k] ? 1u : 0u; }
+    uint32_t tot;
+    uint32_t run = before + block_excl_scan(c, s_w, &tot);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        cell_start[s0 + k] = run;
+        parent[s0 + k] = s0 + k;
+        comp_size[s0 + k] = 0u;
+        comp_rank[s0 + k] = 0xFFFFFFFFu;
+        run += v[k];
+    }
+    occ = block_sum(occ, s_w);
+    if (threadIdx.x == 0 && occ) atomicAdd(&st->n_cells, occ);
+}
+
+// counting sort: record of point i goes to cell_start[slot] + rank
+__global__ __launch_bounds__(kBlock) void k_cell_place(const DevState* st, const float* __restrict__ cen_x,
+                                                       const float* __restrict__ cen_y, const float* __restrict__ cen_z,
+                                                       const uint32_t* __restrict__ pt_slot, const uint32_t* __restrict__ pt_rank,
+                                                       const uint32_t* __restrict__ cell_start, float4* __restrict__ rec) {
+    if (cluster_stage_off(st)) return;
+    const bool from_in = st->c_from_input != 0;
+    const float* __restrict__ x = from_in ? st->src_x : cen_x;
+    const float* __restrict__ y = from_in ? st->src_y : cen_y;
+    const float* __restrict__ z = from_in ? st->src_z : cen_z;
+    const uint32_t n = st->c_n;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        rec[cell_start[pt_slot[i]] + pt_rank[i]] = make_float4(x[i], y[i], z[i], u2f(i));
 }
 
 // ------------------------------------------------------------------------------------------
-// union-find over cells (lock-free, roots are the smallest cell id of their component)
+// union-find over cells (slots).  The root of a set is its cell of smallest priority, and the
+// priority of a cell is the smallest point index it holds, so the root of a finished component
+// carries the component's discovery key (its first point in index order).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
     while (true) {
@@ -847,25 +877,16 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
     }
 }
 
-__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+__device__ __forceinline__ void uf_union(uint32_t* parent, const uint32_t* __restrict__ prio, uint32_t a, uint32_t b) {
     while (true) {
         a = uf_find(parent, a);
         b = uf_find(parent, b);
         if (a == b) return;
-        if (a > b) { const uint32_t t = a; a = b; b = t; }
-        // hang the larger root b under the smaller root a
+        if (prio[a] > prio[b]) { const uint32_t t = a; a = b; b = t; }
+        // hang the root of larger priority value b under a
         const uint32_t old = atomicCAS(parent + b, b, a);
         if (old == b) return;
     }
-}
-
-__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t n, uint32_t v) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a[mid] < v) lo = mid + 1; else hi = mid;
-    }
-    return lo;
 }
 
 // FLANN's L2_Simple: ((dx*dx + dy*dy) + dz*dz) in float32, no contraction.
@@ -881,9 +902,9 @@ __device__ __forceinline__ float l2_simple(const float4& a, const float4& b) {
 // cell graph -> components.  Points of one cell are mutually within the radius (clique), and a
 // neighbour of a point of A lies in a cell at most 2 away per axis, so the components of the
 // point graph {d2 < r2} are the components of the cell graph whose edges are "some cross
-// pair satisfies d2 < r2".  One wave per cell; lane t owns stencil offset t of one half of the
-// 5x5x5 stencil (62 offsets, ascending in cell key), found through the cell hash table.
-//   k_cell_hook    : backward half, no atomics: parent[c] = smallest adjacent cell id (or c)
+// pair satisfies d2 < r2".  One wave per cell; lane t owns offset t of one half of the 5x5x5
+// stencil (62 offsets), looked up through the hash table.
+//   k_cell_hook    : backward half, no atomics: parent[c] = adjacent cell of smallest priority
 //   k_cell_compress: pointer jumping, parent[c] = root
 //   k_cell_union   : forward half: pairs whose roots already agree are skipped without a
 //                    distance test; the rest are tested and united by CAS (few survive the hook)
@@ -891,7 +912,7 @@ __device__ __forceinline__ float l2_simple(const float4& a, const float4& b) {
 constexpr int kCellPtsCap = 64;
 constexpr int kStencil = 62;
 
-// forward offset number t (0..61), ascending in key: (0,0,+1..2) ; (0,+1..2,*) ; (+1..2,*,*)
+// forward offset number t (0..61): (0,0,+1..2) ; (0,+1..2,*) ; (+1..2,*,*)
 __device__ __forceinline__ void stencil_offset(uint32_t t, int* dx, int* dy, int* dz) {
     if (t < 2) { *dz = 0; *dy = 0; *dx = (int)t + 1; return; }
     const uint32_t u = t - 2;
@@ -900,22 +921,16 @@ __device__ __forceinline__ void stencil_offset(uint32_t t, int* dx, int* dy, int
     *dz = 1 + (int)(v / 25); *dy = (int)((v % 25) / 5) - 2; *dx = (int)(v % 5) - 2;
 }
 
-struct CellGrid {
-    uint32_t dimx, dimy, dimz, hmask;
-    const unsigned long long* tab;
-    // cell id at (rx,ry,rz) + lane's offset of the forward (sign=+1) or backward (-1) half-stencil
-    __device__ __forceinline__ uint32_t neighbour(uint32_t rx, uint32_t ry, uint32_t rz, uint32_t lane, int sign) const {
-        if (lane >= (uint32_t)kStencil) return 0xFFFFFFFFu;
-        int dx, dy, dz;
-        // backward candidates in ascending key order = negated forward offsets in reverse order
-        stencil_offset(sign > 0 ? lane : (uint32_t)(kStencil - 1) - lane, &dx, &dy, &dz);
-        const long long nx = (long long)rx + sign * dx, ny = (long long)ry + sign * dy, nz = (long long)rz + sign * dz;
-        if (nx < 0 || ny < 0 || nz < 0 || nx >= (long long)dimx || ny >= (long long)dimy || nz >= (long long)dimz)
-            return 0xFFFFFFFFu;
-        const uint32_t key = (uint32_t)nx + dimx * ((uint32_t)ny + dimy * (uint32_t)nz);
-        return hash_lookup(tab, hmask, key);
-    }
-};
+// slot of the cell at this lane's stencil offset from the cell with packed key `ka`
+__device__ __forceinline__ uint32_t stencil_neighbour(const unsigned long long* __restrict__ hkey, uint32_t mask,
+                                                      unsigned long long ka, uint32_t lane, int sign) {
+    if (lane >= (uint32_t)kStencil) return kNoSlot;
+    int dx, dy, dz;
+    stencil_offset(lane, &dx, &dy, &dz);
+    // biased coordinates stay inside 21 bits: k_cell_insert keeps |c| < 2^20 - 4
+    const long long off = (long long)(sign * dx) + ((long long)(sign * dy) << 21) + ((long long)(sign * dz) << 42);
+    return hash_lookup(hkey, mask, (unsigned long long)((long long)ka + off));
+}
 
 // does some point of B (this lane's cell) lie within the radius of some point of A (in LDS)?
 __device__ __forceinline__ bool lane_pair_hit(const float4* s_pa, uint32_t an, const float4* __restrict__ rec,
@@ -945,93 +960,90 @@ __device__ __forceinline__ bool wave_pair_hit(const float4* __restrict__ rec, ui
     return hit;
 }
 
-__global__ __launch_bounds__(kBlock) void k_cell_hook(const float4* __restrict__ rec, const DevState* st,
-                                                      const uint32_t* __restrict__ cell_key,
+__global__ __launch_bounds__(kBlock) void k_cell_hook(const float4* __restrict__ rec, const DevState* st, CellTable tab,
                                                       const uint32_t* __restrict__ cell_start,
-                                                      const unsigned long long* __restrict__ hash_tab,
                                                       uint32_t* __restrict__ parent) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
-    if (st->err) return;
-    const uint32_t ncell = st->n_cells;
-    CellGrid g{st->cdim[0], st->cdim[1], st->cdim[2], st->hash_mask, hash_tab};
+    if (cluster_stage_off(st)) return;
+    const uint32_t mask = st->hash_mask, cap = mask + 1u;
     const float r2 = st->r2;
     const uint32_t w = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
-    for (uint32_t a = blockIdx.x * kWavesPerBlock + w; a < ncell; a += nwaves) {
-        const uint32_t ka = cell_key[a];
-        const uint32_t rx = ka % g.dimx, ry = (ka / g.dimx) % g.dimy, rz = ka / (g.dimx * g.dimy);
-        const uint32_t b = g.neighbour(rx, ry, rz, lane, -1);
-        const bool found = b != 0xFFFFFFFFu;
-        uint64_t found_mask = __ballot(found);
+    for (uint32_t a = blockIdx.x * kWavesPerBlock + w; a < cap; a += nwaves) {
+        const uint32_t an = tab.hcount[a];
+        if (an == 0) continue;
+        const unsigned long long ka = tab.hkey[a] - 1ull;
+        const uint32_t pa = tab.hmin[a];
+        const uint32_t b = stencil_neighbour(tab.hkey, mask, ka, lane, -1);
+        // only cells of smaller priority can become the parent
+        const bool cand = b != kNoSlot && tab.hmin[b] < pa;
+        uint64_t cand_mask = __ballot(cand);
+        if (cand_mask == 0) continue;   // parent[a] == a from k_slot_apply
+        const uint32_t a0 = cell_start[a];
+        uint32_t b0 = 0, bn = 0, pb = 0xFFFFFFFFu;
+        if (cand) { b0 = cell_start[b]; bn = tab.hcount[b]; pb = tab.hmin[b]; }
+        const uint32_t bn_max = wave_max(bn);
         uint32_t target = a;
-        if (found_mask != 0) {
-            const uint32_t a0 = cell_start[a], an = cell_start[a + 1] - a0;
-            uint32_t b0 = 0, bn = 0;
-            if (found) { b0 = cell_start[b]; bn = cell_start[b + 1] - b0; }
-            uint32_t bn_max = bn;
-#pragma unroll
-            for (int d = kWave / 2; d > 0; d >>= 1) bn_max = max(bn_max, (uint32_t)__shfl_xor(bn_max, d, kWave));
-            if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
-                if (lane < an) s_pa[w][lane] = rec[a0 + lane];
-                __builtin_amdgcn_wave_barrier();
-                const bool hit = found && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2);
-                const uint64_t hits = __ballot(hit);
-                if (hits) target = __shfl(b, __ffsll((unsigned long long)hits) - 1, kWave);   // lanes ascend in key
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                while (found_mask) {   // ascending key: the first hit is the smallest adjacent id
-                    const int t = __ffsll((unsigned long long)found_mask) - 1;
-                    found_mask &= found_mask - 1;
-                    const uint32_t cb = __shfl(b, t, kWave), cb0 = __shfl(b0, t, kWave), cbn = __shfl(bn, t, kWave);
-                    if (wave_pair_hit(rec, a0, an, cb0, cbn, r2)) { target = cb; break; }
-                }
+        if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
+            if (lane < an) s_pa[w][lane] = rec[a0 + lane];
+            __builtin_amdgcn_wave_barrier();
+            const bool hit = cand && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2);
+            const unsigned long long best = wave_min_u64(hit ? (((unsigned long long)pb << 32) | b) : ~0ull);
+            if (best != ~0ull) target = (uint32_t)best;
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            // big cells: candidates in ascending priority, whole wave per pair, stop at the first hit
+            while (cand_mask) {
+                const unsigned long long pick = wave_min_u64(((cand_mask >> lane) & 1ull) ? (((unsigned long long)pb << 32) | lane) : ~0ull);
+                const int t = (int)(uint32_t)pick;
+                cand_mask &= ~(1ull << t);
+                const uint32_t cb = __shfl(b, t, kWave), cb0 = __shfl(b0, t, kWave), cbn = __shfl(bn, t, kWave);
+                if (wave_pair_hit(rec, a0, an, cb0, cbn, r2)) { target = cb; break; }
             }
         }
-        if (lane == 0) parent[a] = target;   // target <= a: a forest, no cycles
+        if (lane == 0 && target != a) parent[a] = target;   // strictly decreasing priority: a forest
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_cell_compress(const DevState* st, uint32_t* __restrict__ parent) {
-    if (st->err) return;
-    const uint32_t ncell = st->n_cells;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(kBlock) void k_cell_compress(const DevState* st, const uint32_t* __restrict__ hcount,
+                                                          uint32_t* __restrict__ parent) {
+    if (cluster_stage_off(st)) return;
+    const uint32_t cap = st->hash_mask + 1u;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cap; c += gridDim.x * blockDim.x) {
+        if (hcount[c] == 0) continue;
         const uint32_t r = uf_find(parent, c);
         st_agent(parent + c, r);
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_cell_union(const float4* __restrict__ rec, const DevState* st,
-                                                       const uint32_t* __restrict__ cell_key,
+__global__ __launch_bounds__(kBlock) void k_cell_union(const float4* __restrict__ rec, const DevState* st, CellTable tab,
                                                        const uint32_t* __restrict__ cell_start,
-                                                       const unsigned long long* __restrict__ hash_tab,
                                                        uint32_t* __restrict__ parent) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
-    if (st->err) return;
-    const uint32_t ncell = st->n_cells;
-    CellGrid g{st->cdim[0], st->cdim[1], st->cdim[2], st->hash_mask, hash_tab};
+    if (cluster_stage_off(st)) return;
+    const uint32_t mask = st->hash_mask, cap = mask + 1u;
     const float r2 = st->r2;
     const uint32_t w = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
-    for (uint32_t a = blockIdx.x * kWavesPerBlock + w; a < ncell; a += nwaves) {
-        const uint32_t ka = cell_key[a];
-        const uint32_t rx = ka % g.dimx, ry = (ka / g.dimx) % g.dimy, rz = ka / (g.dimx * g.dimy);
-        const uint32_t b = g.neighbour(rx, ry, rz, lane, +1);
+    for (uint32_t a = blockIdx.x * kWavesPerBlock + w; a < cap; a += nwaves) {
+        const uint32_t an = tab.hcount[a];
+        if (an == 0) continue;
+        const unsigned long long ka = tab.hkey[a] - 1ull;
+        const uint32_t b = stencil_neighbour(tab.hkey, mask, ka, lane, +1);
         bool need = false;
-        if (b != 0xFFFFFFFFu) need = uf_find(parent, a) != uf_find(parent, b);
+        if (b != kNoSlot) need = uf_find(parent, a) != uf_find(parent, b);
         uint64_t need_mask = __ballot(need);
         if (need_mask == 0) continue;
-        const uint32_t a0 = cell_start[a], an = cell_start[a + 1] - a0;
+        const uint32_t a0 = cell_start[a];
         uint32_t b0 = 0, bn = 0;
-        if (need) { b0 = cell_start[b]; bn = cell_start[b + 1] - b0; }
-        uint32_t bn_max = bn;
-#pragma unroll
-        for (int d = kWave / 2; d > 0; d >>= 1) bn_max = max(bn_max, (uint32_t)__shfl_xor(bn_max, d, kWave));
+        if (need) { b0 = cell_start[b]; bn = tab.hcount[b]; }
+        const uint32_t bn_max = wave_max(bn);
         if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
             if (lane < an) s_pa[w][lane] = rec[a0 + lane];
             __builtin_amdgcn_wave_barrier();
-            if (need && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2)) uf_union(parent, a, b);
+            if (need && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2)) uf_union(parent, tab.hmin, a, b);
             __builtin_amdgcn_wave_barrier();
         } else {
             while (need_mask) {
@@ -1042,180 +1054,138 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const float4* __restrict_
                 if (lane == 0) { ra = uf_find(parent, a); rb = uf_find(parent, cb); }
                 ra = __shfl(ra, 0, kWave); rb = __shfl(rb, 0, kWave);
                 if (ra == rb) continue;
-                if (wave_pair_hit(rec, a0, an, cb0, cbn, r2) && lane == 0) uf_union(parent, a, cb);
+                if (wave_pair_hit(rec, a0, an, cb0, cbn, r2) && lane == 0) uf_union(parent, tab.hmin, a, cb);
             }
         }
     }
 }
 
-// Component of every cell; component size and smallest point index (its discovery key).
-// Cells are handled 64 at a time; lanes whose cells share a root combine their contribution
-// in registers first, so a component costs one atomic pair per wave, not per cell.
-__global__ __launch_bounds__(kBlock) void k_cell_flatten(const DevState* st, const uint32_t* __restrict__ cell_start,
-                                                         const uint32_t* __restrict__ cell_minidx,
-                                                         uint32_t* __restrict__ parent, uint32_t* __restrict__ cell_root,
-                                                         uint32_t* __restrict__ comp_size, uint32_t* __restrict__ comp_min) {
-    if (st->err) return;
-    const uint32_t ncell = st->n_cells;
+// Root cell of every point; component sizes.  Points are handled 64 at a time; lanes whose
+// points share a root add up in registers first, so a component costs one atomic per wave.
+__global__ __launch_bounds__(kBlock) void k_cell_flatten(const DevState* st, const uint32_t* __restrict__ pt_slot,
+                                                         uint32_t* __restrict__ parent, uint32_t* __restrict__ pt_root,
+                                                         uint32_t* __restrict__ comp_size) {
+    if (cluster_stage_off(st)) return;
+    const uint32_t n = st->c_n;
     const uint32_t lane = lane_id();
     const uint32_t nthreads = gridDim.x * blockDim.x;
-    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < ncell; base += nthreads) {
-        const uint32_t c = base + lane;
-        const bool valid = c < ncell;
-        uint32_t r = 0xFFFFFFFFu, cnt = 0, mn = 0xFFFFFFFFu;
-        if (valid) {
-            r = uf_find(parent, c);
-            cell_root[c] = r;
-            cnt = cell_start[c + 1] - cell_start[c];
-            mn = cell_minidx[c];
-        }
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += nthreads) {
+        const uint32_t i = base + lane;
+        const bool valid = i < n;
+        uint32_t r = 0xFFFFFFFFu;
+        if (valid) { r = uf_find(parent, pt_slot[i]); pt_root[i] = r; }
         uint64_t todo = __ballot(valid);
         while (todo) {
             const int leader = __ffsll((unsigned long long)todo) - 1;
             const uint32_t rl = __shfl(r, leader, kWave);
-            const bool mine = valid && r == rl;
-            uint32_t c2 = mine ? cnt : 0u, m2 = mine ? mn : 0xFFFFFFFFu;
-#pragma unroll
-            for (int d = kWave / 2; d > 0; d >>= 1) {
-                c2 += __shfl_xor(c2, d, kWave);
-                m2 = min(m2, (uint32_t)__shfl_xor(m2, d, kWave));
-            }
-            if ((int)lane == leader) { atomicAdd(comp_size + rl, c2); atomicMin(comp_min + rl, m2); }
-            todo &= ~__ballot(mine);
+            const uint64_t same = __ballot(valid && r == rl);
+            if ((int)lane == leader) atomicAdd(comp_size + rl, (uint32_t)__popcll(same));
+            todo &= ~same;
         }
     }
 }
 
-// extractEuclideanClusters' size filter: kept_val[first point of component] = size if kept.
-__global__ __launch_bounds__(kBlock) void k_mark_kept(const DevState* st, const uint32_t* __restrict__ cell_root,
-                                                      const uint32_t* __restrict__ comp_size,
-                                                      const uint32_t* __restrict__ comp_min,
-                                                      uint32_t* __restrict__ kept_val) {
-    if (st->err) return;
-    const uint32_t ncell = st->n_cells;
-    const uint32_t lo = st->min_cluster, hi = st->max_cluster;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
-        if (cell_root[c] != c) continue;
-        const uint32_t s = comp_size[c];
-        if (s >= lo && s <= hi) kept_val[comp_min[c]] = s;
-    }
+// extractEuclideanClusters' size filter and discovery order.  Point i opens a kept cluster iff it
+// is the first point of its component (hmin[root] == i) and min <= size <= max.
+__device__ __forceinline__ uint32_t kept_size(uint32_t i, const uint32_t* __restrict__ pt_root,
+                                              const uint32_t* __restrict__ hmin, const uint32_t* __restrict__ comp_size,
+                                              uint32_t lo, uint32_t hi, uint32_t* root) {
+    const uint32_t r = pt_root[i];
+    *root = r;
+    if (hmin[r] != i) return 0u;
+    const uint32_t s = comp_size[r];
+    return (s >= lo && s <= hi) ? s : 0u;
 }
 
-// Two-value scan over point-index space: (number of kept clusters, sum of their sizes).
-__global__ __launch_bounds__(kBlock) void k_kept_count(const DevState* st, const uint32_t* __restrict__ kept_val,
-                                                       uint2* __restrict__ tile_sums) {
-    __shared__ uint32_t s_a[kWavesPerBlock], s_b[kWavesPerBlock];
-    if (st->err) return;
+__global__ __launch_bounds__(kBlock) void k_kept_count(const DevState* st, const uint32_t* __restrict__ pt_root,
+                                                       const uint32_t* __restrict__ hmin, const uint32_t* __restrict__ comp_size,
+                                                       uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_pts) {
+    __shared__ uint32_t s_w[kWavesPerBlock];
+    if (cluster_stage_off(st)) return;
     const uint32_t n = st->c_n;
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= n) return;
+    const uint32_t lo = st->min_cluster, hi = st->max_cluster;
     uint32_t c = 0, s = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t i = base + threadIdx.x * kScanItems + k;
-        if (i < n) { const uint32_t v = kept_val[i]; c += v ? 1u : 0u; s += v; }
+        if (i < n) { uint32_t r; const uint32_t v = kept_size(i, pt_root, hmin, comp_size, lo, hi, &r); c += v ? 1u : 0u; s += v; }
     }
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) { c += __shfl_xor(c, d, kWave); s += __shfl_xor(s, d, kWave); }
-    if (lane_id() == 0) { s_a[threadIdx.x / kWave] = c; s_b[threadIdx.x / kWave] = s; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t ta = 0, tb = 0;
-        for (int i = 0; i < kWavesPerBlock; ++i) { ta += s_a[i]; tb += s_b[i]; }
-        tile_sums[blockIdx.x] = make_uint2(ta, tb);
-    }
+    const uint32_t tc = block_sum(c, s_w);
+    const uint32_t ts = block_sum(s, s_w);
+    if (threadIdx.x == 0) { tile_cnt[blockIdx.x] = tc; tile_pts[blockIdx.x] = ts; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_kept_scan_tiles(uint2* __restrict__ tile_sums, DevState* st,
-                                                            uint32_t* __restrict__ offsets_out, uint32_t npass_csr) {
+// comp_rank[root] = discovery rank of the kept cluster; offsets_out[rank] = CSR offset.
+__global__ __launch_bounds__(kBlock) void k_kept_apply(DevState* st, const uint32_t* __restrict__ pt_root,
+                                                       const uint32_t* __restrict__ hmin, const uint32_t* __restrict__ comp_size,
+                                                       const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_pts,
+                                                       uint32_t* __restrict__ comp_rank, uint32_t* __restrict__ offsets_out,
+                                                       uint32_t npass_csr) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    if (st->err) return;
+    if (cluster_stage_off(st)) return;
     const uint32_t n = st->c_n;
-    const uint32_t ntiles = (n + kScanTile - 1) / kScanTile;
-    uint32_t ca = 0, cb = 0;
-    for (uint32_t base = 0; base < ntiles; base += kBlock) {
-        const uint32_t i = base + threadIdx.x;
-        const uint2 v = i < ntiles ? tile_sums[i] : make_uint2(0u, 0u);
-        uint32_t ta, tb;
-        const uint32_t ea = block_excl_scan(v.x, s_w, &ta);
-        const uint32_t eb = block_excl_scan(v.y, s_w, &tb);
-        if (i < ntiles) tile_sums[i] = make_uint2(ca + ea, cb + eb);
-        ca += ta; cb += tb;
+    if (n == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_kept = 0; st->n_kept_pts = 0; offsets_out[0] = 0; make_plan(&st->plan_csr, 1, npass_csr); }
+        return;
     }
-    if (threadIdx.x == 0) {
-        st->n_kept = ca; st->n_kept_pts = cb;
-        offsets_out[ca] = cb;
-        // keys of the CSR partition are 0..n_kept (n_kept = "not in a kept cluster")
-        if (!make_plan(&st->plan_csr, bits_for((uint64_t)ca + 1), npass_csr)) st->err = kErrReplanCsr;
-    }
-}
-
-// rank_at[first point] = discovery rank of the kept cluster; offsets_out[rank] = CSR offset.
-__global__ __launch_bounds__(kBlock) void k_kept_apply(const DevState* st, const uint32_t* __restrict__ kept_val,
-                                                       const uint2* __restrict__ tile_sums_x,
-                                                       uint32_t* __restrict__ rank_at, uint32_t* __restrict__ offsets_out) {
-    __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    if (st->err) return;
-    const uint32_t n = st->c_n;
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= n) return;
-    uint32_t v[kScanItems];
+    const uint32_t before_c = tiles_before(tile_cnt, blockIdx.x, s_w);
+    const uint32_t before_s = tiles_before(tile_pts, blockIdx.x, s_w);
+    const uint32_t lo = st->min_cluster, hi = st->max_cluster;
+    uint32_t v[kScanItems], root[kScanItems];
     uint32_t c = 0, s = 0;
     const uint32_t i0 = base + threadIdx.x * kScanItems;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t i = i0 + k;
-        v[k] = i < n ? kept_val[i] : 0u;
+        v[k] = 0; root[k] = 0;
+        if (i < n) v[k] = kept_size(i, pt_root, hmin, comp_size, lo, hi, &root[k]);
         c += v[k] ? 1u : 0u; s += v[k];
     }
-    uint32_t tot;
-    const uint2 tb = tile_sums_x[blockIdx.x];
-    uint32_t rc = tb.x + block_excl_scan(c, s_w, &tot);
-    uint32_t rs = tb.y + block_excl_scan(s, s_w, &tot);
+    uint32_t totc, tots;
+    uint32_t rc = before_c + block_excl_scan(c, s_w, &totc);
+    uint32_t rs = before_s + block_excl_scan(s, s_w, &tots);
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
-        if (v[k]) { rank_at[i0 + k] = rc; offsets_out[rc] = rs; ++rc; rs += v[k]; }
+        if (v[k]) { comp_rank[root[k]] = rc; offsets_out[rc] = rs; ++rc; rs += v[k]; }
     }
-}
-
-// label[point] = rank of its cluster, or n_kept when its component was filtered out.
-__global__ __launch_bounds__(kBlock) void k_label_points(const float4* __restrict__ rec, const DevState* st,
-                                                         const uint32_t* __restrict__ rec_cell,
-                                                         const uint32_t* __restrict__ cell_root,
-                                                         const uint32_t* __restrict__ comp_size,
-                                                         const uint32_t* __restrict__ comp_min,
-                                                         const uint32_t* __restrict__ rank_at,
-                                                         uint32_t* __restrict__ label) {
-    if (st->err) return;
-    const uint32_t n = st->c_n;
-    const uint32_t lo = st->min_cluster, hi = st->max_cluster, trash = st->n_kept;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t r = cell_root[rec_cell[i]];
-        const uint32_t s = comp_size[r];
-        const uint32_t idx = f2u(rec[i].w);
-        label[idx] = (s >= lo && s <= hi) ? rank_at[comp_min[r]] : trash;
+    if (threadIdx.x == 0 && base + kScanTile >= n) {   // the last tile knows the totals
+        const uint32_t nk = before_c + totc, np = before_s + tots;
+        st->n_kept = nk; st->n_kept_pts = np;
+        offsets_out[nk] = np;
+        // keys of the CSR partition are 0..n_kept (n_kept = "not in a kept cluster")
+        if (!make_plan(&st->plan_csr, bits_for((uint64_t)nk + 1), npass_csr)) atomicOr(&st->err, (uint32_t)kErrReplanCsr);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// CSR: stable partition of point indices 0..c_n-1 by label (LSD over plan_csr digits).
+// CSR: stable partition of point indices 0..c_n-1 by cluster rank (LSD over plan_csr digits).
 // Pass 0 reads the identity permutation, later passes read the previous output.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool csr_pass_info(const DevState* st, int pass, uint32_t* count, uint32_t* bits,
                                               uint32_t* shift) {
+    if (cluster_stage_off(st)) return false;
     *count = st->c_n; *bits = st->plan_csr.bits[pass]; *shift = st->plan_csr.shift[pass];
     return st->n_kept != 0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_csr_hist(const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ label,
-                                                     const DevState* st, int pass, uint32_t* __restrict__ table) {
+__device__ __forceinline__ uint32_t point_label(uint32_t p, const uint32_t* __restrict__ pt_root,
+                                                const uint32_t* __restrict__ comp_rank, uint32_t trash) {
+    return min(comp_rank[pt_root[p]], trash);
+}
+
+__global__ __launch_bounds__(kBlock) void k_csr_hist(const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ pt_root,
+                                                     const uint32_t* __restrict__ comp_rank, const DevState* st, int pass,
+                                                     uint32_t* __restrict__ table) {
     __shared__ uint32_t s_h[kMaxBins];
-    if (st->err) return;
     uint32_t count, bits, shift;
     if (!csr_pass_info(st, pass, &count, &bits, &shift)) return;
     const uint32_t tile_base = blockIdx.x * kTile;
     if (tile_base >= count) return;
-    const uint32_t nb = (1u << bits) + 1u;
+    const uint32_t nb = (1u << bits) + 1u, trash = st->n_kept;
     for (uint32_t b = threadIdx.x; b < nb; b += kBlock) s_h[b] = 0;
     __syncthreads();
     const uint32_t mask = (1u << bits) - 1u;
@@ -1225,7 +1195,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_hist(const uint32_t* __restrict_
         const uint32_t i = wbase + j * kWave;
         if (i < count) {
             const uint32_t p = pass == 0 ? i : idx_in[i];
-            atomicAdd(&s_h[(label[p] >> shift) & mask], 1u);
+            atomicAdd(&s_h[(point_label(p, pt_root, comp_rank, trash) >> shift) & mask], 1u);
         }
     }
     __syncthreads();
@@ -1233,18 +1203,18 @@ __global__ __launch_bounds__(kBlock) void k_csr_hist(const uint32_t* __restrict_
     for (uint32_t b = threadIdx.x; b < nb; b += kBlock) row[b] = s_h[b];
 }
 
-__global__ __launch_bounds__(kBlock) void k_csr_scatter(const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ label,
-                                                        const DevState* st, int pass, const uint32_t* __restrict__ table_x,
+__global__ __launch_bounds__(kBlock) void k_csr_scatter(const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ pt_root,
+                                                        const uint32_t* __restrict__ comp_rank, const DevState* st, int pass,
+                                                        const uint32_t* __restrict__ table_x,
                                                         const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ idx_out) {
     __shared__ uint32_t s_hist[kWavesPerBlock * kMaxBins];
     __shared__ uint32_t s_base[kMaxBins];
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    if (st->err) return;
     uint32_t count, bits, shift;
     if (!csr_pass_info(st, pass, &count, &bits, &shift)) return;
     const uint32_t tile_base = blockIdx.x * kTile;
     if (tile_base >= count) return;
-    const uint32_t nb = (1u << bits) + 1u;
+    const uint32_t nb = (1u << bits) + 1u, trash = st->n_kept;
     for (uint32_t b = threadIdx.x; b < kWavesPerBlock * nb; b += kBlock) s_hist[b] = 0;
     scan_bins_to_lds(bin_total, nb, s_base, s_w);
     const uint32_t w = threadIdx.x / kWave;
@@ -1260,7 +1230,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_scatter(const uint32_t* __restri
         pt[j] = 0;
         if (active) {
             pt[j] = pass == 0 ? i : idx_in[i];
-            d = (label[pt[j]] >> shift) & mask;
+            d = (point_label(pt[j], pt_root, comp_rank, trash) >> shift) & mask;
         }
         const uint64_t peers = match_digit(d, bits, active);
         const uint32_t rank = __popcll(peers & lanemask_lt());
@@ -1289,18 +1259,66 @@ __global__ __launch_bounds__(kBlock) void k_csr_scatter(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// end of frame: results -> pinned host memory (zero-copy stores), hash table reset
+// ------------------------------------------------------------------------------------------
+struct HostOut {
+    DevState* state;
+    uint32_t* offsets;     // n_kept + 1
+    uint32_t* indices;     // n_kept_pts, discovery order
+    float* cloud;          // voxel cloud in st->out_layout
+};
+
+__global__ __launch_bounds__(kBlock) void k_emit(const DevState* st, HostOut out, const uint32_t* __restrict__ d_offsets,
+                                                 const uint32_t* __restrict__ d_indices, const float* __restrict__ cen_x,
+                                                 const float* __restrict__ cen_y, const float* __restrict__ cen_z,
+                                                 CellTable tab) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    // reset the cell table for the next frame (also after an error: only touched slots are dirty,
+    // and they all lie below hash_mask + 1)
+    if (st->kind != kFrameVoxelOnly && !st->trivial && st->hash_mask) {
+        const uint32_t cap = st->hash_mask + 1u;
+        for (uint32_t i = tid; i < cap; i += nth) { tab.hkey[i] = 0ull; tab.hcount[i] = 0u; tab.hmin[i] = 0xFFFFFFFFu; }
+    }
+    if (tid == 0) *out.state = *st;
+    if (st->err) return;
+    if (st->kind != kFrameVoxelOnly && !st->trivial) {
+        const uint32_t k = st->n_kept, np = st->n_kept_pts;
+        for (uint32_t i = tid; i <= k; i += nth) out.offsets[i] = d_offsets[i];
+        for (uint32_t i = tid; i < np; i += nth) out.indices[i] = d_indices[i];
+    }
+    if (st->emit_cloud) {
+        const bool pt = st->passthrough != 0;
+        const float* __restrict__ px = pt ? st->src_x : cen_x;
+        const float* __restrict__ py = pt ? st->src_y : cen_y;
+        const float* __restrict__ pz = pt ? st->src_z : cen_z;
+        const uint32_t m = st->m, layout = st->out_layout, stride = st->out_soa_stride;
+        for (uint32_t i = tid; i < m; i += nth) {
+            const float x = px[i], y = py[i], z = pz[i];
+            if (layout == 0) {
+                reinterpret_cast<float4*>(out.cloud)[i] = make_float4(x, y, z, 1.0f);
+            } else if (layout == 1) {
+                out.cloud[i] = x; out.cloud[stride + i] = y; out.cloud[2 * (size_t)stride + i] = z;
+            } else {
+                out.cloud[3 * (size_t)i] = x; out.cloud[3 * (size_t)i + 1] = y; out.cloud[3 * (size_t)i + 2] = z;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // PointWithRad per cluster (msg/PointWithRad.msg): one wave per cluster.
 // centre = double mean rounded to float; r = max calculate_distance() (od.cpp:457-464).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_cluster_summaries(SoaPair src, const DevState* st,
+__global__ __launch_bounds__(kBlock) void k_cluster_summaries(const DevState* st, const float* __restrict__ cen_x,
+                                                              const float* __restrict__ cen_y, const float* __restrict__ cen_z,
                                                               const uint32_t* __restrict__ offsets,
                                                               const uint32_t* __restrict__ indices,
                                                               float4* __restrict__ xyzr) {
     if (st->err) return;
     const bool sel = st->c_from_input != 0;
-    const float* x = sel ? src.bx : src.ax;
-    const float* y = sel ? src.by : src.ay;
-    const float* z = sel ? src.bz : src.az;
+    const float* __restrict__ x = sel ? st->src_x : cen_x;
+    const float* __restrict__ y = sel ? st->src_y : cen_y;
+    const float* __restrict__ z = sel ? st->src_z : cen_z;
     const uint32_t k = st->n_kept;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;

@@ -91,11 +91,16 @@ def test_kat5_overflow_passthrough(ctx, capi):
     pts1 = np.array([[0, 0, 0], [3000, 0, 0]], dtype=f32)
     vox1, pt1 = ctx.voxel_downsample(pts1)
     assert not pt1 and vox1.shape[0] == 2
-    # documented limit of the neighbour grid: extent/tolerance beyond 2^32 cells is a loud error
     ctx.set_params(leaf=0.001, tol=0.1, min_cluster=1, max_cluster=10)
+    res = ctx.process_xyz(pts)                       # 30000 cells apart: still singletons
+    assert list(np.diff(res["offsets"])) == [1, 1, 1, 1]
+    # documented limit of the neighbour grid: |coordinate| / (tol/1.99) beyond 2^20 cells is a loud error
+    far = np.array([[0, 0, 0], [1.0e6, 0, 0]], dtype=f32)
     with pytest.raises(capi.PcopError) as e:
-        ctx.process_xyz(pts)
+        ctx.euclidean_clusters(far)
     assert e.value.status == -7
+    res = ctx.euclidean_clusters(pts)                # and the context is usable again afterwards
+    assert list(np.diff(res[0])) == [1, 1, 1, 1]
 
 
 def test_kat6_kat7_filter_and_order(ctx, oracle):

@@ -16,9 +16,8 @@ def show_state(st):
     print("  state: err=%d n_in=%d n_valid=%d pt=%d m=%d min_b=%s div_b=%s mul=%s kb=%d bits=%s" % (
         st.err, st.n_in, st.n_valid, st.passthrough, st.m, list(st.min_b), list(st.div_b), list(st.mul),
         st.plan_voxel.key_bits, list(st.plan_voxel.bits)))
-    print("         c_n=%d from_input=%d r2=%g cdim=%s ckb=%d cbits=%s cells=%d kept=%d kept_pts=%d csr_bits=%s" % (
-        st.c_n, st.c_from_input, st.r2, list(st.cdim), st.plan_cell.key_bits, list(st.plan_cell.bits), st.n_cells,
-        st.n_kept, st.n_kept_pts, list(st.plan_csr.bits)))
+    print("         c_n=%d from_input=%d r2=%g hash_mask=%d cells=%d kept=%d kept_pts=%d csr_bits=%s" % (
+        st.c_n, st.c_from_input, st.r2, st.hash_mask, st.n_cells, st.n_kept, st.n_kept_pts, list(st.plan_csr.bits)))
 
 
 def run(cfg, n):
