@@ -61,6 +61,7 @@ struct pcop_ctx {
     unsigned long long* hkey = nullptr;                           // cell hash table
     uint32_t *hcount = nullptr, *hmin = nullptr;
     uint32_t *cell_start = nullptr, *parent = nullptr, *comp_size = nullptr, *comp_rank = nullptr;   // per slot
+    uint32_t* cell_list = nullptr;   // occupied slots, dense
     uint32_t *pt_slot = nullptr, *pt_rank = nullptr, *pt_root = nullptr;                            // per point
     uint32_t *idx_a = nullptr, *idx_b = nullptr, *d_offsets = nullptr;
     float4* d_xyzr = nullptr;
@@ -200,22 +201,23 @@ void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb) {
         const CellTable tab = cell_table(c);
         const uint32_t hcap = hash_cap_for(nb);
         const uint32_t hg = std::max(1u, hcap / kScanTile);       // scan tiles over hash slots
-        const uint32_t wg = std::min(8192u, std::max(1u, hcap / kWavesPerBlock));   // one wave per slot, grid-strided
+        const uint32_t wg = std::min(8192u, std::max(1u, div_up(nb, kWavesPerBlock)));   // one wave per cell, grid-strided
         k_cell_insert<<<tg, kBlock, 0, s>>>(c->d_state, c->cen_x, c->cen_y, c->cen_z, tab, c->pt_slot, c->pt_rank);
         mark(c, "k_cell_insert");
-        k_slot_count<<<hg, kBlock, 0, s>>>(c->d_state, c->hcount, c->tile_a);
+        k_slot_count<<<hg, kBlock, 0, s>>>(c->d_state, c->hcount, c->tile_a, c->tile_b);
         mark(c, "k_slot_count");
-        k_slot_apply<<<hg, kBlock, 0, s>>>(c->d_state, c->hcount, c->tile_a, c->cell_start, c->parent, c->comp_size, c->comp_rank);
+        k_slot_apply<<<hg, kBlock, 0, s>>>(c->d_state, c->hcount, c->tile_a, c->tile_b, c->cell_start, c->cell_list, c->parent,
+                                           c->comp_size, c->comp_rank);
         mark(c, "k_slot_apply");
         k_cell_place<<<tg, kBlock, 0, s>>>(c->d_state, c->cen_x, c->cen_y, c->cen_z, c->pt_slot, c->pt_rank, c->cell_start, c->rec_a);
         mark(c, "k_cell_place");
-        k_cell_hook<<<wg, kBlock, 0, s>>>(c->rec_a, c->d_state, tab, c->cell_start, c->parent);
+        k_cell_hook<<<wg, kBlock, 0, s>>>(c->rec_a, c->d_state, tab, c->cell_start, c->cell_list, c->parent);
         mark(c, "k_cell_hook");
-        k_cell_compress<<<stride_grid(hcap), kBlock, 0, s>>>(c->d_state, c->hcount, c->parent);
+        k_cell_compress<<<tg, kBlock, 0, s>>>(c->d_state, c->cell_list, c->parent);
         mark(c, "k_cell_compress");
-        k_cell_union<<<wg, kBlock, 0, s>>>(c->rec_a, c->d_state, tab, c->cell_start, c->parent);
+        k_cell_union<<<wg, kBlock, 0, s>>>(c->rec_a, c->d_state, tab, c->cell_start, c->cell_list, c->parent);
         mark(c, "k_cell_union");
-        k_cell_flatten<<<tg, kBlock, 0, s>>>(c->d_state, c->pt_slot, c->parent, c->pt_root, c->comp_size);
+        k_cell_flatten<<<64, kBlock, 0, s>>>(c->d_state, c->pt_slot, c->parent, c->pt_root, c->comp_size);
         mark(c, "k_cell_flatten");
         k_kept_count<<<sg, kBlock, 0, s>>>(c->d_state, c->pt_root, c->hmin, c->comp_size, c->tile_a, c->tile_b);
         mark(c, "k_kept_count");
@@ -478,7 +480,7 @@ int pcop_create(pcop_ctx** out, int device_id, size_t max_points) {
     TRY(dev_alloc(c, &c->partials, (size_t)kReduceBlocks));
     TRY(dev_alloc(c, &c->hkey, hcap)); TRY(dev_alloc(c, &c->hcount, hcap)); TRY(dev_alloc(c, &c->hmin, hcap));
     TRY(dev_alloc(c, &c->cell_start, hcap)); TRY(dev_alloc(c, &c->parent, hcap));
-    TRY(dev_alloc(c, &c->comp_size, hcap)); TRY(dev_alloc(c, &c->comp_rank, hcap));
+    TRY(dev_alloc(c, &c->comp_size, hcap)); TRY(dev_alloc(c, &c->comp_rank, hcap)); TRY(dev_alloc(c, &c->cell_list, n + 1));
     TRY(dev_alloc(c, &c->pt_slot, n + 1)); TRY(dev_alloc(c, &c->pt_rank, n + 1)); TRY(dev_alloc(c, &c->pt_root, n + 1));
     TRY(dev_alloc(c, &c->idx_a, n + 1)); TRY(dev_alloc(c, &c->idx_b, n + 1)); TRY(dev_alloc(c, &c->d_offsets, n + 2));
     TRY(dev_alloc(c, &c->d_xyzr, n + 1));
@@ -508,7 +510,7 @@ void pcop_destroy(pcop_ctx* c) {
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     void* dev[] = {c->in_x, c->in_y, c->in_z, c->cen_x, c->cen_y, c->cen_z, c->rec_a, c->rec_b, c->table, c->table_x,
                    c->bin_total, c->tile_a, c->tile_b, c->partials, c->hkey, c->hcount, c->hmin, c->cell_start, c->parent,
-                   c->comp_size, c->comp_rank, c->pt_slot, c->pt_rank, c->pt_root, c->idx_a, c->idx_b, c->d_offsets,
+                   c->comp_size, c->comp_rank, c->cell_list, c->pt_slot, c->pt_rank, c->pt_root, c->idx_a, c->idx_b, c->d_offsets,
                    c->d_xyzr, c->d_raw, c->d_state};
     for (void* p : dev) if (p) hipFree(p);
     for (void* p : c->user_allocs) if (p) hipFree(p);

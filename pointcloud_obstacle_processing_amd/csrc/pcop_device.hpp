@@ -42,7 +42,7 @@ constexpr int kTile = kBlock * kItems;           // records per partition block
 constexpr int kMaxPasses = 3;                    // 3 x 11 bits >= 32-bit keys
 constexpr int kScanItems = 4;                    // elements per thread in flag-scan kernels
 constexpr int kScanTile = kBlock * kScanItems;
-constexpr int kReduceBlocks = 512;               // grid of the min/max kernel
+constexpr int kReduceBlocks = 256;               // grid of the min/max kernel: one block per CU, short ticket queue
 constexpr int kCellBias = 1 << 20;               // cell coordinates are stored biased, 21 bits per axis
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
@@ -634,6 +634,8 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(const float4* __restric
                                                          float* __restrict__ cx, float* __restrict__ cy,
                                                          float* __restrict__ cz) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    __shared__ float4 s_rec[kScanTile];
+    __shared__ uint32_t s_key[kScanTile + 1];
     if (st->err || st->kind == kFrameClusterOnly) return;
     if (st->passthrough) {   // "output = *input_": the voxel cloud is the input cloud, every point kept
         if (blockIdx.x == 0 && threadIdx.x == 0) finish_voxel(st, st->n_in);
@@ -648,19 +650,27 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(const float4* __restric
     if (base >= n) return;
     const uint32_t before = tiles_before(tile_heads, blockIdx.x, s_w);
     VoxelKey key; key.init(st);
+    // stage the tile's records and keys in LDS (coalesced), so that the in-order run sums below
+    // chase LDS, not L2
+    const uint32_t cnt = min((uint32_t)kScanTile, n - base);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t j = k * kBlock + threadIdx.x;
+        if (j < cnt) { const float4 r = rec[base + j]; s_rec[j] = r; s_key[j + 1] = key(r); }
+    }
+    if (threadIdx.x == 0) s_key[0] = base > 0 ? key(rec[base - 1]) : 0u;
+    __syncthreads();
     uint32_t kcur[kScanItems];
     bool head[kScanItems];
     uint32_t c = 0;
-    const uint32_t i0 = base + threadIdx.x * kScanItems;
-    uint32_t kprev = (i0 > 0 && i0 <= n) ? key(rec[i0 - 1]) : 0u;
+    const uint32_t j0 = threadIdx.x * kScanItems;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
-        const uint32_t i = i0 + k;
+        const uint32_t j = j0 + k;
         head[k] = false;
-        if (i < n) {
-            kcur[k] = key(rec[i]);
-            head[k] = (i == 0) || (kcur[k] != kprev);
-            kprev = kcur[k];
+        if (j < cnt) {
+            kcur[k] = s_key[j + 1];
+            head[k] = (base + j == 0) || (kcur[k] != s_key[j]);
             c += head[k] ? 1u : 0u;
         }
     }
@@ -669,20 +679,26 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(const float4* __restric
     if (threadIdx.x == 0 && base + kScanTile >= n) finish_voxel(st, before + tot);   // the last tile
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
-        const uint32_t i = i0 + k;
-        if (i < n && head[k]) {
+        const uint32_t j = j0 + k;
+        if (j < cnt && head[k]) {
             float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-            uint32_t j = i;
-            float4 r = rec[j];
-            while (true) {
+            uint32_t jj = j;
+            do {   // the part of the run inside this tile
+                const float4 r = s_rec[jj];
                 sx += r.x; sy += r.y; sz += r.z;
-                ++j;
-                if (j >= n) break;
-                r = rec[j];
-                if (key(r) != kcur[k]) break;
+                ++jj;
+            } while (jj < cnt && s_key[jj + 1] == kcur[k]);
+            uint32_t len = jj - j;
+            if (jj == cnt) {   // the run may continue in the next tile(s)
+                for (uint32_t g = base + cnt; g < n; ++g) {
+                    const float4 r = rec[g];
+                    if (key(r) != kcur[k]) break;
+                    sx += r.x; sy += r.y; sz += r.z;
+                    ++len;
+                }
             }
-            const float cnt = (float)(j - i);
-            cx[rank] = sx / cnt; cy[rank] = sy / cnt; cz[rank] = sz / cnt;
+            const float fc = (float)len;
+            cx[rank] = sx / fc; cy[rank] = sy / fc; cz[rank] = sz / fc;
             ++rank;
         }
     }
@@ -801,49 +817,58 @@ __global__ __launch_bounds__(kBlock) void k_cell_insert(DevState* st, const floa
     }
 }
 
-// points per tile of kScanTile slots
+// points and occupied slots per tile of kScanTile slots
 __global__ __launch_bounds__(kBlock) void k_slot_count(const DevState* st, const uint32_t* __restrict__ hcount,
-                                                       uint32_t* __restrict__ tile_sums) {
+                                                       uint32_t* __restrict__ tile_pts, uint32_t* __restrict__ tile_occ) {
     __shared__ uint32_t s_w[kWavesPerBlock];
     if (cluster_stage_off(st)) return;
     const uint32_t cap = st->hash_mask + 1u;
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= cap) return;
-    uint32_t c = 0;
+    uint32_t c = 0, o = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) c += hcount[base + threadIdx.x * kScanItems + k];   // cap is a multiple of 1024
+    for (int k = 0; k < kScanItems; ++k) {   // cap is a multiple of 1024
+        const uint32_t v = hcount[base + threadIdx.x * kScanItems + k];
+        c += v; o += v ? 1u : 0u;
+    }
     const uint32_t t = block_sum(c, s_w);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = t;
+    const uint32_t u = block_sum(o, s_w);
+    if (threadIdx.x == 0) { tile_pts[blockIdx.x] = t; tile_occ[blockIdx.x] = u; }
 }
 
-// cell_start[slot] = number of points in slots before it; union-find init
+// cell_start[slot] = number of points in slots before it; dense list of occupied slots;
+// union-find init
 __global__ __launch_bounds__(kBlock) void k_slot_apply(DevState* st, const uint32_t* __restrict__ hcount,
-                                                       const uint32_t* __restrict__ tile_sums,
-                                                       uint32_t* __restrict__ cell_start, uint32_t* __restrict__ parent,
+                                                       const uint32_t* __restrict__ tile_pts,
+                                                       const uint32_t* __restrict__ tile_occ,
+                                                       uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_list,
+                                                       uint32_t* __restrict__ parent,
                                                        uint32_t* __restrict__ comp_size, uint32_t* __restrict__ comp_rank) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     if (cluster_stage_off(st)) return;
     const uint32_t cap = st->hash_mask + 1u;
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= cap) return;
-    const uint32_t before = tiles_before(tile_sums, blockIdx.x, s_w);
+    const uint32_t before = tiles_before(tile_pts, blockIdx.x, s_w);
+    const uint32_t before_occ = tiles_before(tile_occ, blockIdx.x, s_w);
     uint32_t v[kScanItems];
     uint32_t c = 0, occ = 0;
     const uint32_t s0 = base + threadIdx.x * kScanItems;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) { v[k] = hcount[s0 + k]; c += v[k]; occ += v[k] ? 1u : 0u; }
-    uint32_t tot;
+    uint32_t tot, tot_occ;
     uint32_t run = before + block_excl_scan(c, s_w, &tot);
+    uint32_t id = before_occ + block_excl_scan(occ, s_w, &tot_occ);
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         cell_start[s0 + k] = run;
         parent[s0 + k] = s0 + k;
         comp_size[s0 + k] = 0u;
         comp_rank[s0 + k] = 0xFFFFFFFFu;
+        if (v[k]) cell_list[id++] = s0 + k;
         run += v[k];
     }
-    occ = block_sum(occ, s_w);
-    if (threadIdx.x == 0 && occ) atomicAdd(&st->n_cells, occ);
+    if (threadIdx.x == 0 && base + kScanTile >= cap) st->n_cells = before_occ + tot_occ;   // the last tile
 }
 
 // counting sort: record of point i goes to cell_start[slot] + rank
@@ -935,10 +960,17 @@ __device__ __forceinline__ uint32_t stencil_neighbour(const unsigned long long* 
 // does some point of B (this lane's cell) lie within the radius of some point of A (in LDS)?
 __device__ __forceinline__ bool lane_pair_hit(const float4* s_pa, uint32_t an, const float4* __restrict__ rec,
                                               uint32_t b0, uint32_t bn, float r2) {
-    for (uint32_t ib = 0; ib < bn; ++ib) {
-        const float4 pb = rec[b0 + ib];
-        for (uint32_t ia = 0; ia < an; ++ia)
-            if (l2_simple(s_pa[ia], pb) < r2) return true;
+    for (uint32_t ib = 0; ib < bn; ib += 4) {   // four independent loads in flight per step
+        float4 pb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pb[q] = rec[b0 + min(ib + q, bn - 1)];
+        bool hit = false;
+        for (uint32_t ia = 0; ia < an; ++ia) {
+            const float4 pa = s_pa[ia];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hit |= l2_simple(pa, pb[q]) < r2;   // a repeated last point changes nothing
+        }
+        if (hit) return true;
     }
     return false;
 }
@@ -962,17 +994,18 @@ __device__ __forceinline__ bool wave_pair_hit(const float4* __restrict__ rec, ui
 
 __global__ __launch_bounds__(kBlock) void k_cell_hook(const float4* __restrict__ rec, const DevState* st, CellTable tab,
                                                       const uint32_t* __restrict__ cell_start,
+                                                      const uint32_t* __restrict__ cell_list,
                                                       uint32_t* __restrict__ parent) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
     if (cluster_stage_off(st)) return;
-    const uint32_t mask = st->hash_mask, cap = mask + 1u;
+    const uint32_t mask = st->hash_mask, ncell = st->n_cells;
     const float r2 = st->r2;
     const uint32_t w = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
-    for (uint32_t a = blockIdx.x * kWavesPerBlock + w; a < cap; a += nwaves) {
+    for (uint32_t ai = blockIdx.x * kWavesPerBlock + w; ai < ncell; ai += nwaves) {
+        const uint32_t a = cell_list[ai];
         const uint32_t an = tab.hcount[a];
-        if (an == 0) continue;
         const unsigned long long ka = tab.hkey[a] - 1ull;
         const uint32_t pa = tab.hmin[a];
         const uint32_t b = stencil_neighbour(tab.hkey, mask, ka, lane, -1);
@@ -1006,12 +1039,12 @@ __global__ __launch_bounds__(kBlock) void k_cell_hook(const float4* __restrict__
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_cell_compress(const DevState* st, const uint32_t* __restrict__ hcount,
+__global__ __launch_bounds__(kBlock) void k_cell_compress(const DevState* st, const uint32_t* __restrict__ cell_list,
                                                           uint32_t* __restrict__ parent) {
     if (cluster_stage_off(st)) return;
-    const uint32_t cap = st->hash_mask + 1u;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cap; c += gridDim.x * blockDim.x) {
-        if (hcount[c] == 0) continue;
+    const uint32_t ncell = st->n_cells;
+    for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < ncell; ci += gridDim.x * blockDim.x) {
+        const uint32_t c = cell_list[ci];
         const uint32_t r = uf_find(parent, c);
         st_agent(parent + c, r);
     }
@@ -1019,17 +1052,18 @@ __global__ __launch_bounds__(kBlock) void k_cell_compress(const DevState* st, co
 
 __global__ __launch_bounds__(kBlock) void k_cell_union(const float4* __restrict__ rec, const DevState* st, CellTable tab,
                                                        const uint32_t* __restrict__ cell_start,
+                                                       const uint32_t* __restrict__ cell_list,
                                                        uint32_t* __restrict__ parent) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
     if (cluster_stage_off(st)) return;
-    const uint32_t mask = st->hash_mask, cap = mask + 1u;
+    const uint32_t mask = st->hash_mask, ncell = st->n_cells;
     const float r2 = st->r2;
     const uint32_t w = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
-    for (uint32_t a = blockIdx.x * kWavesPerBlock + w; a < cap; a += nwaves) {
+    for (uint32_t ai = blockIdx.x * kWavesPerBlock + w; ai < ncell; ai += nwaves) {
+        const uint32_t a = cell_list[ai];
         const uint32_t an = tab.hcount[a];
-        if (an == 0) continue;
         const unsigned long long ka = tab.hkey[a] - 1ull;
         const uint32_t b = stencil_neighbour(tab.hkey, mask, ka, lane, +1);
         bool need = false;
@@ -1060,17 +1094,24 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const float4* __restrict_
     }
 }
 
-// Root cell of every point; component sizes.  Points are handled 64 at a time; lanes whose
-// points share a root add up in registers first, so a component costs one atomic per wave.
+// Root cell of every point; component sizes.  Each wave walks a contiguous chunk of points 64
+// at a time; lanes whose points share a root add up in registers, and the count of the root a
+// wave is currently running through is carried across steps, so a component that spans a long
+// stretch of points (a ground plane) costs one atomic per wave, not one per step.
 __global__ __launch_bounds__(kBlock) void k_cell_flatten(const DevState* st, const uint32_t* __restrict__ pt_slot,
                                                          uint32_t* __restrict__ parent, uint32_t* __restrict__ pt_root,
                                                          uint32_t* __restrict__ comp_size) {
     if (cluster_stage_off(st)) return;
     const uint32_t n = st->c_n;
     const uint32_t lane = lane_id();
-    const uint32_t nthreads = gridDim.x * blockDim.x;
-    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += nthreads) {
-        const uint32_t i = base + lane;
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+    const uint32_t steps = (n + kWave - 1) / kWave;
+    const uint32_t per = (steps + nwaves - 1) / nwaves;
+    const uint32_t s0 = wave * per, s1 = min(s0 + per, steps);
+    uint32_t carry_root = 0xFFFFFFFFu, carry_cnt = 0;   // wave-uniform
+    for (uint32_t sidx = s0; sidx < s1; ++sidx) {
+        const uint32_t i = sidx * kWave + lane;
         const bool valid = i < n;
         uint32_t r = 0xFFFFFFFFu;
         if (valid) { r = uf_find(parent, pt_slot[i]); pt_root[i] = r; }
@@ -1079,10 +1120,17 @@ __global__ __launch_bounds__(kBlock) void k_cell_flatten(const DevState* st, con
             const int leader = __ffsll((unsigned long long)todo) - 1;
             const uint32_t rl = __shfl(r, leader, kWave);
             const uint64_t same = __ballot(valid && r == rl);
-            if ((int)lane == leader) atomicAdd(comp_size + rl, (uint32_t)__popcll(same));
+            const uint32_t cnt = (uint32_t)__popcll(same);
+            if (rl == carry_root) {
+                carry_cnt += cnt;
+            } else {
+                if (carry_cnt && lane == 0) atomicAdd(comp_size + carry_root, carry_cnt);
+                carry_root = rl; carry_cnt = cnt;
+            }
             todo &= ~same;
         }
     }
+    if (carry_cnt && lane == 0) atomicAdd(comp_size + carry_root, carry_cnt);
 }
 
 // extractEuclideanClusters' size filter and discovery order.  Point i opens a kept cluster iff it
