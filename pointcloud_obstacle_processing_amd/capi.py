@@ -46,7 +46,7 @@ class StageTimes(C.Structure):
 
 
 class RadixPlan(C.Structure):
-    _fields_ = [("key_bits", C.c_uint32), ("npass", C.c_uint32), ("bits", C.c_uint32 * 3), ("shift", C.c_uint32 * 3)]
+    _fields_ = [("key_bits", C.c_uint32), ("npass", C.c_uint32), ("bits", C.c_uint32 * 4), ("shift", C.c_uint32 * 4)]
 
 
 class DevState(C.Structure):

@@ -92,6 +92,7 @@ struct pcop_ctx {
     uint32_t npass_voxel = kMaxPasses, npass_csr = kMaxPasses;
     uint32_t* frame_csr_idx = nullptr;   // device CSR indices of the frame in flight / last frame
     int radix_bits_target = 8;    // preferred digit width when choosing pass counts
+    int maxbits = kNarrowBits;    // digit limit of the kernel variant in use (8: small LDS, 11: wide)
     bool use_graph = true;
     std::map<GraphKey, hipGraphExec_t> graphs;
 
@@ -159,36 +160,36 @@ uint32_t hash_cap_for(uint32_t n) {
 
 CellTable cell_table(pcop_ctx* c) { return CellTable{c->hkey, c->hcount, c->hmin}; }
 
-// The launch sequence of one frame.  nb = launch-size bucket (>= the frame's point count); all
-// real counts are read on the device.  Everything here is capturable into a hipGraph.
-void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb) {
+template <int MAXB>
+void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb) {
     hipStream_t s = c->stream;
+    constexpr uint32_t kBinsGrid = (1u << MAXB) + 1u;
     k_frame_init<<<1, 64, 0, s>>>(c->d_state, c->h_args);
     mark(c, "k_frame_init");
     const uint32_t pg = std::max(1u, div_up(nb, kTile));        // partition tiles
     const uint32_t sg = std::max(1u, div_up(nb, kScanTile));    // scan tiles over points
     const uint32_t tg = stride_grid(nb);
     if (kind != kFrameClusterOnly) {
-        k_minmax_voxel_setup<<<kReduceBlocks, kBlock, 0, s>>>(c->d_state, c->partials, c->npass_voxel);
+        k_minmax_voxel_setup<<<kReduceBlocks, kBlock, 0, s>>>(c->d_state, c->partials, c->npass_voxel, (uint32_t)MAXB);
         mark(c, "k_minmax_voxel_setup");
         float4* bufs[2] = {c->rec_a, c->rec_b};
         float4* sorted = nullptr;
         for (uint32_t p = 0; p < c->npass_voxel; ++p) {
             sorted = bufs[p & 1];
             if (p == 0) {
-                k_radix_hist<SoaSrc><<<pg, kBlock, 0, s>>>(SoaSrc{}, c->d_state, (int)p, c->table);
+                k_radix_hist<SoaSrc, MAXB><<<pg, kBlock, 0, s>>>(SoaSrc{}, c->d_state, (int)p, c->table);
                 mark(c, "k_radix_hist");
-                k_table_scan<<<kMaxBins, kBlock, 0, s>>>(c->d_state, 0, (int)p, c->table, c->table_x, c->bin_total);
+                k_table_scan<<<kBinsGrid, kBlock, 0, s>>>(c->d_state, 0, (int)p, c->table, c->table_x, c->bin_total);
                 mark(c, "k_table_scan");
-                k_radix_scatter<SoaSrc><<<pg, kBlock, 0, s>>>(SoaSrc{}, c->d_state, (int)p, c->table_x, c->bin_total, sorted);
+                k_radix_scatter<SoaSrc, MAXB><<<pg, kBlock, 0, s>>>(SoaSrc{}, c->d_state, (int)p, c->table_x, c->bin_total, sorted);
                 mark(c, "k_radix_scatter");
             } else {
                 RecSrc r{bufs[(p - 1) & 1]};
-                k_radix_hist<RecSrc><<<pg, kBlock, 0, s>>>(r, c->d_state, (int)p, c->table);
+                k_radix_hist<RecSrc, MAXB><<<pg, kBlock, 0, s>>>(r, c->d_state, (int)p, c->table);
                 mark(c, "k_radix_hist");
-                k_table_scan<<<kMaxBins, kBlock, 0, s>>>(c->d_state, 0, (int)p, c->table, c->table_x, c->bin_total);
+                k_table_scan<<<kBinsGrid, kBlock, 0, s>>>(c->d_state, 0, (int)p, c->table, c->table_x, c->bin_total);
                 mark(c, "k_table_scan");
-                k_radix_scatter<RecSrc><<<pg, kBlock, 0, s>>>(r, c->d_state, (int)p, c->table_x, c->bin_total, sorted);
+                k_radix_scatter<RecSrc, MAXB><<<pg, kBlock, 0, s>>>(r, c->d_state, (int)p, c->table_x, c->bin_total, sorted);
                 mark(c, "k_radix_scatter");
             }
         }
@@ -222,16 +223,16 @@ void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb) {
         k_kept_count<<<sg, kBlock, 0, s>>>(c->d_state, c->pt_root, c->hmin, c->comp_size, c->tile_a, c->tile_b);
         mark(c, "k_kept_count");
         k_kept_apply<<<sg, kBlock, 0, s>>>(c->d_state, c->pt_root, c->hmin, c->comp_size, c->tile_a, c->tile_b, c->comp_rank,
-                                           c->d_offsets, c->npass_csr);
+                                           c->d_offsets, c->npass_csr, (uint32_t)MAXB);
         mark(c, "k_kept_apply");
         uint32_t* bufs[2] = {c->idx_a, c->idx_b};
         for (uint32_t p = 0; p < c->npass_csr; ++p) {
             const uint32_t* in = p == 0 ? nullptr : bufs[(p - 1) & 1];
-            k_csr_hist<<<pg, kBlock, 0, s>>>(in, c->pt_root, c->comp_rank, c->d_state, (int)p, c->table);
+            k_csr_hist<MAXB><<<pg, kBlock, 0, s>>>(in, c->pt_root, c->comp_rank, c->d_state, (int)p, c->table);
             mark(c, "k_csr_hist");
-            k_table_scan<<<kMaxBins, kBlock, 0, s>>>(c->d_state, 2, (int)p, c->table, c->table_x, c->bin_total);
+            k_table_scan<<<kBinsGrid, kBlock, 0, s>>>(c->d_state, 2, (int)p, c->table, c->table_x, c->bin_total);
             mark(c, "k_table_scan");
-            k_csr_scatter<<<pg, kBlock, 0, s>>>(in, c->pt_root, c->comp_rank, c->d_state, (int)p, c->table_x, c->bin_total, bufs[p & 1]);
+            k_csr_scatter<MAXB><<<pg, kBlock, 0, s>>>(in, c->pt_root, c->comp_rank, c->d_state, (int)p, c->table_x, c->bin_total, bufs[p & 1]);
             mark(c, "k_csr_scatter");
         }
     }
@@ -239,6 +240,13 @@ void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb) {
     HostOut ho{c->h_state, reinterpret_cast<uint32_t*>(c->h_offsets_disc), reinterpret_cast<uint32_t*>(c->h_indices_disc), c->h_vox};
     k_emit<<<tg, kBlock, 0, s>>>(c->d_state, ho, c->d_offsets, csr, c->cen_x, c->cen_y, c->cen_z, cell_table(c));
     mark(c, "k_emit");
+}
+
+// The launch sequence of one frame.  nb = launch-size bucket (>= the frame's point count); all
+// real counts are read on the device.  Everything here is capturable into a hipGraph.
+void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb) {
+    if (c->maxbits <= kNarrowBits) enqueue_launches_t<kNarrowBits>(c, kind, nb);
+    else enqueue_launches_t<kMaxBits>(c, kind, nb);
 }
 
 int enqueue_frame(pcop_ctx* c) {
@@ -281,9 +289,10 @@ int enqueue_frame(pcop_ctx* c) {
     return PCOP_OK;
 }
 
-uint32_t passes_for(uint32_t key_bits, int target_bits) {
+uint32_t passes_for(const pcop_ctx* c, uint32_t key_bits) {
+    const int target_bits = c->radix_bits_target;
     uint32_t p = (key_bits + (uint32_t)target_bits - 1) / (uint32_t)target_bits;
-    const uint32_t pmin = (key_bits + kMaxBits - 1) / kMaxBits;
+    const uint32_t pmin = (key_bits + (uint32_t)c->maxbits - 1) / (uint32_t)c->maxbits;
     p = std::max(p, pmin);
     return std::min<uint32_t>(std::max<uint32_t>(p, 1u), kMaxPasses);
 }
@@ -312,8 +321,8 @@ int finish_frame(pcop_ctx* c, pcop_result* out) {
         if (e & kErrRange) { c->in_flight = false; c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
         if (e & (kErrReplanVoxel | kErrReplanCsr)) {
             if (attempt >= 4) { c->in_flight = false; c->err = "radix replanning did not converge"; return PCOP_ERR_STATE; }
-            if (e & kErrReplanVoxel) c->npass_voxel = passes_for(hs->plan_voxel.key_bits, c->radix_bits_target);
-            if (e & kErrReplanCsr) c->npass_csr = passes_for(hs->plan_csr.key_bits, c->radix_bits_target);
+            if (e & kErrReplanVoxel) c->npass_voxel = passes_for(c, hs->plan_voxel.key_bits);
+            if (e & kErrReplanCsr) c->npass_csr = passes_for(c, hs->plan_csr.key_bits);
             int rc = enqueue_frame(c);
             if (rc) return rc;
             continue;
@@ -323,13 +332,13 @@ int finish_frame(pcop_ctx* c, pcop_result* out) {
     collect_times(c);
     c->in_flight = false;
     // adapt the pass counts of the next frame to what this one needed
-    if (c->kind != kFrameClusterOnly && !hs->passthrough && hs->n_valid) c->npass_voxel = passes_for(hs->plan_voxel.key_bits, c->radix_bits_target);
+    if (c->kind != kFrameClusterOnly && !hs->passthrough && hs->n_valid) c->npass_voxel = passes_for(c, hs->plan_voxel.key_bits);
     const uint32_t m = hs->m;
     const bool clustered = c->kind != kFrameVoxelOnly;
     uint32_t k = 0;
     if (clustered && !c->result_trivial) {
         k = hs->n_kept;
-        c->npass_csr = passes_for(hs->plan_csr.key_bits, c->radix_bits_target);
+        c->npass_csr = passes_for(c, hs->plan_csr.key_bits);
     }
     // extract(): std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters)
     if (clustered && c->result_trivial) {
@@ -460,6 +469,7 @@ int pcop_create(pcop_ctx** out, int device_id, size_t max_points) {
         const int b = atoi(e);
         if (b >= 4 && b <= kMaxBits) c->radix_bits_target = b;
     }
+    c->maxbits = c->radix_bits_target <= kNarrowBits ? kNarrowBits : kMaxBits;
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     int rc = PCOP_OK;
     const size_t nbk = bucket_of(c, (uint32_t)max_points);           // launch sizes round up to this

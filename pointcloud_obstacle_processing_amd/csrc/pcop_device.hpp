@@ -35,11 +35,12 @@ namespace pcop {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kMaxBits = 11;                     // widest radix digit
+constexpr int kMaxBits = 11;                     // widest radix digit any kernel variant supports
 constexpr int kMaxBins = (1 << kMaxBits) + 1;    // + 1 trash bin (non-finite points)
+constexpr int kNarrowBits = 8;                   // digit limit of the small-LDS kernel variants
 constexpr int kItems = 8;                        // records per thread in the partition kernels
 constexpr int kTile = kBlock * kItems;           // records per partition block
-constexpr int kMaxPasses = 3;                    // 3 x 11 bits >= 32-bit keys
+constexpr int kMaxPasses = 4;                    // 4 x 8 bits = 3 x 11 bits >= 32-bit keys
 constexpr int kScanItems = 4;                    // elements per thread in flag-scan kernels
 constexpr int kScanTile = kBlock * kScanItems;
 constexpr int kReduceBlocks = 256;               // grid of the min/max kernel: one block per CU, short ticket queue
@@ -102,6 +103,7 @@ struct DevState {
     RadixPlan plan_csr;
     uint32_t pad[2];
 };
+static_assert(sizeof(DevState) % 8 == 0, "DevState layout");
 
 // ------------------------------------------------------------------------------------------
 // small helpers
@@ -196,7 +198,7 @@ __device__ __forceinline__ uint32_t bits_for(uint64_t count) {   // bits to inde
 
 // Spread key_bits over the `npass` radix passes the host launched.  Returns false when a
 // digit would be wider than kMaxBits (the host then re-runs the frame with more passes).
-__device__ __forceinline__ bool make_plan(RadixPlan* pl, uint32_t key_bits, uint32_t npass) {
+__device__ __forceinline__ bool make_plan(RadixPlan* pl, uint32_t key_bits, uint32_t npass, uint32_t maxbits) {
     pl->key_bits = key_bits;
     pl->npass = npass;
     const uint32_t each = (key_bits + npass - 1) / npass;
@@ -207,7 +209,7 @@ __device__ __forceinline__ bool make_plan(RadixPlan* pl, uint32_t key_bits, uint
         pl->bits[i] = b; pl->shift[i] = sh;
         sh += b;
     }
-    return each <= (uint32_t)kMaxBits;
+    return each <= maxbits;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -294,12 +296,12 @@ struct MinMaxPartial {
 };
 
 // VoxelGrid::applyFilter up to "divb_mul_ = ..." (SURVEY.md §8a-1 steps 1-4).
-__device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p, uint32_t npass) {
+__device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p, uint32_t npass, uint32_t maxbits) {
     if (st->is_dense && p.nonfinite) { atomicOr(&st->err, (uint32_t)kErrNonFinite); return; }
     st->n_valid = p.valid;
     for (int a = 0; a < 3; ++a) { st->vmin[a] = p.mn[a]; st->vmax[a] = p.mx[a]; }
     for (int a = 0; a < 3; ++a) { st->min_b[a] = 0; st->div_b[a] = 1; st->mul[a] = 1; }
-    make_plan(&st->plan_voxel, 1, npass);
+    make_plan(&st->plan_voxel, 1, npass, maxbits);
     if (p.valid == 0) return;   // empty cloud -> empty output
     const float inv = st->inv_leaf;
     // dx = (int64)((max - min) * inv) + 1; overflow rule: dx*dy*dz > INT32_MAX -> output = input
@@ -326,7 +328,7 @@ __device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p
     st->mul[0] = 1u; st->mul[1] = (uint32_t)div[0]; st->mul[2] = (uint32_t)div[0] * (uint32_t)div[1];
     const uint64_t cells = (uint64_t)(uint32_t)div[0] * (uint32_t)div[1] * (uint32_t)div[2];
     const uint32_t kb = cells > 0xFFFFFFFFull ? 32u : bits_for(cells);
-    if (!make_plan(&st->plan_voxel, kb, npass)) atomicOr(&st->err, (uint32_t)kErrReplanVoxel);
+    if (!make_plan(&st->plan_voxel, kb, npass, maxbits)) atomicOr(&st->err, (uint32_t)kErrReplanVoxel);
 }
 
 __device__ __forceinline__ void reduce_partials_lds(MinMaxPartial* s_p) {   // kBlock entries -> s_p[0]
@@ -343,7 +345,8 @@ __device__ __forceinline__ void reduce_partials_lds(MinMaxPartial* s_p) {   // k
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(DevState* st, MinMaxPartial* partials, uint32_t npass) {
+__global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(DevState* st, MinMaxPartial* partials, uint32_t npass,
+                                                               uint32_t maxbits) {
     __shared__ MinMaxPartial s_p[kBlock];
     __shared__ uint32_t s_last;
     if (st->kind == kFrameClusterOnly) return;
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(DevState* st, Min
     __syncthreads();
     s_p[threadIdx.x] = q;
     reduce_partials_lds(s_p);
-    if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass);
+    if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass, maxbits);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -422,10 +425,10 @@ __device__ __forceinline__ PassInfo pass_info(const DevState* st, int pass) {
     return pi;
 }
 
-template <class Src>
+template <class Src, int MAXB>
 __global__ __launch_bounds__(kBlock) void k_radix_hist(Src src, const DevState* st, int pass,
                                                        uint32_t* __restrict__ table) {
-    __shared__ uint32_t s_h[kMaxBins];
+    __shared__ uint32_t s_h[(1 << MAXB) + 1];
     if (voxel_stage_off(st)) return;
     const PassInfo pi = pass_info(st, pass);
     const uint32_t tile_base = blockIdx.x * kTile;
@@ -492,9 +495,10 @@ __global__ __launch_bounds__(kBlock) void k_table_scan(const DevState* st, int w
 }
 
 // Exclusive scan of bin_total[0..nb) into LDS s_base[0..nb); every thread of the block calls.
+template <int MAXB>
 __device__ __forceinline__ void scan_bins_to_lds(const uint32_t* __restrict__ bin_total, uint32_t nb,
                                                  uint32_t* s_base, uint32_t* s_w) {
-    constexpr int kPer = (kMaxBins + kBlock - 1) / kBlock;   // 9
+    constexpr int kPer = ((1 << MAXB) + 1 + kBlock - 1) / kBlock;   // 9 for 11 bits, 2 for 8
     uint32_t v[kPer];
     uint32_t sum = 0;
     const uint32_t b0 = threadIdx.x * kPer;
@@ -526,13 +530,13 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint32_t nbits, bool
     return m;
 }
 
-template <class Src>
+template <class Src, int MAXB>
 __global__ __launch_bounds__(kBlock) void k_radix_scatter(Src src, const DevState* st, int pass,
                                                           const uint32_t* __restrict__ table_x,
                                                           const uint32_t* __restrict__ bin_total,
                                                           float4* __restrict__ out) {
-    __shared__ uint32_t s_hist[kWavesPerBlock * kMaxBins];
-    __shared__ uint32_t s_base[kMaxBins];
+    __shared__ uint32_t s_hist[kWavesPerBlock * ((1 << MAXB) + 1)];
+    __shared__ uint32_t s_base[(1 << MAXB) + 1];
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     if (voxel_stage_off(st)) return;
     const PassInfo pi = pass_info(st, pass);
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(Src src, const DevStat
     VoxelKey key; key.init(st);
     const uint32_t nb = pi.nb;
     for (uint32_t b = threadIdx.x; b < kWavesPerBlock * nb; b += kBlock) s_hist[b] = 0;
-    scan_bins_to_lds(bin_total, nb, s_base, s_w);   // ends with a barrier
+    scan_bins_to_lds<MAXB>(bin_total, nb, s_base, s_w);   // ends with a barrier
 
     // phase 1: each wave walks its contiguous sub-tile in order; ranks are stable by construction
     const uint32_t w = threadIdx.x / kWave;
@@ -1170,12 +1174,12 @@ __global__ __launch_bounds__(kBlock) void k_kept_apply(DevState* st, const uint3
                                                        const uint32_t* __restrict__ hmin, const uint32_t* __restrict__ comp_size,
                                                        const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_pts,
                                                        uint32_t* __restrict__ comp_rank, uint32_t* __restrict__ offsets_out,
-                                                       uint32_t npass_csr) {
+                                                       uint32_t npass_csr, uint32_t maxbits) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     if (cluster_stage_off(st)) return;
     const uint32_t n = st->c_n;
     if (n == 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_kept = 0; st->n_kept_pts = 0; offsets_out[0] = 0; make_plan(&st->plan_csr, 1, npass_csr); }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_kept = 0; st->n_kept_pts = 0; offsets_out[0] = 0; make_plan(&st->plan_csr, 1, npass_csr, maxbits); }
         return;
     }
     const uint32_t base = blockIdx.x * kScanTile;
@@ -1205,7 +1209,7 @@ __global__ __launch_bounds__(kBlock) void k_kept_apply(DevState* st, const uint3
         st->n_kept = nk; st->n_kept_pts = np;
         offsets_out[nk] = np;
         // keys of the CSR partition are 0..n_kept (n_kept = "not in a kept cluster")
-        if (!make_plan(&st->plan_csr, bits_for((uint64_t)nk + 1), npass_csr)) atomicOr(&st->err, (uint32_t)kErrReplanCsr);
+        if (!make_plan(&st->plan_csr, bits_for((uint64_t)nk + 1), npass_csr, maxbits)) atomicOr(&st->err, (uint32_t)kErrReplanCsr);
     }
 }
 
@@ -1225,10 +1229,11 @@ __device__ __forceinline__ uint32_t point_label(uint32_t p, const uint32_t* __re
     return min(comp_rank[pt_root[p]], trash);
 }
 
+template <int MAXB>
 __global__ __launch_bounds__(kBlock) void k_csr_hist(const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ pt_root,
                                                      const uint32_t* __restrict__ comp_rank, const DevState* st, int pass,
                                                      uint32_t* __restrict__ table) {
-    __shared__ uint32_t s_h[kMaxBins];
+    __shared__ uint32_t s_h[(1 << MAXB) + 1];
     uint32_t count, bits, shift;
     if (!csr_pass_info(st, pass, &count, &bits, &shift)) return;
     const uint32_t tile_base = blockIdx.x * kTile;
@@ -1251,12 +1256,13 @@ __global__ __launch_bounds__(kBlock) void k_csr_hist(const uint32_t* __restrict_
     for (uint32_t b = threadIdx.x; b < nb; b += kBlock) row[b] = s_h[b];
 }
 
+template <int MAXB>
 __global__ __launch_bounds__(kBlock) void k_csr_scatter(const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ pt_root,
                                                         const uint32_t* __restrict__ comp_rank, const DevState* st, int pass,
                                                         const uint32_t* __restrict__ table_x,
                                                         const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ idx_out) {
-    __shared__ uint32_t s_hist[kWavesPerBlock * kMaxBins];
-    __shared__ uint32_t s_base[kMaxBins];
+    __shared__ uint32_t s_hist[kWavesPerBlock * ((1 << MAXB) + 1)];
+    __shared__ uint32_t s_base[(1 << MAXB) + 1];
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     uint32_t count, bits, shift;
     if (!csr_pass_info(st, pass, &count, &bits, &shift)) return;
@@ -1264,7 +1270,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_scatter(const uint32_t* __restri
     if (tile_base >= count) return;
     const uint32_t nb = (1u << bits) + 1u, trash = st->n_kept;
     for (uint32_t b = threadIdx.x; b < kWavesPerBlock * nb; b += kBlock) s_hist[b] = 0;
-    scan_bins_to_lds(bin_total, nb, s_base, s_w);
+    scan_bins_to_lds<MAXB>(bin_total, nb, s_base, s_w);
     const uint32_t w = threadIdx.x / kWave;
     uint32_t* hist_w = s_hist + w * nb;
     const uint32_t mask = (1u << bits) - 1u;
