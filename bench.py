@@ -5,7 +5,8 @@ Metric (BASELINE.json): frames/s at a 1M-point cloud.  Workload: config C3 — 1
 80 % ground plane + 20 % on 20 hovering boxes on a 4.5 m field, leaf 0.02 m, tolerance 0.1 m,
 cluster size 5..20000.  One "step" = one batch of F frames (distinct seeded
 clouds, already resident in HBM as XYZ SoA planes) pushed through the whole chain, F contexts in
-flight per GPU; cluster indices are copied back to pinned host memory inside the timed region.
+flight per GPU (contexts x batch: the frames of a batch share their kernel launches); cluster
+indices are written back to pinned host memory inside the timed region.
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), frames sharded by rank,
 the 32-byte pcop_params struct broadcast from rank 0, no data-path collective ("weak" scaling).
@@ -66,7 +67,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-in-flight", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=8, help="frames per context, processed in the same launches")
+    ap.add_argument("--contexts", type=int, default=2, help="contexts (streams) in flight per GPU")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
@@ -96,23 +98,24 @@ def main():
         params = sharding.broadcast_params(params if rank == 0 else None, src=0, device=torch.device("cuda", local_rank))
 
     # ---- frames: F per rank, seeds sharded by rank --------------------------------------------------
-    F = args.frames_in_flight
+    B, NC = args.batch, args.contexts
+    F = B * NC
     n_pts = synth.CONFIGS[args.config]["n"]
     seeds = sharding.frame_seeds(base_seed=3000, frames_per_rank=F, rank=rank)
     ctxs, ptrs = [], []
-    for s in seeds:
-        c = capi.Context(n_pts, device=local_rank)
+    for ci in range(NC):
+        c = capi.Context(n_pts, device=local_rank, max_frames=B)
         c.set_params_struct(params)
-        ptr, n = c.upload_soa(synth.make_cloud(args.config, seed=s))
+        mine = [c.upload_soa(synth.make_cloud(args.config, seed=s)) for s in seeds[ci * B:(ci + 1) * B]]
         ctxs.append(c)
-        ptrs.append((ptr, n))
+        ptrs.append(([p for p, _ in mine], [n for _, n in mine]))
 
     def step():
-        for c, (ptr, n) in zip(ctxs, ptrs):
-            c.submit_device(ptr, n)
+        for c, (pp, nn) in zip(ctxs, ptrs):
+            c.submit_batch_device(pp, nn)
         out = None
         for c in ctxs:
-            out = c.wait(want_arrays=False)
+            out = c.wait_batch(want_arrays=False)[-1]
         return out
 
     def fence():
@@ -139,7 +142,7 @@ def main():
     result = None
     if rank == 0:
         # ---- single-frame latency (one context, nothing else on the GPU) -----------------------------
-        c0, (ptr0, n0) = ctxs[0], ptrs[0]
+        c0, ptr0, n0 = ctxs[0], ptrs[0][0][0], ptrs[0][1][0]
         lat = []
         for _ in range(20):
             t1 = time.perf_counter()
@@ -189,7 +192,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-pt ground-plane + 20 boxes (L=4.5 m), leaf %g m, tol %g m, clusters %d..%d"
                        % (args.config, n0, p["leaf"], p["tol"], p["min_cluster"], p["max_cluster"]),
-                       "frames_in_flight_per_gpu": F, "frames_per_step": F * world, "voxels_per_frame": int(m_vox),
+                       "frames_in_flight_per_gpu": F, "batch_per_launch": B, "contexts_per_gpu": NC,
+                       "frames_per_step": F * world, "voxels_per_frame": int(m_vox),
                        "input": "XYZ SoA resident in HBM", "parallelism": "frame-sharded, %d rank(s)" % world},
             "latency_ms_single_frame": lat_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "launches_per_frame": len(dom_launches),

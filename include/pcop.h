@@ -93,6 +93,9 @@ typedef struct pcop_ctx pcop_ctx;
 /* device_id >= 0 selects a HIP device; anything else is PCOP_ERR_NO_DEVICE.
  * max_points bounds n (and m) of every later call on this context. */
 int  pcop_create(pcop_ctx** ctx, int device_id, size_t max_points);
+/* Same, with room for max_frames frames that are processed together (pcop_submit_batch). */
+int  pcop_create_batch(pcop_ctx** ctx, int device_id, size_t max_points, int max_frames);
+int  pcop_max_frames(const pcop_ctx* ctx);
 void pcop_destroy(pcop_ctx* ctx);
 int  pcop_set_params(pcop_ctx* ctx, const pcop_params* p);
 int  pcop_get_params(const pcop_ctx* ctx, pcop_params* p);
@@ -136,10 +139,18 @@ int pcop_process_xyz(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int 
 int pcop_submit_xyz(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int is_dense, int mem);
 int pcop_wait(pcop_ctx* ctx, pcop_result* out);
 
+/* Batched form for throughput: nframes independent clouds (xyz[f], n[f]) go through the chain in
+ * the same kernel launches (frames are independent: od.cpp:699-797 keeps no cross-frame state).
+ * pcop_wait_batch fills out[0..nframes).  Results per frame are those of pcop_process_xyz. */
+int pcop_submit_batch(pcop_ctx* ctx, const float* const* xyz, int layout, const size_t* n, int nframes,
+                      int is_dense, int mem);
+int pcop_wait_batch(pcop_ctx* ctx, pcop_result* out, int nframes);
+
 /* PointWithRad[] of the `centroids` topic (msg/PointWithRad.msg:1-4,
  * msg/PointIndicesArray.msg:1) for the last frame / last cluster call:
  * xyzr[4*c..] = centre x,y,z and radius r of cluster c (definition: DESIGN.md). */
 int pcop_cluster_summaries(pcop_ctx* ctx, float* xyzr, int32_t cap_clusters);
+int pcop_cluster_summaries_frame(pcop_ctx* ctx, int frame, float* xyzr, int32_t cap_clusters);
 
 /* Device-side allocation helpers so a host program without its own HIP code
  * (e.g. a ctypes caller) can keep clouds resident in HBM. */

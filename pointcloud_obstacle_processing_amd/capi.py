@@ -20,7 +20,8 @@ EXPORTS = [
     "pcop_set_profiling", "pcop_get_stage_times", "pcop_stream", "pcop_voxel_downsample", "pcop_euclidean_clusters",
     "pcop_process_pointcloud2", "pcop_process_xyz", "pcop_submit_xyz", "pcop_wait", "pcop_cluster_summaries",
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
-    "pcop_debug_buffer",
+    "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
+    "pcop_cluster_summaries_frame",
 ]
 
 
@@ -81,6 +82,16 @@ def load_library():
     vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
     L.pcop_create.restype = C.c_int
     L.pcop_create.argtypes = [C.POINTER(vp), C.c_int, C.c_size_t]
+    L.pcop_create_batch.restype = C.c_int
+    L.pcop_create_batch.argtypes = [C.POINTER(vp), C.c_int, C.c_size_t, C.c_int]
+    L.pcop_max_frames.restype = C.c_int
+    L.pcop_max_frames.argtypes = [vp]
+    L.pcop_submit_batch.restype = C.c_int
+    L.pcop_submit_batch.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int]
+    L.pcop_wait_batch.restype = C.c_int
+    L.pcop_wait_batch.argtypes = [vp, C.POINTER(Result), C.c_int]
+    L.pcop_cluster_summaries_frame.restype = C.c_int
+    L.pcop_cluster_summaries_frame.argtypes = [vp, C.c_int, fp, C.c_int32]
     L.pcop_destroy.restype = None
     L.pcop_destroy.argtypes = [vp]
     L.pcop_set_params.restype = C.c_int
@@ -153,10 +164,11 @@ def unpack_points(flat, layout, m, stride):
 class Context:
     """One GPU context (pcop_ctx)."""
 
-    def __init__(self, max_points, device=0, profiling=False):
+    def __init__(self, max_points, device=0, profiling=False, max_frames=1):
         self.lib = load_library()
         self.h = C.c_void_p()
-        rc = self.lib.pcop_create(C.byref(self.h), int(device), int(max_points))
+        self.max_frames = int(max_frames)
+        rc = self.lib.pcop_create_batch(C.byref(self.h), int(device), int(max_points), int(max_frames))
         if rc:
             raise PcopError(rc, self.lib.pcop_status_string(rc).decode())
         self.max_points = int(max_points)
@@ -232,6 +244,37 @@ class Context:
 
     def submit_device(self, dev_ptr, n, is_dense=True, layout=LAYOUT_SOA):
         self._chk(self.lib.pcop_submit_xyz(self.h, C.c_void_p(dev_ptr), layout, int(n), int(is_dense), MEM_DEVICE))
+
+    def submit_batch_device(self, dev_ptrs, ns, is_dense=True, layout=LAYOUT_SOA):
+        """Enqueue len(dev_ptrs) device-resident clouds as one batch."""
+        k = len(dev_ptrs)
+        ptrs = (C.c_void_p * k)(*[C.c_void_p(p) for p in dev_ptrs])
+        cnt = (C.c_size_t * k)(*[int(n) for n in ns])
+        self._chk(self.lib.pcop_submit_batch(self.h, ptrs, layout, cnt, k, int(is_dense), MEM_DEVICE))
+        self._batch = k
+
+    def submit_batch_host(self, clouds, is_dense=True, layout=LAYOUT_AOS12):
+        k = len(clouds)
+        packed = [pack_points(c, layout) for c in clouds]
+        self._keep = packed
+        ptrs = (C.c_void_p * k)(*[C.c_void_p(p[0].ctypes.data) for p in packed])
+        cnt = (C.c_size_t * k)(*[p[1] for p in packed])
+        self._chk(self.lib.pcop_submit_batch(self.h, ptrs, layout, cnt, k, int(is_dense), MEM_HOST))
+        self._batch = k
+
+    def wait_batch(self, want_arrays=True):
+        k = self._batch
+        res = (Result * k)()
+        self._chk(self.lib.pcop_wait_batch(self.h, res, k))
+        if not want_arrays:
+            return [dict(passthrough=bool(r.passthrough), num_voxels=r.num_voxels, num_clusters=r.num_clusters,
+                         num_indices=r.num_indices) for r in res]
+        return [self._result(r) for r in res]
+
+    def cluster_summaries_frame(self, frame, k):
+        out = np.zeros((max(k, 1), 4), dtype=np.float32)
+        self._chk(self.lib.pcop_cluster_summaries_frame(self.h, int(frame), out.ctypes.data_as(C.POINTER(C.c_float)), int(k)))
+        return out[:k]
 
     def wait(self, want_arrays=True):
         r = Result()

@@ -1,11 +1,11 @@
 // pcop_capi.hip — the C ABI of include/pcop.h on top of the gfx950 kernels in pcop_device.hpp.
 //
-// One context = one GPU + one HIP stream + all the frame's buffers.  A frame is a fixed
-// sequence of kernel launches whose data-dependent sizes live in device memory (DevState) and
-// whose per-frame inputs come through a pinned mailbox (FrameArgs), so the launch arguments are
-// constant: the sequence is captured once into a hipGraph and replayed per frame.  The last
-// kernel writes the results straight into pinned host memory; the host syncs once.
-// There is no CPU fallback: without a HIP device pcop_create fails.
+// One context = one GPU + one HIP stream + the buffers of up to `max_frames` frames.  A batch of
+// frames is one fixed sequence of kernel launches (blockIdx.y = frame) whose data-dependent sizes
+// live in device memory (DevState) and whose per-frame inputs come through pinned mailboxes
+// (FrameArgs), so the launch arguments are constant: the sequence is captured once into a
+// hipGraph and replayed per batch.  The last kernel writes the results straight into pinned host
+// memory; the host syncs once.  There is no CPU fallback: without a HIP device pcop_create fails.
 #include "../../include/pcop.h"
 #include "pcop_device.hpp"
 
@@ -31,66 +31,60 @@ struct ClusterRef {
 inline bool compare_clusters(const ClusterRef& a, const ClusterRef& b) { return a.size < b.size; }
 
 struct GraphKey {
-    uint32_t kind, bucket, npass_voxel, npass_csr;
+    uint32_t kind, bucket, npass_voxel, npass_csr, nframes;
     bool operator<(const GraphKey& o) const {
         if (kind != o.kind) return kind < o.kind;
         if (bucket != o.bucket) return bucket < o.bucket;
         if (npass_voxel != o.npass_voxel) return npass_voxel < o.npass_voxel;
-        return npass_csr < o.npass_csr;
+        if (npass_csr != o.npass_csr) return npass_csr < o.npass_csr;
+        return nframes < o.nframes;
     }
 };
 
-}  // namespace
-
-struct pcop_ctx {
-    int device = -1;
-    size_t cap = 0;               // max_points
-    size_t hash_cap = 0;          // slots of the cell hash table
-    hipStream_t stream = nullptr;
-    pcop_params params{};
-    bool params_set = false;
-    std::string err;
-
-    // device buffers
-    float *in_x = nullptr, *in_y = nullptr, *in_z = nullptr;      // staged input cloud (SoA)
-    float *cen_x = nullptr, *cen_y = nullptr, *cen_z = nullptr;   // voxel centroids (SoA)
-    float4 *rec_a = nullptr, *rec_b = nullptr;                    // partition ping-pong / cell-sorted records
-    uint32_t *table = nullptr, *table_x = nullptr, *bin_total = nullptr;
-    uint32_t *tile_a = nullptr, *tile_b = nullptr;                // per-tile counts
-    MinMaxPartial* partials = nullptr;
-    unsigned long long* hkey = nullptr;                           // cell hash table
-    uint32_t *hcount = nullptr, *hmin = nullptr;
-    uint32_t *cell_start = nullptr, *parent = nullptr, *comp_size = nullptr, *comp_rank = nullptr;   // per slot
-    uint32_t* cell_list = nullptr;   // occupied slots, dense
-    uint32_t *pt_slot = nullptr, *pt_rank = nullptr, *pt_root = nullptr;                            // per point
-    uint32_t *idx_a = nullptr, *idx_b = nullptr, *d_offsets = nullptr;
-    float4* d_xyzr = nullptr;
+// host-side view of one frame slot
+struct Slot {
+    Frame f{};                    // device pointers of the slot (DevState part unused on the host)
+    float *in_x = nullptr, *in_y = nullptr, *in_z = nullptr;   // staged input cloud (SoA)
     uint8_t* d_raw = nullptr;     // raw input bytes (AoS / PointCloud2), grown on demand
     size_t d_raw_bytes = 0;
-    DevState* d_state = nullptr;
-    std::vector<void*> user_allocs;
-
-    // pinned host buffers
-    FrameArgs* h_args = nullptr;  // mailbox read by k_frame_init
+    FrameArgs* h_args = nullptr;  // pinned mailbox
     DevState* h_state = nullptr;
     int32_t *h_offsets_disc = nullptr, *h_indices_disc = nullptr;   // discovery order, as the GPU wrote them
     int32_t *h_offsets = nullptr, *h_indices = nullptr;             // PCL order
     float* h_vox = nullptr;
     float* h_xyzr = nullptr;
     std::vector<int32_t> order;   // order[c] = discovery id of output cluster c
-
-    // current frame
-    const float *src_x = nullptr, *src_y = nullptr, *src_z = nullptr;   // device planes the frame reads
+    const float *src_x = nullptr, *src_y = nullptr, *src_z = nullptr;
     uint32_t n = 0;
+    bool result_trivial = false;
+    bool have_result = false;
+};
+
+}  // namespace
+
+struct pcop_ctx {
+    int device = -1;
+    size_t cap = 0;               // max_points per frame
+    size_t hash_cap = 0;          // slots of a frame's cell hash table
+    uint32_t max_frames = 1;
+    hipStream_t stream = nullptr;
+    pcop_params params{};
+    bool params_set = false;
+    std::string err;
+
+    std::vector<Slot> slots;
+    Frame* d_frames = nullptr;    // device array [max_frames]
+    std::vector<void*> dev_allocs, host_allocs, user_allocs;
+
+    // current batch
+    uint32_t nframes = 0;
     int is_dense = 1;
     uint32_t kind = kFrameChain;
     int out_layout = PCOP_LAYOUT_AOS12;
     bool emit_cloud = false;
     bool in_flight = false;
-    bool have_result = false;
-    bool result_trivial = false;  // r2 == 0: every point is its own component (built on the host)
     uint32_t npass_voxel = kMaxPasses, npass_csr = kMaxPasses;
-    uint32_t* frame_csr_idx = nullptr;   // device CSR indices of the frame in flight / last frame
+    uint32_t frame_npass_csr = kMaxPasses;   // npass_csr of the batch in flight / last batch
     int radix_bits_target = 8;    // preferred digit width when choosing pass counts
     int maxbits = kNarrowBits;    // digit limit of the kernel variant in use (8: small LDS, 11: wide)
     bool use_graph = true;
@@ -120,11 +114,13 @@ namespace {
 template <class T>
 int dev_alloc(pcop_ctx* c, T** p, size_t count) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)));
+    c->dev_allocs.push_back(*p);
     return PCOP_OK;
 }
 template <class T>
 int host_alloc(pcop_ctx* c, T** p, size_t count) {
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+    c->host_allocs.push_back(*p);
     return PCOP_OK;
 }
 
@@ -158,125 +154,111 @@ uint32_t hash_cap_for(uint32_t n) {
     return cap;
 }
 
-CellTable cell_table(pcop_ctx* c) { return CellTable{c->hkey, c->hcount, c->hmin}; }
-
+// The launch sequence of one batch.  nb = launch-size bucket (>= every frame's point count), nf =
+// frames; all real counts are read on the device.  Everything here is capturable into a hipGraph.
 template <int MAXB>
-void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb) {
+void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
     hipStream_t s = c->stream;
+    Frame* fr = c->d_frames;
     constexpr uint32_t kBinsGrid = (1u << MAXB) + 1u;
-    k_frame_init<<<1, 64, 0, s>>>(c->d_state, c->h_args);
+    k_frame_init<<<dim3(1, nf), 64, 0, s>>>(fr);
     mark(c, "k_frame_init");
-    const uint32_t pg = std::max(1u, div_up(nb, kTile));        // partition tiles
-    const uint32_t sg = std::max(1u, div_up(nb, kScanTile));    // scan tiles over points
-    const uint32_t tg = stride_grid(nb);
+    const dim3 pg(std::max(1u, div_up(nb, kTile)), nf);        // partition tiles
+    const dim3 sg(std::max(1u, div_up(nb, kScanTile)), nf);    // scan tiles over points
+    const dim3 tg(stride_grid(nb), nf);
     if (kind != kFrameClusterOnly) {
-        k_minmax_voxel_setup<<<kReduceBlocks, kBlock, 0, s>>>(c->d_state, c->partials, c->npass_voxel, (uint32_t)MAXB);
+        k_minmax_voxel_setup<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, c->npass_voxel, (uint32_t)MAXB);
         mark(c, "k_minmax_voxel_setup");
-        float4* bufs[2] = {c->rec_a, c->rec_b};
-        float4* sorted = nullptr;
         for (uint32_t p = 0; p < c->npass_voxel; ++p) {
-            sorted = bufs[p & 1];
-            if (p == 0) {
-                k_radix_hist<SoaSrc, MAXB><<<pg, kBlock, 0, s>>>(SoaSrc{}, c->d_state, (int)p, c->table);
-                mark(c, "k_radix_hist");
-                k_table_scan<<<kBinsGrid, kBlock, 0, s>>>(c->d_state, 0, (int)p, c->table, c->table_x, c->bin_total);
-                mark(c, "k_table_scan");
-                k_radix_scatter<SoaSrc, MAXB><<<pg, kBlock, 0, s>>>(SoaSrc{}, c->d_state, (int)p, c->table_x, c->bin_total, sorted);
-                mark(c, "k_radix_scatter");
-            } else {
-                RecSrc r{bufs[(p - 1) & 1]};
-                k_radix_hist<RecSrc, MAXB><<<pg, kBlock, 0, s>>>(r, c->d_state, (int)p, c->table);
-                mark(c, "k_radix_hist");
-                k_table_scan<<<kBinsGrid, kBlock, 0, s>>>(c->d_state, 0, (int)p, c->table, c->table_x, c->bin_total);
-                mark(c, "k_table_scan");
-                k_radix_scatter<RecSrc, MAXB><<<pg, kBlock, 0, s>>>(r, c->d_state, (int)p, c->table_x, c->bin_total, sorted);
-                mark(c, "k_radix_scatter");
-            }
+            k_radix_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
+            mark(c, "k_radix_hist");
+            k_table_scan<<<dim3(kBinsGrid, nf), kBlock, 0, s>>>(fr, 0, (int)p);
+            mark(c, "k_table_scan");
+            k_radix_scatter<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
+            mark(c, "k_radix_scatter");
         }
-        k_heads_count<<<sg, kBlock, 0, s>>>(sorted, c->d_state, c->tile_a);
+        k_heads_count<<<sg, kBlock, 0, s>>>(fr, c->npass_voxel);
         mark(c, "k_heads_count");
-        k_voxel_reduce<<<sg, kBlock, 0, s>>>(sorted, c->d_state, c->tile_a, c->cen_x, c->cen_y, c->cen_z);
+        k_voxel_reduce<<<sg, kBlock, 0, s>>>(fr, c->npass_voxel);
         mark(c, "k_voxel_reduce");
     }
     if (kind != kFrameVoxelOnly) {
-        const CellTable tab = cell_table(c);
         const uint32_t hcap = hash_cap_for(nb);
-        const uint32_t hg = std::max(1u, hcap / kScanTile);       // scan tiles over hash slots
-        const uint32_t wg = std::min(8192u, std::max(1u, div_up(nb, kWavesPerBlock)));   // one wave per cell, grid-strided
-        k_cell_insert<<<tg, kBlock, 0, s>>>(c->d_state, c->cen_x, c->cen_y, c->cen_z, tab, c->pt_slot, c->pt_rank);
+        const dim3 hg(std::max(1u, hcap / kScanTile), nf);       // scan tiles over hash slots
+        const dim3 wg(std::min(8192u, std::max(1u, div_up(nb, kWavesPerBlock))), nf);   // one wave per cell, grid-strided
+        k_cell_insert<<<tg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_insert");
-        k_slot_count<<<hg, kBlock, 0, s>>>(c->d_state, c->hcount, c->tile_a, c->tile_b);
+        k_slot_count<<<hg, kBlock, 0, s>>>(fr);
         mark(c, "k_slot_count");
-        k_slot_apply<<<hg, kBlock, 0, s>>>(c->d_state, c->hcount, c->tile_a, c->tile_b, c->cell_start, c->cell_list, c->parent,
-                                           c->comp_size, c->comp_rank);
+        k_slot_apply<<<hg, kBlock, 0, s>>>(fr);
         mark(c, "k_slot_apply");
-        k_cell_place<<<tg, kBlock, 0, s>>>(c->d_state, c->cen_x, c->cen_y, c->cen_z, c->pt_slot, c->pt_rank, c->cell_start, c->rec_a);
+        k_cell_place<<<tg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_place");
-        k_cell_hook<<<wg, kBlock, 0, s>>>(c->rec_a, c->d_state, tab, c->cell_start, c->cell_list, c->parent);
+        k_cell_hook<<<wg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_hook");
-        k_cell_compress<<<tg, kBlock, 0, s>>>(c->d_state, c->cell_list, c->parent);
+        k_cell_compress<<<tg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_compress");
-        k_cell_union<<<wg, kBlock, 0, s>>>(c->rec_a, c->d_state, tab, c->cell_start, c->cell_list, c->parent);
+        k_cell_union<<<wg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_union");
-        k_cell_flatten<<<64, kBlock, 0, s>>>(c->d_state, c->pt_slot, c->parent, c->pt_root, c->comp_size);
+        k_cell_flatten<<<dim3(64, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_flatten");
-        k_kept_count<<<sg, kBlock, 0, s>>>(c->d_state, c->pt_root, c->hmin, c->comp_size, c->tile_a, c->tile_b);
+        k_kept_count<<<sg, kBlock, 0, s>>>(fr);
         mark(c, "k_kept_count");
-        k_kept_apply<<<sg, kBlock, 0, s>>>(c->d_state, c->pt_root, c->hmin, c->comp_size, c->tile_a, c->tile_b, c->comp_rank,
-                                           c->d_offsets, c->npass_csr, (uint32_t)MAXB);
+        k_kept_apply<<<sg, kBlock, 0, s>>>(fr, c->npass_csr, (uint32_t)MAXB);
         mark(c, "k_kept_apply");
-        uint32_t* bufs[2] = {c->idx_a, c->idx_b};
         for (uint32_t p = 0; p < c->npass_csr; ++p) {
-            const uint32_t* in = p == 0 ? nullptr : bufs[(p - 1) & 1];
-            k_csr_hist<MAXB><<<pg, kBlock, 0, s>>>(in, c->pt_root, c->comp_rank, c->d_state, (int)p, c->table);
+            k_csr_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
             mark(c, "k_csr_hist");
-            k_table_scan<<<kBinsGrid, kBlock, 0, s>>>(c->d_state, 2, (int)p, c->table, c->table_x, c->bin_total);
+            k_table_scan<<<dim3(kBinsGrid, nf), kBlock, 0, s>>>(fr, 2, (int)p);
             mark(c, "k_table_scan");
-            k_csr_scatter<MAXB><<<pg, kBlock, 0, s>>>(in, c->pt_root, c->comp_rank, c->d_state, (int)p, c->table_x, c->bin_total, bufs[p & 1]);
+            k_csr_scatter<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
             mark(c, "k_csr_scatter");
         }
     }
-    uint32_t* csr = ((c->npass_csr - 1) & 1) ? c->idx_b : c->idx_a;
-    HostOut ho{c->h_state, reinterpret_cast<uint32_t*>(c->h_offsets_disc), reinterpret_cast<uint32_t*>(c->h_indices_disc), c->h_vox};
-    k_emit<<<tg, kBlock, 0, s>>>(c->d_state, ho, c->d_offsets, csr, c->cen_x, c->cen_y, c->cen_z, cell_table(c));
+    k_emit<<<tg, kBlock, 0, s>>>(fr, c->npass_csr);
     mark(c, "k_emit");
 }
 
-// The launch sequence of one frame.  nb = launch-size bucket (>= the frame's point count); all
-// real counts are read on the device.  Everything here is capturable into a hipGraph.
-void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb) {
-    if (c->maxbits <= kNarrowBits) enqueue_launches_t<kNarrowBits>(c, kind, nb);
-    else enqueue_launches_t<kMaxBits>(c, kind, nb);
+void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
+    if (c->maxbits <= kNarrowBits) enqueue_launches_t<kNarrowBits>(c, kind, nb, nf);
+    else enqueue_launches_t<kMaxBits>(c, kind, nb, nf);
 }
 
-int enqueue_frame(pcop_ctx* c) {
+int enqueue_batch(pcop_ctx* c) {
     const pcop_params& p = c->params;
     const float inv_leaf = 1.0f / p.leaf;                         // Array4f::Ones() / leaf_size_
     const double radius = (double)p.tol;
     const float r2 = (float)(radius * radius);                    // KdTreeFLANN::radiusSearch
-    c->result_trivial = c->kind != kFrameVoxelOnly && !(r2 > 0.0f);
-    FrameArgs& a = *c->h_args;
-    a.n = c->n; a.is_dense = c->is_dense ? 1u : 0u; a.kind = c->kind; a.trivial = c->result_trivial ? 1u : 0u;
-    a.inv_leaf = inv_leaf; a.r2 = r2;
-    a.inv_cell = c->result_trivial ? 1.0 : 1.99 / std::fabs((double)p.tol);
-    a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
-    a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = c->n; a.pad = 0;
-    a.src_x = c->src_x; a.src_y = c->src_y; a.src_z = c->src_z;
-    c->frame_csr_idx = ((c->npass_csr - 1) & 1) ? c->idx_b : c->idx_a;
-    const uint32_t nb = bucket_of(c, c->n);
+    const bool trivial = c->kind != kFrameVoxelOnly && !(r2 > 0.0f);
+    uint32_t nmax = 0;
+    for (uint32_t f = 0; f < c->nframes; ++f) {
+        Slot& sl = c->slots[f];
+        sl.result_trivial = trivial;
+        sl.have_result = false;
+        FrameArgs& a = *sl.h_args;
+        a.n = sl.n; a.is_dense = c->is_dense ? 1u : 0u; a.kind = c->kind; a.trivial = trivial ? 1u : 0u;
+        a.inv_leaf = inv_leaf; a.r2 = r2;
+        a.inv_cell = trivial ? 1.0 : 1.99 / std::fabs((double)p.tol);
+        a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
+        a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.pad = 0;
+        a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
+        nmax = std::max(nmax, sl.n);
+    }
+    c->frame_npass_csr = c->npass_csr;
+    const uint32_t nb = bucket_of(c, nmax);
     c->ev_used = 0;
     if (c->profiling || !c->use_graph) {
         mark(c, "start");
-        enqueue_launches(c, c->kind, nb);
+        enqueue_launches(c, c->kind, nb, c->nframes);
         HIPCHK(c, hipGetLastError());
     } else {
-        const GraphKey key{c->kind, nb, c->npass_voxel, c->npass_csr};
+        const GraphKey key{c->kind, nb, c->npass_voxel, c->npass_csr, c->nframes};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
             HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_launches(c, c->kind, nb);
+            enqueue_launches(c, c->kind, nb, c->nframes);
             HIPCHK(c, hipStreamEndCapture(c->stream, &g));
             HIPCHK(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             hipGraphDestroy(g);
@@ -285,7 +267,6 @@ int enqueue_frame(pcop_ctx* c) {
         HIPCHK(c, hipGraphLaunch(it->second, c->stream));
     }
     c->in_flight = true;
-    c->have_result = false;
     return PCOP_OK;
 }
 
@@ -309,21 +290,69 @@ void collect_times(pcop_ctx* c) {
     }
 }
 
-// Waits for the frame (re-running it when a radix plan was too short) and puts the clusters in
-// PCL's order.  The kernels have already written everything into pinned host memory.
-int finish_frame(pcop_ctx* c, pcop_result* out) {
+// Cluster order of one finished frame: extract()'s std::sort(clusters.rbegin(), clusters.rend(),
+// comparePointClusters) applied to the discovery-ordered clusters the GPU wrote.
+void order_frame(pcop_ctx* c, Slot& sl, pcop_result* out) {
+    const DevState* hs = sl.h_state;
+    const uint32_t m = hs->m;
+    const bool clustered = c->kind != kFrameVoxelOnly;
+    uint32_t k = 0;
+    if (clustered && !sl.result_trivial) k = hs->n_kept;
+    if (clustered && sl.result_trivial) {
+        // r2 == 0: radiusSearch returns nothing, every point is a cluster of one
+        const pcop_params& p = c->params;
+        const bool keep = (uint32_t)p.min_cluster <= 1u && 1u <= (uint32_t)p.max_cluster;
+        const uint32_t c_n = c->kind == kFrameClusterOnly ? sl.n : m;
+        k = keep ? c_n : 0;
+        for (uint32_t i = 0; i < k; ++i) { sl.h_offsets_disc[i] = (int32_t)i; sl.h_indices_disc[i] = (int32_t)i; }
+        sl.h_offsets_disc[k] = (int32_t)k;
+    }
+    std::vector<ClusterRef> refs(k);
+    for (uint32_t i = 0; i < k; ++i) refs[i] = {sl.h_offsets_disc[i + 1] - sl.h_offsets_disc[i], (int32_t)i};
+    std::sort(refs.rbegin(), refs.rend(), compare_clusters);
+    sl.order.resize(k);
+    int32_t pos = 0;
+    sl.h_offsets[0] = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        const int32_t id = refs[i].id;
+        sl.order[i] = id;
+        const int32_t b = sl.h_offsets_disc[id], sz = refs[i].size;
+        std::memcpy(sl.h_indices + pos, sl.h_indices_disc + b, (size_t)sz * 4);
+        pos += sz;
+        sl.h_offsets[i + 1] = pos;
+    }
+    sl.have_result = clustered;
+    if (out) {
+        out->passthrough = (int32_t)hs->passthrough;
+        out->num_voxels = (int32_t)m;
+        out->num_clusters = (int32_t)k;
+        out->num_indices = pos;
+        out->offsets = sl.h_offsets;
+        out->indices = sl.h_indices;
+        out->voxel_xyz = (c->emit_cloud && m) ? sl.h_vox : nullptr;
+    }
+}
+
+// Waits for the batch (re-running it when a radix plan was too short) and puts every frame's
+// clusters in PCL's order.  The kernels have already written everything into pinned host memory.
+int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
     if (!c->in_flight) return PCOP_ERR_STATE;
-    DevState* hs = c->h_state;
     for (int attempt = 0;; ++attempt) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        const uint32_t e = hs->err;
+        uint32_t e = 0, kb_voxel = 0, kb_csr = 0;
+        for (uint32_t f = 0; f < c->nframes; ++f) {
+            const DevState* hs = c->slots[f].h_state;
+            e |= hs->err;
+            if (hs->err & kErrReplanVoxel) kb_voxel = std::max(kb_voxel, hs->plan_voxel.key_bits);
+            if (hs->err & kErrReplanCsr) kb_csr = std::max(kb_csr, hs->plan_csr.key_bits);
+        }
         if (e & kErrNonFinite) { c->in_flight = false; c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
         if (e & kErrRange) { c->in_flight = false; c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
         if (e & (kErrReplanVoxel | kErrReplanCsr)) {
             if (attempt >= 4) { c->in_flight = false; c->err = "radix replanning did not converge"; return PCOP_ERR_STATE; }
-            if (e & kErrReplanVoxel) c->npass_voxel = passes_for(c, hs->plan_voxel.key_bits);
-            if (e & kErrReplanCsr) c->npass_csr = passes_for(c, hs->plan_csr.key_bits);
-            int rc = enqueue_frame(c);
+            if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));
+            if (kb_csr) c->npass_csr = std::max(c->npass_csr, passes_for(c, kb_csr));
+            int rc = enqueue_batch(c);
             if (rc) return rc;
             continue;
         }
@@ -331,49 +360,16 @@ int finish_frame(pcop_ctx* c, pcop_result* out) {
     }
     collect_times(c);
     c->in_flight = false;
-    // adapt the pass counts of the next frame to what this one needed
-    if (c->kind != kFrameClusterOnly && !hs->passthrough && hs->n_valid) c->npass_voxel = passes_for(c, hs->plan_voxel.key_bits);
-    const uint32_t m = hs->m;
-    const bool clustered = c->kind != kFrameVoxelOnly;
-    uint32_t k = 0;
-    if (clustered && !c->result_trivial) {
-        k = hs->n_kept;
-        c->npass_csr = passes_for(c, hs->plan_csr.key_bits);
+    // adapt the pass counts of the next batch to what this one needed
+    uint32_t kb_voxel = 0, kb_csr = 0;
+    for (uint32_t f = 0; f < c->nframes; ++f) {
+        const DevState* hs = c->slots[f].h_state;
+        if (c->kind != kFrameClusterOnly && !hs->passthrough && hs->n_valid) kb_voxel = std::max(kb_voxel, hs->plan_voxel.key_bits);
+        if (c->kind != kFrameVoxelOnly && !c->slots[f].result_trivial) kb_csr = std::max(kb_csr, hs->plan_csr.key_bits);
     }
-    // extract(): std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters)
-    if (clustered && c->result_trivial) {
-        // r2 == 0: radiusSearch returns nothing, every point is a cluster of one
-        const pcop_params& p = c->params;
-        const bool keep = (uint32_t)p.min_cluster <= 1u && 1u <= (uint32_t)p.max_cluster;
-        const uint32_t c_n = c->kind == kFrameClusterOnly ? c->n : m;
-        k = keep ? c_n : 0;
-        for (uint32_t i = 0; i < k; ++i) { c->h_offsets_disc[i] = (int32_t)i; c->h_indices_disc[i] = (int32_t)i; }
-        c->h_offsets_disc[k] = (int32_t)k;
-    }
-    std::vector<ClusterRef> refs(k);
-    for (uint32_t i = 0; i < k; ++i) refs[i] = {c->h_offsets_disc[i + 1] - c->h_offsets_disc[i], (int32_t)i};
-    std::sort(refs.rbegin(), refs.rend(), compare_clusters);
-    c->order.resize(k);
-    int32_t pos = 0;
-    c->h_offsets[0] = 0;
-    for (uint32_t i = 0; i < k; ++i) {
-        const int32_t id = refs[i].id;
-        c->order[i] = id;
-        const int32_t b = c->h_offsets_disc[id], sz = refs[i].size;
-        std::memcpy(c->h_indices + pos, c->h_indices_disc + b, (size_t)sz * 4);
-        pos += sz;
-        c->h_offsets[i + 1] = pos;
-    }
-    c->have_result = clustered;
-    if (out) {
-        out->passthrough = (int32_t)hs->passthrough;
-        out->num_voxels = (int32_t)m;
-        out->num_clusters = (int32_t)k;
-        out->num_indices = pos;
-        out->offsets = c->h_offsets;
-        out->indices = c->h_indices;
-        out->voxel_xyz = (c->emit_cloud && m) ? c->h_vox : nullptr;
-    }
+    if (kb_voxel) c->npass_voxel = passes_for(c, kb_voxel);
+    if (kb_csr) c->npass_csr = passes_for(c, kb_csr);
+    for (uint32_t f = 0; f < c->nframes; ++f) order_frame(c, c->slots[f], (out && f < nout) ? out + f : nullptr);
     return PCOP_OK;
 }
 
@@ -385,41 +381,41 @@ int check_params(pcop_ctx* c, bool need_leaf, bool need_tol) {
     return PCOP_OK;
 }
 
-int ensure_raw(pcop_ctx* c, size_t bytes) {
-    if (bytes <= c->d_raw_bytes) return PCOP_OK;
-    if (c->d_raw) { HIPCHK(c, hipFree(c->d_raw)); c->d_raw = nullptr; c->d_raw_bytes = 0; }
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_raw), bytes));
-    c->d_raw_bytes = bytes;
+int ensure_raw(pcop_ctx* c, Slot& sl, size_t bytes) {
+    if (bytes <= sl.d_raw_bytes) return PCOP_OK;
+    if (sl.d_raw) { HIPCHK(c, hipFree(sl.d_raw)); sl.d_raw = nullptr; sl.d_raw_bytes = 0; }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&sl.d_raw), bytes));
+    sl.d_raw_bytes = bytes;
     return PCOP_OK;
 }
 
 // Put an n-point cloud (host or device, any layout) where the kernels read it: SoA planes in HBM.
-int stage_input(pcop_ctx* c, const float* xyz, int layout, size_t n, int mem) {
+int stage_input(pcop_ctx* c, Slot& sl, const float* xyz, int layout, size_t n, int mem) {
     if (n > c->cap) { c->err = "n exceeds max_points of the context"; return PCOP_ERR_CAPACITY; }
     if (!xyz && n) return PCOP_ERR_ARG;
     if (layout != PCOP_LAYOUT_AOS16 && layout != PCOP_LAYOUT_SOA && layout != PCOP_LAYOUT_AOS12) return PCOP_ERR_ARG;
-    c->n = (uint32_t)n;
+    sl.n = (uint32_t)n;
     if (mem == PCOP_MEM_DEVICE && layout == PCOP_LAYOUT_SOA) {   // read the caller's planes in place
-        c->src_x = xyz; c->src_y = xyz + n; c->src_z = xyz + 2 * n;
+        sl.src_x = xyz; sl.src_y = xyz + n; sl.src_z = xyz + 2 * n;
         return PCOP_OK;
     }
-    c->src_x = c->in_x; c->src_y = c->in_y; c->src_z = c->in_z;
+    sl.src_x = sl.in_x; sl.src_y = sl.in_y; sl.src_z = sl.in_z;
     if (n == 0) return PCOP_OK;
     if (layout == PCOP_LAYOUT_SOA) {   // host planes
-        HIPCHK(c, hipMemcpyAsync(c->in_x, xyz, n * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->in_y, xyz + n, n * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->in_z, xyz + 2 * n, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(sl.in_x, xyz, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(sl.in_y, xyz + n, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(sl.in_z, xyz + 2 * n, n * 4, hipMemcpyHostToDevice, c->stream));
         return PCOP_OK;
     }
     const uint32_t step = layout == PCOP_LAYOUT_AOS16 ? 16u : 12u;
     const uint8_t* raw = reinterpret_cast<const uint8_t*>(xyz);
     if (mem == PCOP_MEM_HOST) {
-        int rc = ensure_raw(c, n * step);
+        int rc = ensure_raw(c, sl, n * step);
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->d_raw, xyz, n * step, hipMemcpyHostToDevice, c->stream));
-        raw = c->d_raw;
+        HIPCHK(c, hipMemcpyAsync(sl.d_raw, xyz, n * step, hipMemcpyHostToDevice, c->stream));
+        raw = sl.d_raw;
     }
-    k_unpack_points<<<stride_grid((uint32_t)n), kBlock, 0, c->stream>>>(raw, (uint32_t)n, step, 0, 4, 8, 0, c->in_x, c->in_y, c->in_z);
+    k_unpack_points<<<stride_grid((uint32_t)n), kBlock, 0, c->stream>>>(raw, (uint32_t)n, step, 0, 4, 8, 0, sl.in_x, sl.in_y, sl.in_z);
     HIPCHK(c, hipGetLastError());
     return PCOP_OK;
 }
@@ -427,6 +423,53 @@ int stage_input(pcop_ctx* c, const float* xyz, int layout, size_t n, int mem) {
 int set_device(pcop_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     return PCOP_OK;
+}
+
+int busy(pcop_ctx* c) {
+    if (c->in_flight) { c->err = "a batch is already in flight on this context"; return PCOP_ERR_STATE; }
+    return PCOP_OK;
+}
+
+int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size_t nscan) {
+    int rc;
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    Frame& f = sl.f;
+    TRY(dev_alloc(c, &sl.in_x, n)); TRY(dev_alloc(c, &sl.in_y, n)); TRY(dev_alloc(c, &sl.in_z, n));
+    TRY(dev_alloc(c, &f.cen_x, n)); TRY(dev_alloc(c, &f.cen_y, n)); TRY(dev_alloc(c, &f.cen_z, n));
+    TRY(dev_alloc(c, &f.rec_a, n)); TRY(dev_alloc(c, &f.rec_b, n));
+    TRY(dev_alloc(c, &f.table, ntiles * kMaxBins)); TRY(dev_alloc(c, &f.table_x, ntiles * kMaxBins));
+    TRY(dev_alloc(c, &f.bin_total, (size_t)kMaxBins));
+    TRY(dev_alloc(c, &f.tile_a, nscan)); TRY(dev_alloc(c, &f.tile_b, nscan));
+    TRY(dev_alloc(c, &f.partials, (size_t)kReduceBlocks));
+    TRY(dev_alloc(c, &f.hkey, hcap)); TRY(dev_alloc(c, &f.hcount, hcap)); TRY(dev_alloc(c, &f.hmin, hcap));
+    TRY(dev_alloc(c, &f.cell_start, hcap)); TRY(dev_alloc(c, &f.parent, hcap));
+    TRY(dev_alloc(c, &f.comp_size, hcap)); TRY(dev_alloc(c, &f.comp_rank, hcap)); TRY(dev_alloc(c, &f.cell_list, n + 1));
+    TRY(dev_alloc(c, &f.pt_slot, n + 1)); TRY(dev_alloc(c, &f.pt_rank, n + 1)); TRY(dev_alloc(c, &f.pt_root, n + 1));
+    TRY(dev_alloc(c, &f.idx_a, n + 1)); TRY(dev_alloc(c, &f.idx_b, n + 1)); TRY(dev_alloc(c, &f.d_offsets, n + 2));
+    TRY(dev_alloc(c, &f.d_xyzr, n + 1));
+    TRY(host_alloc(c, &sl.h_args, 1));
+    TRY(host_alloc(c, &sl.h_state, 1));
+    TRY(host_alloc(c, &sl.h_offsets_disc, n + 2)); TRY(host_alloc(c, &sl.h_indices_disc, n + 1));
+    TRY(host_alloc(c, &sl.h_offsets, n + 2)); TRY(host_alloc(c, &sl.h_indices, n + 1));
+    TRY(host_alloc(c, &sl.h_vox, 4 * n)); TRY(host_alloc(c, &sl.h_xyzr, 4 * (n + 1)));
+#undef TRY
+    f.args = sl.h_args;
+    f.h_state = sl.h_state;
+    f.h_offsets = reinterpret_cast<uint32_t*>(sl.h_offsets_disc);
+    f.h_indices = reinterpret_cast<uint32_t*>(sl.h_indices_disc);
+    f.h_cloud = sl.h_vox;
+    // the cell table starts empty; afterwards every batch's k_emit leaves it empty again
+    HIPCHK(c, hipMemset(f.hkey, 0, hcap * 8));
+    HIPCHK(c, hipMemset(f.hcount, 0, hcap * 4));
+    HIPCHK(c, hipMemset(f.hmin, 0xFF, hcap * 4));
+    std::memset(sl.h_state, 0, sizeof(DevState));
+    std::memset(sl.h_args, 0, sizeof(FrameArgs));
+    return PCOP_OK;
+}
+
+int submit_common(pcop_ctx* c, uint32_t kind, bool emit_cloud, int out_layout, int is_dense) {
+    c->is_dense = is_dense; c->kind = kind; c->emit_cloud = emit_cloud; c->out_layout = out_layout;
+    return enqueue_batch(c);
 }
 
 }  // namespace
@@ -454,10 +497,10 @@ const char* pcop_status_string(int s) {
     }
 }
 
-int pcop_create(pcop_ctx** out, int device_id, size_t max_points) {
+int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_frames) {
     if (!out) return PCOP_ERR_ARG;
     *out = nullptr;
-    if (max_points == 0 || max_points > 0x3FFFFFF0ull) return PCOP_ERR_ARG;
+    if (max_points == 0 || max_points > 0x3FFFFFF0ull || max_frames < 1 || max_frames > 1024) return PCOP_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PCOP_ERR_NO_DEVICE;
     if (device_id < 0 || device_id >= ndev) return PCOP_ERR_NO_DEVICE;
@@ -465,71 +508,53 @@ int pcop_create(pcop_ctx** out, int device_id, size_t max_points) {
     if (!c) return PCOP_ERR_ARG;
     c->device = device_id;
     c->cap = max_points;
+    c->max_frames = (uint32_t)max_frames;
     if (const char* e = getenv("PCOP_RADIX_BITS")) {
         const int b = atoi(e);
         if (b >= 4 && b <= kMaxBits) c->radix_bits_target = b;
     }
     c->maxbits = c->radix_bits_target <= kNarrowBits ? kNarrowBits : kMaxBits;
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
-    int rc = PCOP_OK;
     const size_t nbk = bucket_of(c, (uint32_t)max_points);           // launch sizes round up to this
     const size_t n = std::max<size_t>(max_points, nbk);
     const size_t ntiles = (n + kTile - 1) / kTile + 1;
     const size_t hcap = hash_cap_for((uint32_t)n);
     c->hash_cap = hcap;
     const size_t nscan = std::max((n + kScanTile - 1) / kScanTile, hcap / kScanTile) + 1;
-#define TRY(x) do { rc = (x); if (rc) { std::string m_ = c->err; fprintf(stderr, "pcop_create: %s\n", m_.c_str()); pcop_destroy(c); return rc; } } while (0)
     if (hipSetDevice(device_id) != hipSuccess) { delete c; return PCOP_ERR_NO_DEVICE; }
-    { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return PCOP_ERR_HIP; } }
-    TRY(dev_alloc(c, &c->in_x, n)); TRY(dev_alloc(c, &c->in_y, n)); TRY(dev_alloc(c, &c->in_z, n));
-    TRY(dev_alloc(c, &c->cen_x, n)); TRY(dev_alloc(c, &c->cen_y, n)); TRY(dev_alloc(c, &c->cen_z, n));
-    TRY(dev_alloc(c, &c->rec_a, n)); TRY(dev_alloc(c, &c->rec_b, n));
-    TRY(dev_alloc(c, &c->table, ntiles * kMaxBins)); TRY(dev_alloc(c, &c->table_x, ntiles * kMaxBins));
-    TRY(dev_alloc(c, &c->bin_total, (size_t)kMaxBins));
-    TRY(dev_alloc(c, &c->tile_a, nscan)); TRY(dev_alloc(c, &c->tile_b, nscan));
-    TRY(dev_alloc(c, &c->partials, (size_t)kReduceBlocks));
-    TRY(dev_alloc(c, &c->hkey, hcap)); TRY(dev_alloc(c, &c->hcount, hcap)); TRY(dev_alloc(c, &c->hmin, hcap));
-    TRY(dev_alloc(c, &c->cell_start, hcap)); TRY(dev_alloc(c, &c->parent, hcap));
-    TRY(dev_alloc(c, &c->comp_size, hcap)); TRY(dev_alloc(c, &c->comp_rank, hcap)); TRY(dev_alloc(c, &c->cell_list, n + 1));
-    TRY(dev_alloc(c, &c->pt_slot, n + 1)); TRY(dev_alloc(c, &c->pt_rank, n + 1)); TRY(dev_alloc(c, &c->pt_root, n + 1));
-    TRY(dev_alloc(c, &c->idx_a, n + 1)); TRY(dev_alloc(c, &c->idx_b, n + 1)); TRY(dev_alloc(c, &c->d_offsets, n + 2));
-    TRY(dev_alloc(c, &c->d_xyzr, n + 1));
-    TRY(dev_alloc(c, &c->d_state, 1));
-    TRY(host_alloc(c, &c->h_args, 1));
-    TRY(host_alloc(c, &c->h_state, 1));
-    TRY(host_alloc(c, &c->h_offsets_disc, n + 2)); TRY(host_alloc(c, &c->h_indices_disc, n + 1));
-    TRY(host_alloc(c, &c->h_offsets, n + 2)); TRY(host_alloc(c, &c->h_indices, n + 1));
-    TRY(host_alloc(c, &c->h_vox, 4 * n)); TRY(host_alloc(c, &c->h_xyzr, 4 * (n + 1)));
-    // the cell table starts empty; afterwards every frame's k_emit leaves it empty again
-    if (hipMemset(c->hkey, 0, hcap * 8) != hipSuccess || hipMemset(c->hcount, 0, hcap * 4) != hipSuccess ||
-        hipMemset(c->hmin, 0xFF, hcap * 4) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        c->err = "hipMemset of the cell table failed";
-        TRY(PCOP_ERR_HIP);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PCOP_ERR_HIP; }
+    int rc = PCOP_OK;
+    c->slots.resize(c->max_frames);
+    for (uint32_t f = 0; f < c->max_frames && !rc; ++f) rc = alloc_slot(c, c->slots[f], n, ntiles, hcap, nscan);
+    if (!rc) rc = dev_alloc(c, &c->d_frames, c->max_frames);
+    if (!rc) {
+        std::vector<Frame> hf(c->max_frames);
+        for (uint32_t f = 0; f < c->max_frames; ++f) hf[f] = c->slots[f].f;
+        if (hipMemcpy(c->d_frames, hf.data(), sizeof(Frame) * c->max_frames, hipMemcpyHostToDevice) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) { c->err = "frame table upload failed"; rc = PCOP_ERR_HIP; }
     }
-#undef TRY
-    std::memset(c->h_state, 0, sizeof(DevState));
-    std::memset(c->h_args, 0, sizeof(FrameArgs));
+    if (rc) { fprintf(stderr, "pcop_create: %s\n", c->err.c_str()); pcop_destroy(c); return rc; }
     *out = c;
     return PCOP_OK;
 }
+
+int pcop_create(pcop_ctx** out, int device_id, size_t max_points) { return pcop_create_batch(out, device_id, max_points, 1); }
 
 void pcop_destroy(pcop_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
-    void* dev[] = {c->in_x, c->in_y, c->in_z, c->cen_x, c->cen_y, c->cen_z, c->rec_a, c->rec_b, c->table, c->table_x,
-                   c->bin_total, c->tile_a, c->tile_b, c->partials, c->hkey, c->hcount, c->hmin, c->cell_start, c->parent,
-                   c->comp_size, c->comp_rank, c->cell_list, c->pt_slot, c->pt_rank, c->pt_root, c->idx_a, c->idx_b, c->d_offsets,
-                   c->d_xyzr, c->d_raw, c->d_state};
-    for (void* p : dev) if (p) hipFree(p);
+    for (void* p : c->dev_allocs) if (p) hipFree(p);
+    for (Slot& sl : c->slots) if (sl.d_raw) hipFree(sl.d_raw);
     for (void* p : c->user_allocs) if (p) hipFree(p);
-    void* host[] = {c->h_args, c->h_state, c->h_offsets_disc, c->h_indices_disc, c->h_offsets, c->h_indices, c->h_vox, c->h_xyzr};
-    for (void* p : host) if (p) hipHostFree(p);
+    for (void* p : c->host_allocs) if (p) hipHostFree(p);
     for (hipEvent_t e : c->events) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
+
+int pcop_max_frames(const pcop_ctx* c) { return c ? (int)c->max_frames : 0; }
 
 int pcop_set_params(pcop_ctx* c, const pcop_params* p) {
     if (!c || !p) return PCOP_ERR_ARG;
@@ -563,15 +588,16 @@ void* pcop_stream(const pcop_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int pcop_voxel_downsample(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, float* out_xyz,
                           size_t* out_m, int* passthrough) {
     if (!c || !out_m || !passthrough || (!out_xyz && n)) return PCOP_ERR_ARG;
-    if (c->in_flight) { c->err = "a frame is already in flight on this context"; return PCOP_ERR_STATE; }
-    int rc = check_params(c, true, false);
+    int rc = busy(c);
     if (rc) return rc;
+    if ((rc = check_params(c, true, false))) return rc;
     if ((rc = set_device(c))) return rc;
-    if ((rc = stage_input(c, xyz, layout, n, PCOP_MEM_HOST))) return rc;
-    c->is_dense = is_dense; c->kind = kFrameVoxelOnly; c->emit_cloud = true; c->out_layout = layout;
-    if ((rc = enqueue_frame(c))) return rc;
+    Slot& sl = c->slots[0];
+    if ((rc = stage_input(c, sl, xyz, layout, n, PCOP_MEM_HOST))) return rc;
+    c->nframes = 1;
+    if ((rc = submit_common(c, kFrameVoxelOnly, true, layout, is_dense))) return rc;
     pcop_result r{};
-    if ((rc = finish_frame(c, &r))) return rc;
+    if ((rc = finish_batch(c, &r, 1))) return rc;
     *out_m = (size_t)r.num_voxels;
     *passthrough = r.passthrough;
     if (r.num_voxels == 0) return PCOP_OK;
@@ -582,9 +608,9 @@ int pcop_voxel_downsample(pcop_ctx* c, const float* xyz, int layout, size_t n, i
     }
     const size_t m = (size_t)r.num_voxels;
     if (layout == PCOP_LAYOUT_SOA) {
-        for (int a = 0; a < 3; ++a) std::memcpy(out_xyz + (size_t)a * n, c->h_vox + (size_t)a * n, m * 4);
+        for (int a = 0; a < 3; ++a) std::memcpy(out_xyz + (size_t)a * n, sl.h_vox + (size_t)a * n, m * 4);
     } else {
-        std::memcpy(out_xyz, c->h_vox, m * fl * 4);
+        std::memcpy(out_xyz, sl.h_vox, m * fl * 4);
     }
     return PCOP_OK;
 }
@@ -592,39 +618,49 @@ int pcop_voxel_downsample(pcop_ctx* c, const float* xyz, int layout, size_t n, i
 int pcop_euclidean_clusters(pcop_ctx* c, const float* xyz, int layout, size_t m, int32_t* offsets, int32_t* indices,
                             int32_t* k) {
     if (!c || !offsets || !k || (!indices && m)) return PCOP_ERR_ARG;
-    if (c->in_flight) { c->err = "a frame is already in flight on this context"; return PCOP_ERR_STATE; }
-    int rc = check_params(c, false, true);
+    int rc = busy(c);
     if (rc) return rc;
+    if ((rc = check_params(c, false, true))) return rc;
     if ((rc = set_device(c))) return rc;
-    if ((rc = stage_input(c, xyz, layout, m, PCOP_MEM_HOST))) return rc;
-    c->is_dense = 1; c->kind = kFrameClusterOnly; c->emit_cloud = false; c->out_layout = PCOP_LAYOUT_AOS12;
-    if ((rc = enqueue_frame(c))) return rc;
+    if ((rc = stage_input(c, c->slots[0], xyz, layout, m, PCOP_MEM_HOST))) return rc;
+    c->nframes = 1;
+    if ((rc = submit_common(c, kFrameClusterOnly, false, PCOP_LAYOUT_AOS12, 1))) return rc;
     pcop_result r{};
-    if ((rc = finish_frame(c, &r))) return rc;
+    if ((rc = finish_batch(c, &r, 1))) return rc;
     *k = r.num_clusters;
     std::memcpy(offsets, r.offsets, (size_t)(r.num_clusters + 1) * 4);
     if (r.num_indices) std::memcpy(indices, r.indices, (size_t)r.num_indices * 4);
     return PCOP_OK;
 }
 
-int pcop_submit_xyz(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem) {
-    if (!c) return PCOP_ERR_ARG;
-    if (c->in_flight) { c->err = "a frame is already in flight on this context"; return PCOP_ERR_STATE; }
-    int rc = check_params(c, true, true);
+int pcop_submit_batch(pcop_ctx* c, const float* const* xyz, int layout, const size_t* n, int nframes, int is_dense, int mem) {
+    if (!c || !xyz || !n) return PCOP_ERR_ARG;
+    if (nframes < 1 || (uint32_t)nframes > c->max_frames) { c->err = "nframes exceeds max_frames of the context"; return PCOP_ERR_CAPACITY; }
+    int rc = busy(c);
     if (rc) return rc;
+    if ((rc = check_params(c, true, true))) return rc;
     if (mem != PCOP_MEM_HOST && mem != PCOP_MEM_DEVICE) return PCOP_ERR_ARG;
     if ((rc = set_device(c))) return rc;
-    if ((rc = stage_input(c, xyz, layout, n, mem))) return rc;
-    c->is_dense = is_dense; c->kind = kFrameChain; c->emit_cloud = c->params.publish_clouds != 0; c->out_layout = PCOP_LAYOUT_AOS12;
-    return enqueue_frame(c);
+    for (int f = 0; f < nframes; ++f)
+        if ((rc = stage_input(c, c->slots[f], xyz[f], layout, n[f], mem))) return rc;
+    c->nframes = (uint32_t)nframes;
+    return submit_common(c, kFrameChain, c->params.publish_clouds != 0, PCOP_LAYOUT_AOS12, is_dense);
 }
 
-int pcop_wait(pcop_ctx* c, pcop_result* out) {
-    if (!c) return PCOP_ERR_ARG;
+int pcop_wait_batch(pcop_ctx* c, pcop_result* out, int nframes) {
+    if (!c || nframes < 0) return PCOP_ERR_ARG;
     int rc = set_device(c);
     if (rc) return rc;
-    return finish_frame(c, out);
+    return finish_batch(c, out, (uint32_t)nframes);
 }
+
+int pcop_submit_xyz(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem) {
+    const float* ptrs[1] = {xyz};
+    const size_t ns[1] = {n};
+    return pcop_submit_batch(c, ptrs, layout, ns, 1, is_dense, mem);
+}
+
+int pcop_wait(pcop_ctx* c, pcop_result* out) { return pcop_wait_batch(c, out, out ? 1 : 0); }
 
 int pcop_process_xyz(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem, pcop_result* out) {
     int rc = pcop_submit_xyz(c, xyz, layout, n, is_dense, mem);
@@ -636,81 +672,89 @@ int pcop_process_pointcloud2(pcop_ctx* c, const uint8_t* data, uint32_t width, u
                              uint32_t row_step, uint32_t off_x, uint32_t off_y, uint32_t off_z, int is_bigendian,
                              int is_dense, pcop_result* out) {
     if (!c) return PCOP_ERR_ARG;
-    if (c->in_flight) { c->err = "a frame is already in flight on this context"; return PCOP_ERR_STATE; }
-    int rc = check_params(c, true, true);
+    int rc = busy(c);
     if (rc) return rc;
+    if ((rc = check_params(c, true, true))) return rc;
     const size_t n = (size_t)width * height;
     if (n > c->cap) { c->err = "n exceeds max_points of the context"; return PCOP_ERR_CAPACITY; }
     if (n && !data) return PCOP_ERR_ARG;
     if (point_step < 4 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step) return PCOP_ERR_ARG;
     if (n && row_step < (size_t)width * point_step) return PCOP_ERR_ARG;
     if ((rc = set_device(c))) return rc;
-    c->n = (uint32_t)n;
-    c->src_x = c->in_x; c->src_y = c->in_y; c->src_z = c->in_z;
+    Slot& sl = c->slots[0];
+    sl.n = (uint32_t)n;
+    sl.src_x = sl.in_x; sl.src_y = sl.in_y; sl.src_z = sl.in_z;
     if (n) {
         const size_t row_bytes = (size_t)width * point_step;
-        if ((rc = ensure_raw(c, n * point_step))) return rc;
+        if ((rc = ensure_raw(c, sl, n * point_step))) return rc;
         if (row_step == row_bytes) {
-            HIPCHK(c, hipMemcpyAsync(c->d_raw, data, n * point_step, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(sl.d_raw, data, n * point_step, hipMemcpyHostToDevice, c->stream));
         } else {
-            HIPCHK(c, hipMemcpy2DAsync(c->d_raw, row_bytes, data, row_step, row_bytes, height, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpy2DAsync(sl.d_raw, row_bytes, data, row_step, row_bytes, height, hipMemcpyHostToDevice, c->stream));
         }
-        k_unpack_points<<<stride_grid((uint32_t)n), kBlock, 0, c->stream>>>(c->d_raw, (uint32_t)n, point_step, off_x, off_y, off_z,
-                                                                           is_bigendian, c->in_x, c->in_y, c->in_z);
+        k_unpack_points<<<stride_grid((uint32_t)n), kBlock, 0, c->stream>>>(sl.d_raw, (uint32_t)n, point_step, off_x, off_y, off_z,
+                                                                           is_bigendian, sl.in_x, sl.in_y, sl.in_z);
         HIPCHK(c, hipGetLastError());
     }
-    c->is_dense = is_dense; c->kind = kFrameChain; c->emit_cloud = c->params.publish_clouds != 0; c->out_layout = PCOP_LAYOUT_AOS12;
-    if ((rc = enqueue_frame(c))) return rc;
-    return finish_frame(c, out);
+    c->nframes = 1;
+    if ((rc = submit_common(c, kFrameChain, c->params.publish_clouds != 0, PCOP_LAYOUT_AOS12, is_dense))) return rc;
+    return finish_batch(c, out, out ? 1 : 0);
 }
 
-int pcop_cluster_summaries(pcop_ctx* c, float* xyzr, int32_t cap_clusters) {
-    if (!c || (!xyzr && cap_clusters)) return PCOP_ERR_ARG;
-    if (!c->have_result || c->in_flight) { c->err = "no finished clustered frame on this context"; return PCOP_ERR_STATE; }
+int pcop_cluster_summaries_frame(pcop_ctx* c, int frame, float* xyzr, int32_t cap_clusters) {
+    if (!c || (!xyzr && cap_clusters) || frame < 0 || (uint32_t)frame >= c->max_frames) return PCOP_ERR_ARG;
+    Slot& sl = c->slots[frame];
+    if (!sl.have_result || c->in_flight) { c->err = "no finished clustered frame in this slot"; return PCOP_ERR_STATE; }
     int rc = set_device(c);
     if (rc) return rc;
-    const uint32_t k = (uint32_t)c->order.size();
+    const uint32_t k = (uint32_t)sl.order.size();
     if (k == 0) return PCOP_OK;
     if ((uint32_t)cap_clusters < k) return PCOP_ERR_ARG;
-    if (c->result_trivial) {
+    if (sl.result_trivial) {
         // singletons: centre = the point itself, r = 0
-        const bool from_input = c->kind == kFrameClusterOnly || c->h_state->passthrough;
-        const float *px = from_input ? c->src_x : c->cen_x, *py = from_input ? c->src_y : c->cen_y, *pz = from_input ? c->src_z : c->cen_z;
-        float* tmp = c->h_xyzr;   // 3 planes of k floats
+        const bool from_input = c->kind == kFrameClusterOnly || sl.h_state->passthrough;
+        const float *px = from_input ? sl.src_x : sl.f.cen_x, *py = from_input ? sl.src_y : sl.f.cen_y, *pz = from_input ? sl.src_z : sl.f.cen_z;
+        float* tmp = sl.h_xyzr;   // 3 planes of k floats
         HIPCHK(c, hipMemcpyAsync(tmp, px, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(tmp + k, py, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(tmp + 2 * (size_t)k, pz, (size_t)k * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::vector<float> o(4 * (size_t)k);
         for (uint32_t i = 0; i < k; ++i) {
-            const uint32_t s = (uint32_t)c->order[i];
+            const uint32_t s = (uint32_t)sl.order[i];
             o[4 * (size_t)i] = tmp[s]; o[4 * (size_t)i + 1] = tmp[k + s]; o[4 * (size_t)i + 2] = tmp[2 * (size_t)k + s]; o[4 * (size_t)i + 3] = 0.0f;
         }
         std::memcpy(xyzr, o.data(), o.size() * 4);
         return PCOP_OK;
     }
-    k_cluster_summaries<<<std::min(2048u, std::max(1u, div_up(k, kWavesPerBlock))), kBlock, 0, c->stream>>>(
-        c->d_state, c->cen_x, c->cen_y, c->cen_z, c->d_offsets, c->frame_csr_idx, c->d_xyzr);
+    // one launch over this slot only: a one-frame view of the frame table
+    k_cluster_summaries<<<dim3(std::min(2048u, std::max(1u, div_up(k, kWavesPerBlock))), 1), kBlock, 0, c->stream>>>(
+        c->d_frames + frame, c->frame_npass_csr);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_xyzr, c->d_xyzr, (size_t)k * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sl.h_xyzr, sl.f.d_xyzr, (size_t)k * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (uint32_t i = 0; i < k; ++i) std::memcpy(xyzr + 4 * (size_t)i, c->h_xyzr + 4 * (size_t)c->order[i], 16);
+    for (uint32_t i = 0; i < k; ++i) std::memcpy(xyzr + 4 * (size_t)i, sl.h_xyzr + 4 * (size_t)sl.order[i], 16);
     return PCOP_OK;
+}
+
+int pcop_cluster_summaries(pcop_ctx* c, float* xyzr, int32_t cap_clusters) {
+    return pcop_cluster_summaries_frame(c, 0, xyzr, cap_clusters);
 }
 
 int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* bytes) {
     if (!c || !name || !dev_ptr || !bytes) return PCOP_ERR_ARG;
     const size_t n = c->cap, h = c->hash_cap;
+    const Frame& f = c->slots[0].f;
     struct Ent { const char* nm; void* p; size_t b; };
     const Ent tab[] = {
-        {"state", c->d_state, sizeof(DevState)},
-        {"cen_x", c->cen_x, n * 4}, {"cen_y", c->cen_y, n * 4}, {"cen_z", c->cen_z, n * 4},
-        {"rec_a", c->rec_a, n * 16}, {"rec_b", c->rec_b, n * 16},
-        {"hkey", c->hkey, h * 8}, {"hcount", c->hcount, h * 4}, {"hmin", c->hmin, h * 4},
-        {"cell_start", c->cell_start, h * 4}, {"parent", c->parent, h * 4}, {"comp_size", c->comp_size, h * 4},
-        {"comp_rank", c->comp_rank, h * 4}, {"pt_slot", c->pt_slot, n * 4}, {"pt_rank", c->pt_rank, n * 4},
-        {"pt_root", c->pt_root, n * 4}, {"idx_a", c->idx_a, n * 4}, {"idx_b", c->idx_b, n * 4},
-        {"d_offsets", c->d_offsets, (n + 1) * 4}, {"bin_total", c->bin_total, (size_t)kMaxBins * 4},
+        {"state", c->d_frames, sizeof(DevState)},   // DevState is the first member of Frame
+        {"cen_x", f.cen_x, n * 4}, {"cen_y", f.cen_y, n * 4}, {"cen_z", f.cen_z, n * 4},
+        {"rec_a", f.rec_a, n * 16}, {"rec_b", f.rec_b, n * 16},
+        {"hkey", f.hkey, h * 8}, {"hcount", f.hcount, h * 4}, {"hmin", f.hmin, h * 4},
+        {"cell_start", f.cell_start, h * 4}, {"parent", f.parent, h * 4}, {"comp_size", f.comp_size, h * 4},
+        {"comp_rank", f.comp_rank, h * 4}, {"pt_slot", f.pt_slot, n * 4}, {"pt_rank", f.pt_rank, n * 4},
+        {"pt_root", f.pt_root, n * 4}, {"idx_a", f.idx_a, n * 4}, {"idx_b", f.idx_b, n * 4},
+        {"d_offsets", f.d_offsets, (n + 1) * 4}, {"bin_total", f.bin_total, (size_t)kMaxBins * 4},
     };
     for (const Ent& e : tab) {
         if (std::strcmp(e.nm, name) == 0) { *dev_ptr = e.p; *bytes = e.b; return PCOP_OK; }

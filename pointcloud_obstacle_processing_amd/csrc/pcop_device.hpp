@@ -105,6 +105,34 @@ struct DevState {
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState layout");
 
+struct MinMaxPartial {
+    float mn[3], mx[3];
+    uint32_t valid, nonfinite;
+};
+
+// Everything one frame of a batch owns.  A launch covers a whole batch: blockIdx.y selects the
+// frame, and every kernel takes its buffers from frames[blockIdx.y], so the kernel arguments
+// are the same for every launch and the batch replays as one hipGraph.
+struct Frame {
+    DevState st;
+    const FrameArgs* args;            // pinned host mailbox
+    float *cen_x, *cen_y, *cen_z;     // voxel centroids (SoA)
+    float4 *rec_a, *rec_b;            // partition ping-pong / cell-sorted records
+    uint32_t *table, *table_x, *bin_total, *tile_a, *tile_b;
+    MinMaxPartial* partials;
+    unsigned long long* hkey;         // cell hash table: key+1 (0 = empty)
+    uint32_t *hcount, *hmin;          //                  points, smallest point index (= priority)
+    uint32_t *cell_start, *cell_list, *parent, *comp_size, *comp_rank;
+    uint32_t *pt_slot, *pt_rank, *pt_root;
+    uint32_t *idx_a, *idx_b, *d_offsets;
+    float4* d_xyzr;
+    // pinned host outputs
+    DevState* h_state;
+    uint32_t* h_offsets;              // n_kept + 1, discovery order
+    uint32_t* h_indices;              // n_kept_pts
+    float* h_cloud;                   // voxel cloud in st.out_layout
+};
+
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
@@ -215,15 +243,14 @@ __device__ __forceinline__ bool make_plan(RadixPlan* pl, uint32_t key_bits, uint
 // ------------------------------------------------------------------------------------------
 // record sources and the voxel key
 // ------------------------------------------------------------------------------------------
-struct SoaSrc {   // pass 0: the frame's input planes + implicit idx
+// Pass 0 reads the frame's input planes (+ implicit idx), later passes the 16-byte records the
+// previous pass wrote; pass p writes rec_a when p is even, rec_b when odd.
+struct RecSrc {
     const float* x; const float* y; const float* z;
-    __device__ __forceinline__ void init(const DevState* st) { x = st->src_x; y = st->src_y; z = st->src_z; }
-    __device__ __forceinline__ float4 load(uint32_t i) const { return make_float4(x[i], y[i], z[i], u2f(i)); }
-};
-struct RecSrc {   // later passes: 16-byte records
-    const float4* r;
-    __device__ __forceinline__ void init(const DevState*) {}
-    __device__ __forceinline__ float4 load(uint32_t i) const { return r[i]; }
+    const float4* r;   // null on pass 0
+    __device__ __forceinline__ float4 load(uint32_t i) const {
+        return r ? r[i] : make_float4(x[i], y[i], z[i], u2f(i));
+    }
 };
 
 // PCL's linear voxel index (voxel_grid.hpp, "First pass"): ijk = (int)(floor(p*inv) - (float)min_b).
@@ -246,9 +273,11 @@ struct VoxelKey {
 // ------------------------------------------------------------------------------------------
 // frame init + layout conversion
 // ------------------------------------------------------------------------------------------
-__global__ void k_frame_init(DevState* st, const FrameArgs* args) {
+__global__ void k_frame_init(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const FrameArgs a = *args;
+        const FrameArgs a = *F.args;
         DevState s;
         memset(&s, 0, sizeof(s));
         s.n_in = a.n; s.is_dense = a.is_dense; s.kind = a.kind; s.trivial = a.trivial;
@@ -290,11 +319,6 @@ __global__ __launch_bounds__(kBlock) void k_unpack_points(const uint8_t* __restr
 // ------------------------------------------------------------------------------------------
 // min / max (pcl::getMinMax3D) + grid set-up by the last block to arrive
 // ------------------------------------------------------------------------------------------
-struct MinMaxPartial {
-    float mn[3], mx[3];
-    uint32_t valid, nonfinite;
-};
-
 // VoxelGrid::applyFilter up to "divb_mul_ = ..." (SURVEY.md §8a-1 steps 1-4).
 __device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p, uint32_t npass, uint32_t maxbits) {
     if (st->is_dense && p.nonfinite) { atomicOr(&st->err, (uint32_t)kErrNonFinite); return; }
@@ -345,10 +369,12 @@ __device__ __forceinline__ void reduce_partials_lds(MinMaxPartial* s_p) {   // k
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(DevState* st, MinMaxPartial* partials, uint32_t npass,
-                                                               uint32_t maxbits) {
+__global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(Frame* frames, uint32_t npass, uint32_t maxbits) {
     __shared__ MinMaxPartial s_p[kBlock];
     __shared__ uint32_t s_last;
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    MinMaxPartial* partials = F.partials;
     if (st->kind == kFrameClusterOnly) return;
     const float* __restrict__ x = st->src_x;
     const float* __restrict__ y = st->src_y;
@@ -407,6 +433,17 @@ __global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(DevState* st, Min
 //   k_table_scan    : exclusive scan down each column  -> table_x[tile][bin], bin_total[bin]
 //   k_radix_scatter : stable ranks (wave match-any) + scatter
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ RecSrc rec_source(const Frame& F, int pass) {
+    RecSrc s;
+    s.x = F.st.src_x; s.y = F.st.src_y; s.z = F.st.src_z;
+    s.r = pass == 0 ? nullptr : (((pass - 1) & 1) ? F.rec_b : F.rec_a);
+    return s;
+}
+// output of the last of npass partition passes
+__device__ __forceinline__ const float4* sorted_records(const Frame& F, uint32_t npass) {
+    return ((npass - 1) & 1) ? F.rec_b : F.rec_a;
+}
+
 struct PassInfo {
     uint32_t count, bits, shift, nb;   // nb = (1<<bits) + 1 bins (last = trash)
     bool drop_nonfinite;
@@ -425,15 +462,17 @@ __device__ __forceinline__ PassInfo pass_info(const DevState* st, int pass) {
     return pi;
 }
 
-template <class Src, int MAXB>
-__global__ __launch_bounds__(kBlock) void k_radix_hist(Src src, const DevState* st, int pass,
-                                                       uint32_t* __restrict__ table) {
+template <int MAXB>
+__global__ __launch_bounds__(kBlock) void k_radix_hist(const Frame* frames, int pass) {
     __shared__ uint32_t s_h[(1 << MAXB) + 1];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    uint32_t* __restrict__ table = F.table;
     if (voxel_stage_off(st)) return;
     const PassInfo pi = pass_info(st, pass);
     const uint32_t tile_base = blockIdx.x * kTile;
     if (tile_base >= pi.count) return;
-    src.init(st);
+    const RecSrc src = rec_source(F, pass);
     VoxelKey key; key.init(st);
     for (uint32_t b = threadIdx.x; b < pi.nb; b += kBlock) s_h[b] = 0;
     __syncthreads();
@@ -473,11 +512,13 @@ __device__ __forceinline__ bool table_dims(const DevState* st, int which, int pa
 
 // Exclusive scan down each column of the tile-count table: block b owns bin b.
 // grid = kMaxBins blocks (blocks past the pass's bin count exit at once).
-__global__ __launch_bounds__(kBlock) void k_table_scan(const DevState* st, int which, int pass,
-                                                       const uint32_t* __restrict__ table,
-                                                       uint32_t* __restrict__ table_x,
-                                                       uint32_t* __restrict__ bin_total) {
+__global__ __launch_bounds__(kBlock) void k_table_scan(const Frame* frames, int which, int pass) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint32_t* __restrict__ table = F.table;
+    uint32_t* __restrict__ table_x = F.table_x;
+    uint32_t* __restrict__ bin_total = F.bin_total;
     uint32_t ntiles, nb;
     if (!table_dims(st, which, pass, &ntiles, &nb)) return;
     const uint32_t b = blockIdx.x;
@@ -530,19 +571,21 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint32_t nbits, bool
     return m;
 }
 
-template <class Src, int MAXB>
-__global__ __launch_bounds__(kBlock) void k_radix_scatter(Src src, const DevState* st, int pass,
-                                                          const uint32_t* __restrict__ table_x,
-                                                          const uint32_t* __restrict__ bin_total,
-                                                          float4* __restrict__ out) {
+template <int MAXB>
+__global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, int pass) {
     __shared__ uint32_t s_hist[kWavesPerBlock * ((1 << MAXB) + 1)];
     __shared__ uint32_t s_base[(1 << MAXB) + 1];
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint32_t* __restrict__ table_x = F.table_x;
+    const uint32_t* __restrict__ bin_total = F.bin_total;
+    float4* __restrict__ out = (pass & 1) ? F.rec_b : F.rec_a;
     if (voxel_stage_off(st)) return;
     const PassInfo pi = pass_info(st, pass);
     const uint32_t tile_base = blockIdx.x * kTile;
     if (tile_base >= pi.count) return;
-    src.init(st);
+    const RecSrc src = rec_source(F, pass);
     VoxelKey key; key.init(st);
     const uint32_t nb = pi.nb;
     for (uint32_t b = threadIdx.x; b < kWavesPerBlock * nb; b += kBlock) s_hist[b] = 0;
@@ -596,9 +639,12 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(Src src, const DevStat
 // ------------------------------------------------------------------------------------------
 // run heads over the sorted records -> voxel rank; centroids
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_heads_count(const float4* __restrict__ rec, const DevState* st,
-                                                        uint32_t* __restrict__ tile_heads) {
+__global__ __launch_bounds__(kBlock) void k_heads_count(const Frame* frames, uint32_t npass) {
     __shared__ uint32_t s_w[kWavesPerBlock];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = sorted_records(F, npass);
+    uint32_t* __restrict__ tile_heads = F.tile_a;
     if (voxel_stage_off(st)) return;
     const uint32_t n = st->n_valid;
     const uint32_t base = blockIdx.x * kScanTile;
@@ -633,13 +679,15 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 // Voxel centroids (voxel_grid.hpp "Fourth pass", PCL >= 1.8 CentroidPoint / AccumulatorXYZ):
 // the thread that owns a run head sums the run in order (= ascending point index, the
 // partition is stable) starting from 0.0f and divides by float(count).
-__global__ __launch_bounds__(kBlock) void k_voxel_reduce(const float4* __restrict__ rec, DevState* st,
-                                                         const uint32_t* __restrict__ tile_heads,
-                                                         float* __restrict__ cx, float* __restrict__ cy,
-                                                         float* __restrict__ cz) {
+__global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t npass) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     __shared__ float4 s_rec[kScanTile];
     __shared__ uint32_t s_key[kScanTile + 1];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const float4* __restrict__ rec = sorted_records(F, npass);
+    const uint32_t* __restrict__ tile_heads = F.tile_a;
+    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
     if (st->err || st->kind == kFrameClusterOnly) return;
     if (st->passthrough) {   // "output = *input_": the voxel cloud is the input cloud, every point kept
         if (blockIdx.x == 0 && threadIdx.x == 0) finish_voxel(st, st->n_in);
@@ -765,10 +813,12 @@ __device__ __forceinline__ bool cluster_stage_off(const DevState* st) {
 
 // Every point: its cell's slot and its rank inside the cell.  Runs of consecutive points that
 // fall in one cell (frequent: the points arrive in voxel order) share one set of atomics.
-__global__ __launch_bounds__(kBlock) void k_cell_insert(DevState* st, const float* __restrict__ cen_x,
-                                                        const float* __restrict__ cen_y, const float* __restrict__ cen_z,
-                                                        CellTable tab, uint32_t* __restrict__ pt_slot,
-                                                        uint32_t* __restrict__ pt_rank) {
+__global__ __launch_bounds__(kBlock) void k_cell_insert(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const float* __restrict__ cen_x = F.cen_x; const float* __restrict__ cen_y = F.cen_y; const float* __restrict__ cen_z = F.cen_z;
+    const CellTable tab{F.hkey, F.hcount, F.hmin};
+    uint32_t* __restrict__ pt_slot = F.pt_slot; uint32_t* __restrict__ pt_rank = F.pt_rank;
     if (cluster_stage_off(st)) return;
     const bool from_in = st->c_from_input != 0;
     const float* __restrict__ x = from_in ? st->src_x : cen_x;
@@ -822,9 +872,12 @@ __global__ __launch_bounds__(kBlock) void k_cell_insert(DevState* st, const floa
 }
 
 // points and occupied slots per tile of kScanTile slots
-__global__ __launch_bounds__(kBlock) void k_slot_count(const DevState* st, const uint32_t* __restrict__ hcount,
-                                                       uint32_t* __restrict__ tile_pts, uint32_t* __restrict__ tile_occ) {
+__global__ __launch_bounds__(kBlock) void k_slot_count(const Frame* frames) {
     __shared__ uint32_t s_w[kWavesPerBlock];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint32_t* __restrict__ hcount = F.hcount;
+    uint32_t* __restrict__ tile_pts = F.tile_a; uint32_t* __restrict__ tile_occ = F.tile_b;
     if (cluster_stage_off(st)) return;
     const uint32_t cap = st->hash_mask + 1u;
     const uint32_t base = blockIdx.x * kScanTile;
@@ -842,13 +895,15 @@ __global__ __launch_bounds__(kBlock) void k_slot_count(const DevState* st, const
 
 // cell_start[slot] = number of points in slots before it; dense list of occupied slots;
 // union-find init
-__global__ __launch_bounds__(kBlock) void k_slot_apply(DevState* st, const uint32_t* __restrict__ hcount,
-                                                       const uint32_t* __restrict__ tile_pts,
-                                                       const uint32_t* __restrict__ tile_occ,
-                                                       uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_list,
-                                                       uint32_t* __restrict__ parent,
-                                                       uint32_t* __restrict__ comp_size, uint32_t* __restrict__ comp_rank) {
+__global__ __launch_bounds__(kBlock) void k_slot_apply(Frame* frames) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const uint32_t* __restrict__ hcount = F.hcount;
+    const uint32_t* __restrict__ tile_pts = F.tile_a; const uint32_t* __restrict__ tile_occ = F.tile_b;
+    uint32_t* __restrict__ cell_start = F.cell_start; uint32_t* __restrict__ cell_list = F.cell_list;
+    uint32_t* __restrict__ parent = F.parent; uint32_t* __restrict__ comp_size = F.comp_size;
+    uint32_t* __restrict__ comp_rank = F.comp_rank;
     if (cluster_stage_off(st)) return;
     const uint32_t cap = st->hash_mask + 1u;
     const uint32_t base = blockIdx.x * kScanTile;
@@ -876,10 +931,13 @@ __global__ __launch_bounds__(kBlock) void k_slot_apply(DevState* st, const uint3
 }
 
 // counting sort: record of point i goes to cell_start[slot] + rank
-__global__ __launch_bounds__(kBlock) void k_cell_place(const DevState* st, const float* __restrict__ cen_x,
-                                                       const float* __restrict__ cen_y, const float* __restrict__ cen_z,
-                                                       const uint32_t* __restrict__ pt_slot, const uint32_t* __restrict__ pt_rank,
-                                                       const uint32_t* __restrict__ cell_start, float4* __restrict__ rec) {
+__global__ __launch_bounds__(kBlock) void k_cell_place(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float* __restrict__ cen_x = F.cen_x; const float* __restrict__ cen_y = F.cen_y; const float* __restrict__ cen_z = F.cen_z;
+    const uint32_t* __restrict__ pt_slot = F.pt_slot; const uint32_t* __restrict__ pt_rank = F.pt_rank;
+    const uint32_t* __restrict__ cell_start = F.cell_start;
+    float4* __restrict__ rec = F.rec_a;
     if (cluster_stage_off(st)) return;
     const bool from_in = st->c_from_input != 0;
     const float* __restrict__ x = from_in ? st->src_x : cen_x;
@@ -996,11 +1054,14 @@ __device__ __forceinline__ bool wave_pair_hit(const float4* __restrict__ rec, ui
     return hit;
 }
 
-__global__ __launch_bounds__(kBlock) void k_cell_hook(const float4* __restrict__ rec, const DevState* st, CellTable tab,
-                                                      const uint32_t* __restrict__ cell_start,
-                                                      const uint32_t* __restrict__ cell_list,
-                                                      uint32_t* __restrict__ parent) {
+__global__ __launch_bounds__(kBlock) void k_cell_hook(const Frame* frames) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = F.rec_a;
+    const CellTable tab{F.hkey, F.hcount, F.hmin};
+    const uint32_t* __restrict__ cell_start = F.cell_start; const uint32_t* __restrict__ cell_list = F.cell_list;
+    uint32_t* __restrict__ parent = F.parent;
     if (cluster_stage_off(st)) return;
     const uint32_t mask = st->hash_mask, ncell = st->n_cells;
     const float r2 = st->r2;
@@ -1043,8 +1104,11 @@ __global__ __launch_bounds__(kBlock) void k_cell_hook(const float4* __restrict__
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_cell_compress(const DevState* st, const uint32_t* __restrict__ cell_list,
-                                                          uint32_t* __restrict__ parent) {
+__global__ __launch_bounds__(kBlock) void k_cell_compress(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint32_t* __restrict__ cell_list = F.cell_list;
+    uint32_t* __restrict__ parent = F.parent;
     if (cluster_stage_off(st)) return;
     const uint32_t ncell = st->n_cells;
     for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < ncell; ci += gridDim.x * blockDim.x) {
@@ -1054,11 +1118,14 @@ __global__ __launch_bounds__(kBlock) void k_cell_compress(const DevState* st, co
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_cell_union(const float4* __restrict__ rec, const DevState* st, CellTable tab,
-                                                       const uint32_t* __restrict__ cell_start,
-                                                       const uint32_t* __restrict__ cell_list,
-                                                       uint32_t* __restrict__ parent) {
+__global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = F.rec_a;
+    const CellTable tab{F.hkey, F.hcount, F.hmin};
+    const uint32_t* __restrict__ cell_start = F.cell_start; const uint32_t* __restrict__ cell_list = F.cell_list;
+    uint32_t* __restrict__ parent = F.parent;
     if (cluster_stage_off(st)) return;
     const uint32_t mask = st->hash_mask, ncell = st->n_cells;
     const float r2 = st->r2;
@@ -1102,9 +1169,12 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const float4* __restrict_
 // at a time; lanes whose points share a root add up in registers, and the count of the root a
 // wave is currently running through is carried across steps, so a component that spans a long
 // stretch of points (a ground plane) costs one atomic per wave, not one per step.
-__global__ __launch_bounds__(kBlock) void k_cell_flatten(const DevState* st, const uint32_t* __restrict__ pt_slot,
-                                                         uint32_t* __restrict__ parent, uint32_t* __restrict__ pt_root,
-                                                         uint32_t* __restrict__ comp_size) {
+__global__ __launch_bounds__(kBlock) void k_cell_flatten(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint32_t* __restrict__ pt_slot = F.pt_slot;
+    uint32_t* __restrict__ parent = F.parent; uint32_t* __restrict__ pt_root = F.pt_root;
+    uint32_t* __restrict__ comp_size = F.comp_size;
     if (cluster_stage_off(st)) return;
     const uint32_t n = st->c_n;
     const uint32_t lane = lane_id();
@@ -1149,10 +1219,13 @@ __device__ __forceinline__ uint32_t kept_size(uint32_t i, const uint32_t* __rest
     return (s >= lo && s <= hi) ? s : 0u;
 }
 
-__global__ __launch_bounds__(kBlock) void k_kept_count(const DevState* st, const uint32_t* __restrict__ pt_root,
-                                                       const uint32_t* __restrict__ hmin, const uint32_t* __restrict__ comp_size,
-                                                       uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_pts) {
+__global__ __launch_bounds__(kBlock) void k_kept_count(const Frame* frames) {
     __shared__ uint32_t s_w[kWavesPerBlock];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint32_t* __restrict__ pt_root = F.pt_root; const uint32_t* __restrict__ hmin = F.hmin;
+    const uint32_t* __restrict__ comp_size = F.comp_size;
+    uint32_t* __restrict__ tile_cnt = F.tile_a; uint32_t* __restrict__ tile_pts = F.tile_b;
     if (cluster_stage_off(st)) return;
     const uint32_t n = st->c_n;
     const uint32_t base = blockIdx.x * kScanTile;
@@ -1170,12 +1243,14 @@ __global__ __launch_bounds__(kBlock) void k_kept_count(const DevState* st, const
 }
 
 // comp_rank[root] = discovery rank of the kept cluster; offsets_out[rank] = CSR offset.
-__global__ __launch_bounds__(kBlock) void k_kept_apply(DevState* st, const uint32_t* __restrict__ pt_root,
-                                                       const uint32_t* __restrict__ hmin, const uint32_t* __restrict__ comp_size,
-                                                       const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_pts,
-                                                       uint32_t* __restrict__ comp_rank, uint32_t* __restrict__ offsets_out,
-                                                       uint32_t npass_csr, uint32_t maxbits) {
+__global__ __launch_bounds__(kBlock) void k_kept_apply(Frame* frames, uint32_t npass_csr, uint32_t maxbits) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const uint32_t* __restrict__ pt_root = F.pt_root; const uint32_t* __restrict__ hmin = F.hmin;
+    const uint32_t* __restrict__ comp_size = F.comp_size;
+    const uint32_t* __restrict__ tile_cnt = F.tile_a; const uint32_t* __restrict__ tile_pts = F.tile_b;
+    uint32_t* __restrict__ comp_rank = F.comp_rank; uint32_t* __restrict__ offsets_out = F.d_offsets;
     if (cluster_stage_off(st)) return;
     const uint32_t n = st->c_n;
     if (n == 0) {
@@ -1230,10 +1305,13 @@ __device__ __forceinline__ uint32_t point_label(uint32_t p, const uint32_t* __re
 }
 
 template <int MAXB>
-__global__ __launch_bounds__(kBlock) void k_csr_hist(const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ pt_root,
-                                                     const uint32_t* __restrict__ comp_rank, const DevState* st, int pass,
-                                                     uint32_t* __restrict__ table) {
+__global__ __launch_bounds__(kBlock) void k_csr_hist(const Frame* frames, int pass) {
     __shared__ uint32_t s_h[(1 << MAXB) + 1];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint32_t* __restrict__ idx_in = pass == 0 ? nullptr : (((pass - 1) & 1) ? F.idx_b : F.idx_a);
+    const uint32_t* __restrict__ pt_root = F.pt_root; const uint32_t* __restrict__ comp_rank = F.comp_rank;
+    uint32_t* __restrict__ table = F.table;
     uint32_t count, bits, shift;
     if (!csr_pass_info(st, pass, &count, &bits, &shift)) return;
     const uint32_t tile_base = blockIdx.x * kTile;
@@ -1257,13 +1335,16 @@ __global__ __launch_bounds__(kBlock) void k_csr_hist(const uint32_t* __restrict_
 }
 
 template <int MAXB>
-__global__ __launch_bounds__(kBlock) void k_csr_scatter(const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ pt_root,
-                                                        const uint32_t* __restrict__ comp_rank, const DevState* st, int pass,
-                                                        const uint32_t* __restrict__ table_x,
-                                                        const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ idx_out) {
+__global__ __launch_bounds__(kBlock) void k_csr_scatter(const Frame* frames, int pass) {
     __shared__ uint32_t s_hist[kWavesPerBlock * ((1 << MAXB) + 1)];
     __shared__ uint32_t s_base[(1 << MAXB) + 1];
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint32_t* __restrict__ idx_in = pass == 0 ? nullptr : (((pass - 1) & 1) ? F.idx_b : F.idx_a);
+    uint32_t* __restrict__ idx_out = (pass & 1) ? F.idx_b : F.idx_a;
+    const uint32_t* __restrict__ pt_root = F.pt_root; const uint32_t* __restrict__ comp_rank = F.comp_rank;
+    const uint32_t* __restrict__ table_x = F.table_x; const uint32_t* __restrict__ bin_total = F.bin_total;
     uint32_t count, bits, shift;
     if (!csr_pass_info(st, pass, &count, &bits, &shift)) return;
     const uint32_t tile_base = blockIdx.x * kTile;
@@ -1322,10 +1403,14 @@ struct HostOut {
     float* cloud;          // voxel cloud in st->out_layout
 };
 
-__global__ __launch_bounds__(kBlock) void k_emit(const DevState* st, HostOut out, const uint32_t* __restrict__ d_offsets,
-                                                 const uint32_t* __restrict__ d_indices, const float* __restrict__ cen_x,
-                                                 const float* __restrict__ cen_y, const float* __restrict__ cen_z,
-                                                 CellTable tab) {
+__global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t npass_csr) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const HostOut out{F.h_state, F.h_offsets, F.h_indices, F.h_cloud};
+    const uint32_t* __restrict__ d_offsets = F.d_offsets;
+    const uint32_t* __restrict__ d_indices = ((npass_csr - 1) & 1) ? F.idx_b : F.idx_a;
+    const float* __restrict__ cen_x = F.cen_x; const float* __restrict__ cen_y = F.cen_y; const float* __restrict__ cen_z = F.cen_z;
+    const CellTable tab{F.hkey, F.hcount, F.hmin};
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     // reset the cell table for the next frame (also after an error: only touched slots are dirty,
     // and they all lie below hash_mask + 1)
@@ -1363,11 +1448,13 @@ __global__ __launch_bounds__(kBlock) void k_emit(const DevState* st, HostOut out
 // PointWithRad per cluster (msg/PointWithRad.msg): one wave per cluster.
 // centre = double mean rounded to float; r = max calculate_distance() (od.cpp:457-464).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_cluster_summaries(const DevState* st, const float* __restrict__ cen_x,
-                                                              const float* __restrict__ cen_y, const float* __restrict__ cen_z,
-                                                              const uint32_t* __restrict__ offsets,
-                                                              const uint32_t* __restrict__ indices,
-                                                              float4* __restrict__ xyzr) {
+__global__ __launch_bounds__(kBlock) void k_cluster_summaries(const Frame* frames, uint32_t npass_csr) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float* __restrict__ cen_x = F.cen_x; const float* __restrict__ cen_y = F.cen_y; const float* __restrict__ cen_z = F.cen_z;
+    const uint32_t* __restrict__ offsets = F.d_offsets;
+    const uint32_t* __restrict__ indices = ((npass_csr - 1) & 1) ? F.idx_b : F.idx_a;
+    float4* __restrict__ xyzr = F.d_xyzr;
     if (st->err) return;
     const bool sel = st->c_from_input != 0;
     const float* __restrict__ x = sel ? st->src_x : cen_x;

@@ -315,6 +315,31 @@ def test_frames_in_flight_on_several_contexts(capi, oracle):
         c.close()
 
 
+def test_batched_frames_match_oracle(capi, oracle):
+    """pcop_submit_batch: frames of different sizes and shapes in one set of launches."""
+    p = synth.params_of("C3")
+    clouds = [synth.make_cloud("C3", n=120_000, seed=200), synth.make_cloud("C3", n=60_000, seed=201),
+              synth.uniform_field(30_000, 7), synth.make_cloud("C3", n=200_000, seed=203), np.zeros((0, 3), dtype=f32)]
+    refs = [oracle.process_xyz(c, **p) for c in clouds]
+    c = capi.Context(200_000, max_frames=6)
+    c.set_params(publish_clouds=1, **p)
+    for rep in range(2):
+        c.submit_batch_host(clouds)
+        got = c.wait_batch()
+        for g, r in zip(got, refs):
+            if len(r["voxel_xyz"]):
+                assert_same_cloud(g["voxel_xyz"], r["voxel_xyz"])
+            assert g["num_voxels"] == len(r["voxel_xyz"])
+            assert_same_clusters(g["offsets"], g["indices"], r["offsets"], r["indices"])
+    k = len(got[3]["offsets"]) - 1
+    xyzr = c.cluster_summaries_frame(3, k)
+    ref = oracle.cluster_summaries(got[3]["voxel_xyz"], got[3]["offsets"], got[3]["indices"])
+    assert np.max(np.abs(xyzr - ref)) <= 1e-5
+    with pytest.raises(capi.PcopError):              # more frames than the context holds
+        c.submit_batch_host(clouds + clouds)
+    c.close()
+
+
 def test_pointcloud2_entry(ctx, oracle):
     """sensor_msgs/PointCloud2 with extra fields (Kinect: xyz + pad + rgb, point_step 32) and row padding."""
     p = synth.params_of("C1")

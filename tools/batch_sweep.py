@@ -1,0 +1,26 @@
+"""Throughput vs batch size (frames per launch) and contexts in flight."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+from pointcloud_obstacle_processing_amd import capi, synth
+p = synth.params_of("C3")
+clouds = [synth.make_cloud("C3", seed=3000 + i) for i in range(4)]
+for B, NC in [(1, 1), (1, 2), (2, 1), (4, 1), (8, 1), (8, 2), (16, 1), (16, 2), (32, 1)]:
+    ctxs = []
+    for ci in range(NC):
+        c = capi.Context(1_000_000, max_frames=B); c.set_params(publish_clouds=0, **p)
+        up = [c.upload_soa(clouds[(ci * B + i) % len(clouds)]) for i in range(B)]
+        ctxs.append((c, [u[0] for u in up], [u[1] for u in up]))
+    for _ in range(3):
+        for c, pp, nn in ctxs: c.submit_batch_device(pp, nn)
+        for c, _, _ in ctxs: c.wait_batch(want_arrays=False)
+    steps = max(3, 64 // (B * NC))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for c, pp, nn in ctxs: c.submit_batch_device(pp, nn)
+        for c, _, _ in ctxs: c.wait_batch(want_arrays=False)
+    dt = time.perf_counter() - t0
+    print("batch %2d x ctx %d: %8.1f frames/s  (%.1f us/frame, step %.2f ms)" % (B, NC, steps * B * NC / dt, 1e6 * dt / (steps * B * NC), 1e3 * dt / steps), flush=True)
+    for c, _, _ in ctxs: c.close()
