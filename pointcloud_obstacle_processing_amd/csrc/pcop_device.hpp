@@ -123,6 +123,8 @@ struct Frame {
     unsigned long long* hkey;         // cell hash table: key+1 (0 = empty)
     uint32_t *hcount, *hmin;          //                  points, smallest point index (= priority)
     uint32_t *cell_start, *cell_list, *parent, *comp_size, *comp_rank;
+    uint4* slot_meta;                 // per occupied slot: {first record, points, smallest point index, 0}
+    uint4* cell_info;                 // per cell (dense), 2 x uint4: {key lo, key hi, first record, points}, {min idx, slot, 0, 0}
     uint32_t *pt_slot, *pt_rank, *pt_root;
     uint32_t *idx_a, *idx_b, *d_offsets;
     float4* d_xyzr;
@@ -383,8 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(Frame* frames, ui
     const float fmax = 3.402823466e+38f;
     float mn0 = fmax, mn1 = fmax, mn2 = fmax, mx0 = -fmax, mx1 = -fmax, mx2 = -fmax;
     uint32_t valid = 0, bad = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float a = x[i], b = y[i], c = z[i];
+    auto take = [&](float a, float b, float c) {
         if (finite3(a, b, c)) {
             ++valid;
             mn0 = a < mn0 ? a : mn0; mx0 = a > mx0 ? a : mx0;
@@ -393,7 +394,20 @@ __global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(Frame* frames, ui
         } else {
             ++bad;
         }
+    };
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    // 16-byte loads when the three planes are 16-byte aligned (they are when n % 4 == 0 or the
+    // planes come from the context's own staging buffers)
+    const bool vec = ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)z)) & 15u) == 0;
+    const uint32_t n4 = vec ? n / 4 : 0;
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    const float4* __restrict__ y4 = reinterpret_cast<const float4*>(y);
+    const float4* __restrict__ z4 = reinterpret_cast<const float4*>(z);
+    for (uint32_t i = gtid; i < n4; i += gsz) {
+        const float4 a = x4[i], b = y4[i], c = z4[i];
+        take(a.x, b.x, c.x); take(a.y, b.y, c.y); take(a.z, b.z, c.z); take(a.w, b.w, c.w);
     }
+    for (uint32_t i = n4 * 4 + gtid; i < n; i += gsz) take(x[i], y[i], z[i]);
     MinMaxPartial p;
     p.mn[0] = mn0; p.mn[1] = mn1; p.mn[2] = mn2; p.mx[0] = mx0; p.mx[1] = mx1; p.mx[2] = mx2;
     p.valid = valid; p.nonfinite = bad;
@@ -904,6 +918,8 @@ __global__ __launch_bounds__(kBlock) void k_slot_apply(Frame* frames) {
     uint32_t* __restrict__ cell_start = F.cell_start; uint32_t* __restrict__ cell_list = F.cell_list;
     uint32_t* __restrict__ parent = F.parent; uint32_t* __restrict__ comp_size = F.comp_size;
     uint32_t* __restrict__ comp_rank = F.comp_rank;
+    uint4* __restrict__ slot_meta = F.slot_meta; uint4* __restrict__ cell_info = F.cell_info;
+    const unsigned long long* __restrict__ hkey = F.hkey; const uint32_t* __restrict__ hmin = F.hmin;
     if (cluster_stage_off(st)) return;
     const uint32_t cap = st->hash_mask + 1u;
     const uint32_t base = blockIdx.x * kScanTile;
@@ -924,7 +940,14 @@ __global__ __launch_bounds__(kBlock) void k_slot_apply(Frame* frames) {
         parent[s0 + k] = s0 + k;
         comp_size[s0 + k] = 0u;
         comp_rank[s0 + k] = 0xFFFFFFFFu;
-        if (v[k]) cell_list[id++] = s0 + k;
+        if (v[k]) {
+            const unsigned long long k1 = hkey[s0 + k];
+            const uint32_t mi = hmin[s0 + k];
+            slot_meta[s0 + k] = make_uint4(run, v[k], mi, 0u);
+            cell_info[2 * (size_t)id] = make_uint4((uint32_t)k1, (uint32_t)(k1 >> 32), run, v[k]);
+            cell_info[2 * (size_t)id + 1] = make_uint4(mi, s0 + k, 0u, 0u);
+            cell_list[id++] = s0 + k;
+        }
         run += v[k];
     }
     if (threadIdx.x == 0 && base + kScanTile >= cap) st->n_cells = before_occ + tot_occ;   // the last tile
@@ -1059,8 +1082,8 @@ __global__ __launch_bounds__(kBlock) void k_cell_hook(const Frame* frames) {
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const float4* __restrict__ rec = F.rec_a;
-    const CellTable tab{F.hkey, F.hcount, F.hmin};
-    const uint32_t* __restrict__ cell_start = F.cell_start; const uint32_t* __restrict__ cell_list = F.cell_list;
+    const unsigned long long* __restrict__ hkey = F.hkey;
+    const uint4* __restrict__ slot_meta = F.slot_meta; const uint4* __restrict__ cell_info = F.cell_info;
     uint32_t* __restrict__ parent = F.parent;
     if (cluster_stage_off(st)) return;
     const uint32_t mask = st->hash_mask, ncell = st->n_cells;
@@ -1069,18 +1092,17 @@ __global__ __launch_bounds__(kBlock) void k_cell_hook(const Frame* frames) {
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
     for (uint32_t ai = blockIdx.x * kWavesPerBlock + w; ai < ncell; ai += nwaves) {
-        const uint32_t a = cell_list[ai];
-        const uint32_t an = tab.hcount[a];
-        const unsigned long long ka = tab.hkey[a] - 1ull;
-        const uint32_t pa = tab.hmin[a];
-        const uint32_t b = stencil_neighbour(tab.hkey, mask, ka, lane, -1);
+        const uint4 i0 = cell_info[2 * (size_t)ai], i1 = cell_info[2 * (size_t)ai + 1];
+        const unsigned long long ka = (((unsigned long long)i0.y << 32) | i0.x) - 1ull;
+        const uint32_t a0 = i0.z, an = i0.w, pa = i1.x, a = i1.y;
+        const uint32_t b = stencil_neighbour(hkey, mask, ka, lane, -1);
+        uint4 mb = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+        if (b != kNoSlot) mb = slot_meta[b];
         // only cells of smaller priority can become the parent
-        const bool cand = b != kNoSlot && tab.hmin[b] < pa;
+        const bool cand = b != kNoSlot && mb.z < pa;
         uint64_t cand_mask = __ballot(cand);
         if (cand_mask == 0) continue;   // parent[a] == a from k_slot_apply
-        const uint32_t a0 = cell_start[a];
-        uint32_t b0 = 0, bn = 0, pb = 0xFFFFFFFFu;
-        if (cand) { b0 = cell_start[b]; bn = tab.hcount[b]; pb = tab.hmin[b]; }
+        const uint32_t b0 = mb.x, bn = cand ? mb.y : 0u, pb = mb.z;
         const uint32_t bn_max = wave_max(bn);
         uint32_t target = a;
         if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
@@ -1123,8 +1145,9 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const float4* __restrict__ rec = F.rec_a;
-    const CellTable tab{F.hkey, F.hcount, F.hmin};
-    const uint32_t* __restrict__ cell_start = F.cell_start; const uint32_t* __restrict__ cell_list = F.cell_list;
+    const unsigned long long* __restrict__ hkey = F.hkey;
+    const uint32_t* __restrict__ hmin = F.hmin;
+    const uint4* __restrict__ slot_meta = F.slot_meta; const uint4* __restrict__ cell_info = F.cell_info;
     uint32_t* __restrict__ parent = F.parent;
     if (cluster_stage_off(st)) return;
     const uint32_t mask = st->hash_mask, ncell = st->n_cells;
@@ -1133,22 +1156,21 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
     for (uint32_t ai = blockIdx.x * kWavesPerBlock + w; ai < ncell; ai += nwaves) {
-        const uint32_t a = cell_list[ai];
-        const uint32_t an = tab.hcount[a];
-        const unsigned long long ka = tab.hkey[a] - 1ull;
-        const uint32_t b = stencil_neighbour(tab.hkey, mask, ka, lane, +1);
+        const uint4 i0 = cell_info[2 * (size_t)ai], i1 = cell_info[2 * (size_t)ai + 1];
+        const unsigned long long ka = (((unsigned long long)i0.y << 32) | i0.x) - 1ull;
+        const uint32_t a0 = i0.z, an = i0.w, a = i1.y;
+        const uint32_t b = stencil_neighbour(hkey, mask, ka, lane, +1);
         bool need = false;
         if (b != kNoSlot) need = uf_find(parent, a) != uf_find(parent, b);
         uint64_t need_mask = __ballot(need);
         if (need_mask == 0) continue;
-        const uint32_t a0 = cell_start[a];
         uint32_t b0 = 0, bn = 0;
-        if (need) { b0 = cell_start[b]; bn = tab.hcount[b]; }
+        if (need) { const uint4 mb = slot_meta[b]; b0 = mb.x; bn = mb.y; }
         const uint32_t bn_max = wave_max(bn);
         if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
             if (lane < an) s_pa[w][lane] = rec[a0 + lane];
             __builtin_amdgcn_wave_barrier();
-            if (need && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2)) uf_union(parent, tab.hmin, a, b);
+            if (need && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2)) uf_union(parent, hmin, a, b);
             __builtin_amdgcn_wave_barrier();
         } else {
             while (need_mask) {
@@ -1159,7 +1181,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
                 if (lane == 0) { ra = uf_find(parent, a); rb = uf_find(parent, cb); }
                 ra = __shfl(ra, 0, kWave); rb = __shfl(rb, 0, kWave);
                 if (ra == rb) continue;
-                if (wave_pair_hit(rec, a0, an, cb0, cbn, r2) && lane == 0) uf_union(parent, tab.hmin, a, cb);
+                if (wave_pair_hit(rec, a0, an, cb0, cbn, r2) && lane == 0) uf_union(parent, hmin, a, cb);
             }
         }
     }
