@@ -194,7 +194,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
         mark(c, "k_slot_apply");
         k_cell_place<<<tg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_place");
-        k_cell_hook<<<wg, kBlock, 0, s>>>(fr);
+        k_cell_hook<<<dim3(std::min(8192u, std::max(1u, div_up(nb, kBlock / kHookGroup))), nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_hook");
         k_cell_compress<<<tg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_compress");

@@ -1077,8 +1077,23 @@ __device__ __forceinline__ bool wave_pair_hit(const float4* __restrict__ rec, ui
     return hit;
 }
 
+// Hooking only needs SOME adjacent cell of smaller priority, so it looks at the 13 backward cells
+// of the 3x3x3 neighbourhood only: four cells per wave, 16 lanes each (13 used).
+constexpr int kHookGroup = 16;
+constexpr int kHookStencil = 13;
+constexpr int kHookPtsCap = 32;
+
+// backward offset t (0..12) of the 3x3x3 stencil: (0,0,-1) ; (0,-1,*) ; (-1,*,*)
+__device__ __forceinline__ long long hook_offset(uint32_t t) {
+    int dx, dy, dz;
+    if (t == 0) { dx = -1; dy = 0; dz = 0; }
+    else if (t < 4) { dx = (int)t - 2; dy = -1; dz = 0; }
+    else { const uint32_t v = t - 4; dx = (int)(v % 3) - 1; dy = (int)(v / 3) - 1; dz = -1; }
+    return (long long)dx + ((long long)dy << 21) + ((long long)dz << 42);
+}
+
 __global__ __launch_bounds__(kBlock) void k_cell_hook(const Frame* frames) {
-    __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
+    __shared__ float4 s_pa[kBlock / kHookGroup][kHookPtsCap];
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const float4* __restrict__ rec = F.rec_a;
@@ -1088,41 +1103,49 @@ __global__ __launch_bounds__(kBlock) void k_cell_hook(const Frame* frames) {
     if (cluster_stage_off(st)) return;
     const uint32_t mask = st->hash_mask, ncell = st->n_cells;
     const float r2 = st->r2;
-    const uint32_t w = threadIdx.x / kWave;
-    const uint32_t lane = lane_id();
-    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
-    for (uint32_t ai = blockIdx.x * kWavesPerBlock + w; ai < ncell; ai += nwaves) {
-        const uint4 i0 = cell_info[2 * (size_t)ai], i1 = cell_info[2 * (size_t)ai + 1];
+    const uint32_t g = threadIdx.x / kHookGroup;          // group in block
+    const uint32_t gl = threadIdx.x % kHookGroup;         // lane in group
+    const uint32_t ngroups = gridDim.x * (kBlock / kHookGroup);
+    // trip count is uniform per wave: the four groups of a wave stride together
+    const uint32_t wave_first = (blockIdx.x * (kBlock / kHookGroup) + (threadIdx.x / kWave) * (kWave / kHookGroup));
+    for (uint32_t base = wave_first; base < ncell; base += ngroups) {
+        const uint32_t ai = base + (g % (kWave / kHookGroup));
+        const bool live = ai < ncell;
+        uint4 i0 = make_uint4(1u, 0u, 0u, 0u), i1 = make_uint4(0u, 0u, 0u, 0u);
+        if (live) { i0 = cell_info[2 * (size_t)ai]; i1 = cell_info[2 * (size_t)ai + 1]; }
         const unsigned long long ka = (((unsigned long long)i0.y << 32) | i0.x) - 1ull;
         const uint32_t a0 = i0.z, an = i0.w, pa = i1.x, a = i1.y;
-        const uint32_t b = stencil_neighbour(hkey, mask, ka, lane, -1);
+        uint32_t b = kNoSlot;
+        if (live && gl < (uint32_t)kHookStencil) b = hash_lookup(hkey, mask, (unsigned long long)((long long)ka + hook_offset(gl)));
         uint4 mb = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
         if (b != kNoSlot) mb = slot_meta[b];
-        // only cells of smaller priority can become the parent
-        const bool cand = b != kNoSlot && mb.z < pa;
-        uint64_t cand_mask = __ballot(cand);
-        if (cand_mask == 0) continue;   // parent[a] == a from k_slot_apply
+        const bool cand = b != kNoSlot && mb.z < pa;     // only cells of smaller priority can become the parent
         const uint32_t b0 = mb.x, bn = cand ? mb.y : 0u, pb = mb.z;
-        const uint32_t bn_max = wave_max(bn);
-        uint32_t target = a;
-        if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
-            if (lane < an) s_pa[w][lane] = rec[a0 + lane];
-            __builtin_amdgcn_wave_barrier();
-            const bool hit = cand && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2);
-            const unsigned long long best = wave_min_u64(hit ? (((unsigned long long)pb << 32) | b) : ~0ull);
-            if (best != ~0ull) target = (uint32_t)best;
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            // big cells: candidates in ascending priority, whole wave per pair, stop at the first hit
-            while (cand_mask) {
-                const unsigned long long pick = wave_min_u64(((cand_mask >> lane) & 1ull) ? (((unsigned long long)pb << 32) | lane) : ~0ull);
-                const int t = (int)(uint32_t)pick;
-                cand_mask &= ~(1ull << t);
-                const uint32_t cb = __shfl(b, t, kWave), cb0 = __shfl(b0, t, kWave), cbn = __shfl(bn, t, kWave);
-                if (wave_pair_hit(rec, a0, an, cb0, cbn, r2)) { target = cb; break; }
+        // stage A's points (per group) when they fit
+        const bool small = an <= (uint32_t)kHookPtsCap;
+        if (live && small) for (uint32_t t = gl; t < an; t += kHookGroup) s_pa[g][t] = rec[a0 + t];
+        __builtin_amdgcn_wave_barrier();
+        bool hit = false;
+        if (cand) {
+            if (small) {
+                hit = lane_pair_hit(s_pa[g], an, rec, b0, bn, r2);
+            } else {   // a big cell: this lane walks A from memory
+                for (uint32_t ia = 0; ia < an && !hit; ++ia) {
+                    const float4 pa4 = rec[a0 + ia];
+                    for (uint32_t ib = 0; ib < bn; ++ib)
+                        if (l2_simple(pa4, rec[b0 + ib]) < r2) { hit = true; break; }
+                }
             }
         }
-        if (lane == 0 && target != a) parent[a] = target;   // strictly decreasing priority: a forest
+        // smallest priority among the group's hits
+        unsigned long long best = hit ? (((unsigned long long)pb << 32) | b) : ~0ull;
+#pragma unroll
+        for (int d = kHookGroup / 2; d > 0; d >>= 1) {
+            const unsigned long long o = __shfl_xor(best, d, kWave);
+            best = o < best ? o : best;
+        }
+        if (live && gl == 0 && best != ~0ull) parent[a] = (uint32_t)best;   // strictly decreasing priority: a forest
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1160,8 +1183,15 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
         const unsigned long long ka = (((unsigned long long)i0.y << 32) | i0.x) - 1ull;
         const uint32_t a0 = i0.z, an = i0.w, a = i1.y;
         const uint32_t b = stencil_neighbour(hkey, mask, ka, lane, +1);
+        // after hook + compress almost every neighbour already points at A's root: one load decides
+        uint32_t ra = 0;
+        if (lane == 0) ra = uf_find(parent, a);
+        ra = __shfl(ra, 0, kWave);
         bool need = false;
-        if (b != kNoSlot) need = uf_find(parent, a) != uf_find(parent, b);
+        if (b != kNoSlot) {
+            const uint32_t pb = ld_agent(parent + b);
+            if (pb != ra) need = uf_find(parent, b) != ra;
+        }
         uint64_t need_mask = __ballot(need);
         if (need_mask == 0) continue;
         uint32_t b0 = 0, bn = 0;
