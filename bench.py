@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/
 def kernel_alg_bytes(name, occurrence, n, m, n_cells):
     """Algorithmic (compulsory) bytes of one launch of a kernel of the frame; DESIGN.md §Roofline.
     n = input points, m = voxels.  `occurrence` = index of this launch among launches of the same name."""
-    if name == "k_minmax_voxel_setup":
+    if name == "k_minmax":
         return 12 * n
     if name == "k_radix_hist":
         return (12 if occurrence == 0 else 16) * n

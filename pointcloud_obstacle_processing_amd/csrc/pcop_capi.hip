@@ -167,8 +167,10 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
     const dim3 sg(std::max(1u, div_up(nb, kScanTile)), nf);    // scan tiles over points
     const dim3 tg(stride_grid(nb), nf);
     if (kind != kFrameClusterOnly) {
-        k_minmax_voxel_setup<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, c->npass_voxel, (uint32_t)MAXB);
-        mark(c, "k_minmax_voxel_setup");
+        k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr);
+        mark(c, "k_minmax");
+        k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB);
+        mark(c, "k_voxel_setup");
         for (uint32_t p = 0; p < c->npass_voxel; ++p) {
             k_radix_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
             mark(c, "k_radix_hist");

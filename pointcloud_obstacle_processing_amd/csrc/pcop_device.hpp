@@ -371,9 +371,8 @@ __device__ __forceinline__ void reduce_partials_lds(MinMaxPartial* s_p) {   // k
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(Frame* frames, uint32_t npass, uint32_t maxbits) {
+__global__ __launch_bounds__(kBlock) void k_minmax(Frame* frames) {
     __shared__ MinMaxPartial s_p[kBlock];
-    __shared__ uint32_t s_last;
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     MinMaxPartial* partials = F.partials;
@@ -413,29 +412,25 @@ __global__ __launch_bounds__(kBlock) void k_minmax_voxel_setup(Frame* frames, ui
     p.valid = valid; p.nonfinite = bad;
     s_p[threadIdx.x] = p;
     reduce_partials_lds(s_p);
-    // publish the block's partial, then take a ticket; the block that draws the last one finishes
-    if (threadIdx.x == 0) {
-        uint32_t* dst = reinterpret_cast<uint32_t*>(partials + blockIdx.x);
-        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(&s_p[0]);
-        for (int k = 0; k < 8; ++k) st_agent(dst + k, srcw[k]);
-        __threadfence();
-        const uint32_t t = atomicAdd(&st->ticket, 1u);
-        s_last = (t == gridDim.x - 1) ? 1u : 0u;
-        if (s_last) __threadfence();
-    }
-    __syncthreads();
-    if (!s_last) return;
+    if (threadIdx.x == 0) partials[blockIdx.x] = s_p[0];
+}
+
+// one block per frame: reduce the block partials and derive the voxel grid
+__global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t nblocks, uint32_t npass, uint32_t maxbits) {
+    __shared__ MinMaxPartial s_p[kBlock];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    if (st->kind == kFrameClusterOnly) return;
+    const MinMaxPartial* __restrict__ partials = F.partials;
+    const float fmax = 3.402823466e+38f;
     MinMaxPartial q;
     for (int a = 0; a < 3; ++a) { q.mn[a] = fmax; q.mx[a] = -fmax; }
     q.valid = 0; q.nonfinite = 0;
-    for (uint32_t i = threadIdx.x; i < gridDim.x; i += kBlock) {
-        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(partials + i);
-        uint32_t wds[8];
-        for (int k = 0; k < 8; ++k) wds[k] = ld_agent(srcw + k);
-        for (int a = 0; a < 3; ++a) { q.mn[a] = fminf(q.mn[a], u2f(wds[a])); q.mx[a] = fmaxf(q.mx[a], u2f(wds[3 + a])); }
-        q.valid += wds[6]; q.nonfinite += wds[7];
+    for (uint32_t i = threadIdx.x; i < nblocks; i += kBlock) {
+        const MinMaxPartial p = partials[i];
+        for (int a = 0; a < 3; ++a) { q.mn[a] = fminf(q.mn[a], p.mn[a]); q.mx[a] = fmaxf(q.mx[a], p.mx[a]); }
+        q.valid += p.valid; q.nonfinite += p.nonfinite;
     }
-    __syncthreads();
     s_p[threadIdx.x] = q;
     reduce_partials_lds(s_p);
     if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass, maxbits);
@@ -785,12 +780,18 @@ struct CellTable {
     uint32_t* hmin;
 };
 
-__device__ __forceinline__ uint32_t cell_hash(unsigned long long key) {
-    unsigned long long h = key * 0x9E3779B97F4A7C15ull;
+// The table is 64 interleaved sub-tables: a cell may only sit in slots whose low 6 bits equal its
+// index inside its 4x4x4 block of cells, and the bucket (slot >> 6) is hashed from the block's
+// key.  Cells of one block therefore share a 64-slot bucket, so the slots, parents, metadata and
+// point records of spatial neighbours share cache lines.  Probing steps from bucket to bucket.
+__device__ __forceinline__ uint32_t cell_home(unsigned long long key, uint32_t mask) {
+    const unsigned long long bx = (key & 0x1FFFFFull) >> 2, by = ((key >> 21) & 0x1FFFFFull) >> 2, bz = (key >> 42) >> 2;
+    unsigned long long h = (bx | (by << 19) | (bz << 38)) * 0x9E3779B97F4A7C15ull;
     h ^= h >> 29;
     h *= 0xBF58476D1CE4E5B9ull;
     h ^= h >> 32;
-    return (uint32_t)h;
+    const uint32_t idx = (uint32_t)(key & 3ull) | ((uint32_t)((key >> 21) & 3ull) << 2) | ((uint32_t)((key >> 42) & 3ull) << 4);
+    return (((uint32_t)h << 6) | idx) & mask;
 }
 
 __device__ __forceinline__ unsigned long long pack_cell(long long cx, long long cy, long long cz) {
@@ -800,24 +801,24 @@ __device__ __forceinline__ unsigned long long pack_cell(long long cx, long long 
 
 __device__ __forceinline__ uint32_t hash_find_or_insert(unsigned long long* hkey, uint32_t mask, unsigned long long key) {
     const unsigned long long want = key + 1ull;
-    uint32_t slot = cell_hash(key) & mask;
+    uint32_t slot = cell_home(key, mask);
     while (true) {
         unsigned long long k = hkey[slot];
         if (k == 0ull) k = atomicCAS(hkey + slot, 0ull, want);
         if (k == 0ull || k == want) return slot;
-        slot = (slot + 1u) & mask;
+        slot = (slot + 64u) & mask;
     }
 }
 
 __device__ __forceinline__ uint32_t hash_lookup(const unsigned long long* __restrict__ hkey, uint32_t mask,
                                                 unsigned long long key) {
     const unsigned long long want = key + 1ull;
-    uint32_t slot = cell_hash(key) & mask;
+    uint32_t slot = cell_home(key, mask);
     while (true) {
         const unsigned long long k = hkey[slot];
         if (k == want) return slot;
         if (k == 0ull) return kNoSlot;
-        slot = (slot + 1u) & mask;
+        slot = (slot + 64u) & mask;
     }
 }
 
