@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpcop.so")
+LIB_PATH = os.environ.get("PCOP_LIB", os.path.join(_HERE, "csrc", "libpcop.so"))   # PCOP_LIB: experiment builds
 
 LAYOUT_AOS16, LAYOUT_SOA, LAYOUT_AOS12 = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1

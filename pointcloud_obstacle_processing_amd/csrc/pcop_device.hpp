@@ -38,7 +38,10 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxBits = 11;                     // widest radix digit any kernel variant supports
 constexpr int kMaxBins = (1 << kMaxBits) + 1;    // + 1 trash bin (non-finite points)
 constexpr int kNarrowBits = 8;                   // digit limit of the small-LDS kernel variants
-constexpr int kItems = 8;                        // records per thread in the partition kernels
+#ifndef PCOP_ITEMS
+#define PCOP_ITEMS 8
+#endif
+constexpr int kItems = PCOP_ITEMS;               // records per thread in the partition kernels
 constexpr int kTile = kBlock * kItems;           // records per partition block
 constexpr int kMaxPasses = 4;                    // 4 x 8 bits = 3 x 11 bits >= 32-bit keys
 constexpr int kScanItems = 4;                    // elements per thread in flag-scan kernels

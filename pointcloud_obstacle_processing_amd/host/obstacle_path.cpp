@@ -1,0 +1,151 @@
+#include "obstacle_path.hpp"
+
+#include <cstring>
+#include <stdexcept>
+
+namespace pcop_host {
+
+namespace {
+pcop_ctx* g_ctx = nullptr;
+size_t g_cap = 0;
+
+void check(pcop_ctx* c, int rc, const char* what) {
+    if (rc == PCOP_OK) return;
+    std::string msg = std::string(what) + ": " + pcop_status_string(rc);
+    if (c) msg += std::string(" (") + pcop_last_error(c) + ")";
+    throw std::runtime_error(msg);
+}
+}  // namespace
+
+pcop_ctx* default_context(size_t min_points) {
+    if (g_ctx && g_cap >= min_points) return g_ctx;
+    release_default_context();
+    size_t cap = 1u << 20;
+    while (cap < min_points) cap <<= 1;
+    pcop_ctx* c = nullptr;
+    check(nullptr, pcop_create(&c, 0, cap), "pcop_create");
+    g_ctx = c; g_cap = cap;
+    return g_ctx;
+}
+
+void release_default_context() {
+    if (g_ctx) pcop_destroy(g_ctx);
+    g_ctx = nullptr; g_cap = 0;
+}
+
+void downsample_cloud(const PointCloudXYZ::Ptr& input_cloud, PointCloudXYZ& output_cloud, float leaf_size,
+                      Publisher<PointCloud2>& pub, bool publish) {
+    const size_t n = input_cloud->points.size();
+    pcop_ctx* c = default_context(n);
+    pcop_params p{};
+    pcop_get_params(c, &p);
+    p.leaf = leaf_size;                                   // sor.setLeafSize(leaf, leaf, leaf)   od.cpp:284
+    check(c, pcop_set_params(c, &p), "pcop_set_params");
+    output_cloud.points.resize(n);
+    size_t m = 0;
+    int passthrough = 0;
+    check(c, pcop_voxel_downsample(c, n ? &input_cloud->points[0].x : nullptr, PCOP_LAYOUT_AOS16, n,
+                                   input_cloud->is_dense ? 1 : 0, n ? &output_cloud.points[0].x : nullptr, &m, &passthrough),
+          "pcop_voxel_downsample");                       // sor.filter(output_cloud)               od.cpp:285
+    output_cloud.points.resize(m);
+    output_cloud.header = input_cloud->header;            // Filter::filter copies the header
+    output_cloud.width = (uint32_t)m; output_cloud.height = 1;
+    output_cloud.is_dense = passthrough ? input_cloud->is_dense : true;
+    if (publish) {                                        // od.cpp:288-295
+        PointCloud2 publish_cloud;
+        to_pointcloud2(output_cloud, &publish_cloud);
+        publish_cloud.header.frame_id = "world";
+        pub.publish(publish_cloud);
+    }
+}
+
+void extract_euclidian_clusters(PointCloudXYZ::Ptr& input_cloud, std::vector<PointIndices>& cluster_indices,
+                                float cluster_tolerance, int min_cluster_size, int max_cluster_size,
+                                KdTreeHandle::Ptr& search_method) {
+    (void)search_method;   // ec.setSearchMethod(tree): the neighbour index is rebuilt on the GPU per call
+    const size_t m = input_cloud->points.size();
+    pcop_ctx* c = default_context(m);
+    pcop_params p{};
+    pcop_get_params(c, &p);
+    p.tol = cluster_tolerance; p.min_cluster = min_cluster_size; p.max_cluster = max_cluster_size;   // od.cpp:447-449
+    if (!(p.leaf > 0.0f)) p.leaf = 1.0f;
+    check(c, pcop_set_params(c, &p), "pcop_set_params");
+    std::vector<int32_t> offsets(m + 1), indices(m ? m : 1);
+    int32_t k = 0;
+    check(c, pcop_euclidean_clusters(c, m ? &input_cloud->points[0].x : nullptr, PCOP_LAYOUT_AOS16, m, offsets.data(),
+                                     indices.data(), &k),
+          "pcop_euclidean_clusters");                     // ec.extract(cluster_indices)           od.cpp:454
+    cluster_indices.clear();
+    cluster_indices.resize((size_t)k);
+    for (int32_t cidx = 0; cidx < k; ++cidx) {
+        PointIndices& pi = cluster_indices[(size_t)cidx];
+        pi.header = input_cloud->header;
+        pi.indices.assign(indices.begin() + offsets[cidx], indices.begin() + offsets[cidx + 1]);
+    }
+}
+
+ObstacleNode::ObstacleNode(const NodeParams& prm, size_t max_points, int device) : params(prm) {
+    downsample_publisher.topic = "voxel_grid"; downsample_publisher.queue_size = 1;
+    centroid_publisher.topic = "centroids"; centroid_publisher.queue_size = 1;
+    euc_cluster_publisher.topic = "euc_clusters"; euc_cluster_publisher.queue_size = 5;
+    check(nullptr, pcop_create(&ctx_, device, max_points), "pcop_create");
+}
+
+ObstacleNode::~ObstacleNode() {
+    if (ctx_) pcop_destroy(ctx_);
+}
+
+int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
+    uint32_t ox = 0, oy = 0, oz = 0;
+    if (!find_xyz_fields(cloud_msg, &ox, &oy, &oz, &error_)) return PCOP_ERR_ARG;
+    pcop_params p{};
+    p.leaf = params.downsample_size;                 // od.cpp:740
+    p.tol = params.euc_cluster_tolerance;            // od.cpp:796
+    p.min_cluster = params.euc_min_cluster_size;
+    p.max_cluster = params.euc_max_cluster_size;
+    p.publish_clouds = 1;                            // the voxel cloud is needed on the host for euc_clusters
+    int rc = pcop_set_params(ctx_, &p);
+    if (rc) { error_ = pcop_last_error(ctx_); return rc; }
+    pcop_result r{};
+    rc = pcop_process_pointcloud2(ctx_, cloud_msg.data.data(), cloud_msg.width, cloud_msg.height, cloud_msg.point_step,
+                                  cloud_msg.row_step, ox, oy, oz, cloud_msg.is_bigendian ? 1 : 0, cloud_msg.is_dense ? 1 : 0, &r);
+    if (rc) { error_ = pcop_last_error(ctx_); return rc; }
+    passthrough = r.passthrough;
+    // the downsampled cloud (statistical_outlier_input_cloud, od.cpp:740-741)
+    voxel_cloud.header = cloud_msg.header;
+    voxel_cloud.points.resize((size_t)r.num_voxels);
+    for (int32_t i = 0; i < r.num_voxels; ++i) {
+        PointXYZ& q = voxel_cloud.points[(size_t)i];
+        q.x = r.voxel_xyz[3 * i]; q.y = r.voxel_xyz[3 * i + 1]; q.z = r.voxel_xyz[3 * i + 2]; q.pad = 1.0f;
+    }
+    voxel_cloud.width = (uint32_t)r.num_voxels; voxel_cloud.height = 1; voxel_cloud.is_dense = true;
+    if (params.publish_point_clouds) {               // od.cpp:288-295
+        PointCloud2 msg;
+        to_pointcloud2(voxel_cloud, &msg);
+        msg.header.frame_id = "world";
+        downsample_publisher.publish(msg);
+    }
+    // std::vector<pcl::PointIndices> euc_cluster_indices (od.cpp:793-797)
+    euc_cluster_indices.assign((size_t)r.num_clusters, PointIndices());
+    for (int32_t c = 0; c < r.num_clusters; ++c)
+        euc_cluster_indices[(size_t)c].indices.assign(r.indices + r.offsets[c], r.indices + r.offsets[c + 1]);
+    // "centroids": one PointWithRad per cluster (the commented-out publish of od.cpp:857-858)
+    PointIndicesArray centroids;
+    centroids.points.resize((size_t)r.num_clusters);
+    if (r.num_clusters) {
+        rc = pcop_cluster_summaries(ctx_, &centroids.points[0].x, r.num_clusters);
+        if (rc) { error_ = pcop_last_error(ctx_); return rc; }
+    }
+    centroid_publisher.publish(centroids);
+    // "euc_clusters": the points of all kept clusters, frame "/world" (od.cpp:861-866)
+    PointCloudXYZ clustered;
+    clustered.points.reserve((size_t)r.num_indices);
+    for (int32_t j = 0; j < r.num_indices; ++j) clustered.points.push_back(voxel_cloud.points[(size_t)r.indices[j]]);
+    PointCloud2 clusters;
+    to_pointcloud2(clustered, &clusters);
+    clusters.header.frame_id = "/world";
+    euc_cluster_publisher.publish(clusters);
+    return PCOP_OK;
+}
+
+}  // namespace pcop_host

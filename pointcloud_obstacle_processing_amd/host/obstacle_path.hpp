@@ -1,0 +1,63 @@
+// obstacle_path.hpp — host-side mirror of the reference's hot path (od.cpp = minibot_cr18/src/
+// obstacle_detection.cpp), same function names and argument meaning, on top of the C ABI
+// (include/pcop.h).  No PCL, no ROS: a ROS build wraps these with the adapter in
+// ros1/obstacle_detection_mi355x.cpp.
+//
+//   downsample_cloud            od.cpp:271-296     VoxelGrid + optional publish on "voxel_grid"
+//   extract_euclidian_clusters  od.cpp:430-455     EuclideanClusterExtraction
+//   ObstacleNode::cloud_cb      od.cpp:674-928     the part of the callback the north star names:
+//                                                  PointCloud2 in -> voxel grid -> clusters ->
+//                                                  "voxel_grid", "centroids", "euc_clusters" out
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/pcop.h"
+#include "params_yaml.hpp"
+#include "pcop_types.hpp"
+#include "pointcloud2.hpp"
+
+namespace pcop_host {
+
+// One GPU context shared by the free functions below (the reference keeps its state in globals too,
+// od.cpp:69-125).  Throws std::runtime_error when no GPU / libpcop is unusable: there is no CPU path.
+pcop_ctx* default_context(size_t min_points);
+void release_default_context();
+
+// od.cpp:271-296.  Same signature with the stand-in types; leaf_size is the cubic VoxelGrid leaf.
+void downsample_cloud(const PointCloudXYZ::Ptr& input_cloud, PointCloudXYZ& output_cloud, float leaf_size,
+                      Publisher<PointCloud2>& pub, bool publish);
+
+// od.cpp:430-455.  search_method is kept for call compatibility (the index is built on the GPU).
+void extract_euclidian_clusters(PointCloudXYZ::Ptr& input_cloud, std::vector<PointIndices>& cluster_indices,
+                                float cluster_tolerance, int min_cluster_size, int max_cluster_size,
+                                KdTreeHandle::Ptr& search_method);
+
+// The node surface of the path: same topic names, queue sizes and parameter keys as od.cpp:930-1015.
+class ObstacleNode {
+public:
+    static constexpr const char* kPointTopic = "/kinect2/qhd/points";   // od.cpp:80
+    explicit ObstacleNode(const NodeParams& params, size_t max_points = 1u << 20, int device = 0);
+    ~ObstacleNode();
+    ObstacleNode(const ObstacleNode&) = delete;
+    ObstacleNode& operator=(const ObstacleNode&) = delete;
+
+    // The hot path of cloud_cb for one (already accumulated) cloud.  Returns a pcop_status.
+    int cloud_cb(const PointCloud2& cloud_msg);
+    const std::string& last_error() const { return error_; }
+
+    NodeParams params;
+    Publisher<PointCloud2> downsample_publisher;        // "voxel_grid",   queue 1   (od.cpp:1004)
+    Publisher<PointIndicesArray> centroid_publisher;    // "centroids",    queue 1   (od.cpp:1009)
+    Publisher<PointCloud2> euc_cluster_publisher;       // "euc_clusters", queue 5   (od.cpp:1010)
+    std::vector<PointIndices> euc_cluster_indices;      // od.cpp:793
+    PointCloudXYZ voxel_cloud;                          // statistical_outlier_input_cloud in od.cpp:740
+    int passthrough = 0;
+
+private:
+    pcop_ctx* ctx_ = nullptr;
+    std::string error_;
+};
+
+}  // namespace pcop_host

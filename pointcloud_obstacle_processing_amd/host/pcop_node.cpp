@@ -1,0 +1,89 @@
+// pcop_node — ROS-free stand-in for the node's hot path: reads the same params.yaml tree and a
+// serialized sensor_msgs/PointCloud2, runs the path on the GPU and writes what the node would
+// publish on "voxel_grid", "centroids" and "euc_clusters", plus the cluster indices.
+//
+//   pcop_node --params params.yaml --cloud in.pc2 --out outdir [--device 0] [--stage-api]
+//
+// --stage-api runs the two free functions (downsample_cloud, extract_euclidian_clusters) the way
+// cloud_cb calls them (od.cpp:740, od.cpp:791-797) instead of the fused frame entry.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+
+#include "obstacle_path.hpp"
+
+using namespace pcop_host;
+
+static void write_indices(const std::string& path, const std::vector<PointIndices>& clusters) {
+    std::ofstream f(path);
+    f << clusters.size() << "\n";
+    for (const PointIndices& c : clusters) {
+        f << c.indices.size();
+        for (int i : c.indices) f << " " << i;
+        f << "\n";
+    }
+}
+
+int main(int argc, char** argv) {
+    std::string params_path, cloud_path, out_dir = ".";
+    int device = 0;
+    bool stage_api = false;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--params" && i + 1 < argc) params_path = argv[++i];
+        else if (a == "--cloud" && i + 1 < argc) cloud_path = argv[++i];
+        else if (a == "--out" && i + 1 < argc) out_dir = argv[++i];
+        else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (a == "--stage-api") stage_api = true;
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    if (params_path.empty() || cloud_path.empty()) {
+        std::fprintf(stderr, "usage: pcop_node --params params.yaml --cloud in.pc2 --out outdir [--device N] [--stage-api]\n");
+        return 2;
+    }
+    std::string err;
+    NodeParams prm;
+    if (!load_node_params(params_path, &prm, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    PointCloud2 msg;
+    if (!read_pointcloud2_file(cloud_path, &msg, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    try {
+        if (stage_api) {
+            PointCloudXYZ::Ptr in(new PointCloudXYZ);
+            if (!from_pointcloud2(msg, in.get(), &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            Publisher<PointCloud2> pub;
+            pub.topic = "voxel_grid";
+            PointCloudXYZ::Ptr vox(new PointCloudXYZ);
+            downsample_cloud(in, *vox, prm.downsample_size, pub, prm.publish_point_clouds);          // od.cpp:740
+            KdTreeHandle::Ptr tree(new KdTreeHandle);
+            tree->setInputCloud(vox);                                                                 // od.cpp:791-792
+            std::vector<PointIndices> clusters;
+            extract_euclidian_clusters(vox, clusters, prm.euc_cluster_tolerance, prm.euc_min_cluster_size,
+                                       prm.euc_max_cluster_size, tree);                              // od.cpp:796
+            if (pub.published && !write_pointcloud2_file(out_dir + "/voxel_grid.pc2", pub.last, &err)) throw std::runtime_error(err);
+            write_indices(out_dir + "/cluster_indices.txt", clusters);
+            std::printf("stage-api: N=%zu M=%zu K=%zu\n", in->size(), vox->size(), clusters.size());
+            release_default_context();
+            return 0;
+        }
+        ObstacleNode node(prm, std::max<size_t>((size_t)msg.width * msg.height, 1024), device);
+        const int rc = node.cloud_cb(msg);
+        if (rc) { std::fprintf(stderr, "cloud_cb failed: %s (%s)\n", pcop_status_string(rc), node.last_error().c_str()); return 1; }
+        if (node.downsample_publisher.published &&
+            !write_pointcloud2_file(out_dir + "/voxel_grid.pc2", node.downsample_publisher.last, &err)) throw std::runtime_error(err);
+        if (!write_pointcloud2_file(out_dir + "/euc_clusters.pc2", node.euc_cluster_publisher.last, &err)) throw std::runtime_error(err);
+        {
+            std::ofstream f(out_dir + "/centroids.txt");   // PointIndicesArray: one "x y z r" line per PointWithRad
+            f.precision(9);
+            for (const PointWithRad& p : node.centroid_publisher.last.points) f << p.x << " " << p.y << " " << p.z << " " << p.r << "\n";
+        }
+        write_indices(out_dir + "/cluster_indices.txt", node.euc_cluster_indices);
+        std::printf("frame: N=%u M=%zu K=%zu passthrough=%d\n", msg.width * msg.height, node.voxel_cloud.size(),
+                    node.euc_cluster_indices.size(), node.passthrough);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
