@@ -33,13 +33,13 @@ def kernel_alg_bytes(name, occurrence, n, m, n_cells):
     if name == "k_minmax":
         return 12 * n
     if name == "k_radix_hist":
-        return (12 if occurrence == 0 else 16) * n
+        return 12 * n                   # xyz planes (pass 0) or packed 12-byte records
     if name == "k_radix_scatter":
-        return ((12 if occurrence == 0 else 16) + 16) * n
+        return (12 + 12) * n            # read every record once, write it once
     if name == "k_heads_count":
-        return 16 * n
+        return 12 * n
     if name == "k_voxel_reduce":
-        return 16 * n + 12 * m
+        return 12 * n + 12 * m
     if name == "k_cell_insert":
         return 12 * m + 8 * m
     if name == "k_cell_place":

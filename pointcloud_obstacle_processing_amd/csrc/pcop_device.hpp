@@ -248,13 +248,19 @@ __device__ __forceinline__ bool make_plan(RadixPlan* pl, uint32_t key_bits, uint
 // ------------------------------------------------------------------------------------------
 // record sources and the voxel key
 // ------------------------------------------------------------------------------------------
-// Pass 0 reads the frame's input planes (+ implicit idx), later passes the 16-byte records the
-// previous pass wrote; pass p writes rec_a when p is even, rec_b when odd.
+// Voxel-stage records are packed 12-byte xyz triples: the partition is stable, so the point index
+// never has to travel.  Pass 0 reads the frame's input planes, later passes the records the previous
+// pass wrote; pass p writes rec_a when p is even, rec_b when odd.
+struct Rec3 {
+    float x, y, z;
+};
 struct RecSrc {
     const float* x; const float* y; const float* z;
-    const float4* r;   // null on pass 0
-    __device__ __forceinline__ float4 load(uint32_t i) const {
-        return r ? r[i] : make_float4(x[i], y[i], z[i], u2f(i));
+    const Rec3* r;   // null on pass 0
+    __device__ __forceinline__ Rec3 load(uint32_t i) const {
+        if (r) return r[i];
+        Rec3 v; v.x = x[i]; v.y = y[i]; v.z = z[i];
+        return v;
     }
 };
 
@@ -267,7 +273,8 @@ struct VoxelKey {
         fb0 = (float)st->min_b[0]; fb1 = (float)st->min_b[1]; fb2 = (float)st->min_b[2];
         mul1 = st->mul[1]; mul2 = st->mul[2];
     }
-    __device__ __forceinline__ uint32_t operator()(const float4& p) const {
+    template <class P>
+    __device__ __forceinline__ uint32_t operator()(const P& p) const {
         const int i0 = (int)(floorf(p.x * inv) - fb0);
         const int i1 = (int)(floorf(p.y * inv) - fb1);
         const int i2 = (int)(floorf(p.z * inv) - fb2);
@@ -448,12 +455,12 @@ __global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t 
 __device__ __forceinline__ RecSrc rec_source(const Frame& F, int pass) {
     RecSrc s;
     s.x = F.st.src_x; s.y = F.st.src_y; s.z = F.st.src_z;
-    s.r = pass == 0 ? nullptr : (((pass - 1) & 1) ? F.rec_b : F.rec_a);
+    s.r = pass == 0 ? nullptr : reinterpret_cast<const Rec3*>(((pass - 1) & 1) ? F.rec_b : F.rec_a);
     return s;
 }
 // output of the last of npass partition passes
-__device__ __forceinline__ const float4* sorted_records(const Frame& F, uint32_t npass) {
-    return ((npass - 1) & 1) ? F.rec_b : F.rec_a;
+__device__ __forceinline__ const Rec3* sorted_records(const Frame& F, uint32_t npass) {
+    return reinterpret_cast<const Rec3*>(((npass - 1) & 1) ? F.rec_b : F.rec_a);
 }
 
 struct PassInfo {
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_hist(const Frame* frames, int 
     for (int j = 0; j < kItems; ++j) {
         const uint32_t i = wbase + j * kWave;
         if (i < pi.count) {
-            const float4 r = src.load(i);
+            const Rec3 r = src.load(i);
             uint32_t d;
             if (pi.drop_nonfinite && !finite3(r.x, r.y, r.z)) d = pi.nb - 1;
             else d = (key(r) >> pi.shift) & mask;
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
     const DevState* st = &F.st;
     const uint32_t* __restrict__ table_x = F.table_x;
     const uint32_t* __restrict__ bin_total = F.bin_total;
-    float4* __restrict__ out = (pass & 1) ? F.rec_b : F.rec_a;
+    Rec3* __restrict__ out = reinterpret_cast<Rec3*>((pass & 1) ? F.rec_b : F.rec_a);
     if (voxel_stage_off(st)) return;
     const PassInfo pi = pass_info(st, pass);
     const uint32_t tile_base = blockIdx.x * kTile;
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
     uint32_t* hist_w = s_hist + w * nb;
     const uint32_t mask = (1u << pi.bits) - 1u;
     const uint32_t wbase = tile_base + w * (kItems * kWave) + lane_id();
-    float4 rec[kItems];
+    Rec3 rec[kItems];
     uint32_t dig[kItems], lrank[kItems];
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(kBlock) void k_heads_count(const Frame* frames, uin
     __shared__ uint32_t s_w[kWavesPerBlock];
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
-    const float4* __restrict__ rec = sorted_records(F, npass);
+    const Rec3* __restrict__ rec = sorted_records(F, npass);
     uint32_t* __restrict__ tile_heads = F.tile_a;
     if (voxel_stage_off(st)) return;
     const uint32_t n = st->n_valid;
@@ -693,11 +700,11 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 // partition is stable) starting from 0.0f and divides by float(count).
 __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t npass) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    __shared__ float4 s_rec[kScanTile];
+    __shared__ Rec3 s_rec[kScanTile];
     __shared__ uint32_t s_key[kScanTile + 1];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
-    const float4* __restrict__ rec = sorted_records(F, npass);
+    const Rec3* __restrict__ rec = sorted_records(F, npass);
     const uint32_t* __restrict__ tile_heads = F.tile_a;
     float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
     if (st->err || st->kind == kFrameClusterOnly) return;
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t j = k * kBlock + threadIdx.x;
-        if (j < cnt) { const float4 r = rec[base + j]; s_rec[j] = r; s_key[j + 1] = key(r); }
+        if (j < cnt) { const Rec3 r = rec[base + j]; s_rec[j] = r; s_key[j + 1] = key(r); }
     }
     if (threadIdx.x == 0) s_key[0] = base > 0 ? key(rec[base - 1]) : 0u;
     __syncthreads();
@@ -748,14 +755,14 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
             float sx = 0.0f, sy = 0.0f, sz = 0.0f;
             uint32_t jj = j;
             do {   // the part of the run inside this tile
-                const float4 r = s_rec[jj];
+                const Rec3 r = s_rec[jj];
                 sx += r.x; sy += r.y; sz += r.z;
                 ++jj;
             } while (jj < cnt && s_key[jj + 1] == kcur[k]);
             uint32_t len = jj - j;
             if (jj == cnt) {   // the run may continue in the next tile(s)
                 for (uint32_t g = base + cnt; g < n; ++g) {
-                    const float4 r = rec[g];
+                    const Rec3 r = rec[g];
                     if (key(r) != kcur[k]) break;
                     sx += r.x; sy += r.y; sz += r.z;
                     ++len;
@@ -940,11 +947,11 @@ __global__ __launch_bounds__(kBlock) void k_slot_apply(Frame* frames) {
     uint32_t id = before_occ + block_excl_scan(occ, s_w, &tot_occ);
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
-        cell_start[s0 + k] = run;
-        parent[s0 + k] = s0 + k;
-        comp_size[s0 + k] = 0u;
-        comp_rank[s0 + k] = 0xFFFFFFFFu;
-        if (v[k]) {
+        if (v[k]) {   // only occupied slots are ever read
+            cell_start[s0 + k] = run;
+            parent[s0 + k] = s0 + k;
+            comp_size[s0 + k] = 0u;
+            comp_rank[s0 + k] = 0xFFFFFFFFu;
             const unsigned long long k1 = hkey[s0 + k];
             const uint32_t mi = hmin[s0 + k];
             slot_meta[s0 + k] = make_uint4(run, v[k], mi, 0u);
@@ -1468,11 +1475,20 @@ __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t n
     const float* __restrict__ cen_x = F.cen_x; const float* __restrict__ cen_y = F.cen_y; const float* __restrict__ cen_z = F.cen_z;
     const CellTable tab{F.hkey, F.hcount, F.hmin};
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-    // reset the cell table for the next frame (also after an error: only touched slots are dirty,
-    // and they all lie below hash_mask + 1)
+    // reset the cell table for the next frame: the occupied slots are listed in cell_list; after an
+    // error the list may be incomplete, so everything below hash_mask + 1 is cleared instead
     if (st->kind != kFrameVoxelOnly && !st->trivial && st->hash_mask) {
-        const uint32_t cap = st->hash_mask + 1u;
-        for (uint32_t i = tid; i < cap; i += nth) { tab.hkey[i] = 0ull; tab.hcount[i] = 0u; tab.hmin[i] = 0xFFFFFFFFu; }
+        if (st->err) {
+            const uint32_t cap = st->hash_mask + 1u;
+            for (uint32_t i = tid; i < cap; i += nth) { tab.hkey[i] = 0ull; tab.hcount[i] = 0u; tab.hmin[i] = 0xFFFFFFFFu; }
+        } else {
+            const uint32_t nc = st->n_cells;
+            const uint32_t* __restrict__ cell_list = F.cell_list;
+            for (uint32_t i = tid; i < nc; i += nth) {
+                const uint32_t s = cell_list[i];
+                tab.hkey[s] = 0ull; tab.hcount[s] = 0u; tab.hmin[s] = 0xFFFFFFFFu;
+            }
+        }
     }
     if (tid == 0) *out.state = *st;
     if (st->err) return;

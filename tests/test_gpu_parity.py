@@ -197,21 +197,17 @@ def test_voxel_stage_matches_oracle(ctx, oracle, layout, seed, n, leaf):
 
 
 def test_voxel_stage_sorted_records_are_stable(ctx, oracle):
-    """Stage-wise: after the partition passes the records are ordered by (voxel key, point index)."""
+    """Stage-wise: after the partition passes the 12-byte records are ordered by (voxel key, point index)."""
     pts = synth.uniform_field(30_000, 9)
     ctx.set_params(leaf=0.1, tol=0.1)
     ctx.voxel_downsample(pts)
     st = ctx.debug_state()
     npass = st.plan_voxel.npass
-    rec = ctx.debug_buffer("rec_a" if npass % 2 == 1 else "rec_b", np.float32, 4 * len(pts)).reshape(-1, 4)
-    idx = rec[:, 3].view(np.uint32)
+    rec = ctx.debug_buffer("rec_a" if npass % 2 == 1 else "rec_b", np.float32, 3 * len(pts)).reshape(-1, 3)
     keys, grid, _ = oracle.voxel_keys(pts, 0.1)
     assert list(grid[:3]) == list(st.min_b) and list(grid[3:6]) == list(st.div_b)
-    assert sorted(idx.tolist()) == list(range(len(pts)))
-    k_sorted = keys[idx].astype(np.int64)
-    order = np.lexsort((idx, k_sorted))
-    assert np.array_equal(order, np.arange(len(pts)))          # already sorted by (key, idx)
-    assert np.array_equal(rec[:, :3], pts[idx])
+    order = np.lexsort((np.arange(len(pts)), keys.astype(np.int64)))      # by key, ties by point index
+    assert rec.tobytes() == pts[order].tobytes()
 
 
 @pytest.mark.parametrize("cfg,n,mn,mx", [("C1", 10_000, 5, 20000), ("C1", 10_000, 1, 10**9), ("C2", 30_000, 5, 10**9),

@@ -1,0 +1,34 @@
+"""HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters in KiB).
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of a wide coalesced streaming read,
+so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16-B-per-lane stores."""
+import collections, csv, json, sys
+fdir, wdir, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+out = sys.argv[4] if len(sys.argv) > 4 else None
+grid_of = {}
+
+
+def load(d):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(d + "/pmc_counter_collection.csv")):
+        acc[r["Kernel_Name"]].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
+    return acc
+
+
+F, W = load(fdir), load(wdir)
+res = {}
+print("%-58s %12s %12s %12s" % ("kernel", "fetch_KiB", "write_KiB", "hbm_MB/launch"))
+for k in sorted(F, key=lambda k: -sum(v for v, _ in F[k])):
+    if not k.startswith("pcop::") and "pcop::" not in k:
+        continue
+    # batched launches only: the largest grid of this kernel
+    gmax = max(g for _, g in F[k])
+    fv = [v for v, g in F[k] if g == gmax]
+    wv = [v for v, g in W.get(k, []) if g == gmax]
+    f = sum(fv) / max(len(fv), 1)
+    w = sum(wv) / max(len(wv), 1)
+    hbm = (2.0 * f + w) * 1024.0
+    name = k.split("(")[0].replace("void ", "")
+    res[name] = {"fetch_kib": f, "write_kib": w, "hbm_bytes_per_launch": hbm, "batch": batch}
+    print("%-58s %12.0f %12.0f %12.2f" % (name[:58], f, w, hbm / 1e6))
+if out:
+    json.dump(res, open(out, "w"), indent=1)
