@@ -143,6 +143,7 @@ def main():
     if rank == 0:
         # ---- single-frame latency (one context, nothing else on the GPU) -----------------------------
         c0, ptr0, n0 = ctxs[0], ptrs[0][0][0], ptrs[0][1][0]
+        m_vox = last["num_voxels"]
         lat = []
         for _ in range(20):
             t1 = time.perf_counter()
@@ -151,18 +152,19 @@ def main():
             lat.append(time.perf_counter() - t1)
         lat_ms = 1e3 * float(np.median(lat))
 
-        # ---- per-kernel times: HIP events on the context's own stream -----------------------------------
-        prof = capi.Context(n_pts, device=local_rank, profiling=True)
+        # ---- per-kernel times: HIP events on the context's own stream, same batch size as the timed run ----
+        prof = capi.Context(n_pts, device=local_rank, profiling=True, max_frames=B)
         prof.set_params_struct(params)
+        pp, nn = ptrs[0]
         for _ in range(3):
-            prof.submit_device(ptr0, n0)
-            prof.wait(want_arrays=False)
+            prof.submit_batch_device(pp, nn)
+            prof.wait_batch(want_arrays=False)
         acc = {}
         reps = 10
         n_cells = 0
         for _ in range(reps):
-            prof.submit_device(ptr0, n0)
-            prof.wait(want_arrays=False)
+            prof.submit_batch_device(pp, nn)
+            prof.wait_batch(want_arrays=False)
             st = prof.debug_state()
             n_cells = st.n_cells
             seen = {}
@@ -180,10 +182,20 @@ def main():
         dom = max((nm for nm in totals if nm.startswith("k_")), key=lambda k: totals[k])
         dom_launches = by_name[dom]
         dom_ms = sum(ms for _, ms in dom_launches) / len(dom_launches)
-        dom_bytes = sum(kernel_alg_bytes(dom, occ, n0, m_vox, n_cells) for occ, _ in dom_launches) / len(dom_launches)
+        # one launch covers B frames
+        dom_bytes = B * sum(kernel_alg_bytes(dom, occ, n0, m_vox, n_cells) for occ, _ in dom_launches) / len(dom_launches)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         frame_bytes = 12 * n0 + 28 * m_vox
         prof.close()
+        # HBM bytes per launch from the committed PMC passes of this command (profiles/), if they match
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            for k, v in pmc.items():
+                if k.split("::")[-1].split("<")[0] == dom and v.get("batch") == B:
+                    traffic = v["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
 
         result = {
             "metric": "frames/sec at 1M-pt cloud, 1/2/4/8 MI355X; HBM GB/s vs roofline",
@@ -198,7 +210,8 @@ def main():
             "latency_ms_single_frame": lat_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "launches_per_frame": len(dom_launches),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes},
+                         "traffic": traffic, "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes,
+                         "frames_per_launch": B, "peak_measured_copy": 6290.0},
             "frame_roofline": {"alg_bytes_per_frame": frame_bytes,
                                "achieved_GBs_pipelined": frame_bytes * fps / world / 1e9,
                                "frac_pipelined": frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS,
