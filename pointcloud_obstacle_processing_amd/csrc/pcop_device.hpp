@@ -592,9 +592,14 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint32_t nbits, bool
 
 template <int MAXB>
 __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, int pass) {
-    __shared__ uint32_t s_hist[kWavesPerBlock * ((1 << MAXB) + 1)];
-    __shared__ uint32_t s_base[(1 << MAXB) + 1];
+    constexpr int kBins = (1 << MAXB) + 1;
+    __shared__ uint32_t s_hist[kWavesPerBlock * kBins];   // per wave and bin: count, then offset inside the bin
+    __shared__ uint32_t s_base[kBins];                    // global start of the bin
+    __shared__ uint32_t s_lbase[kBins];                   // start of the bin inside the staged tile
+    __shared__ uint32_t s_gstart[kBins];                  // global position of the tile's first record of the bin
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    __shared__ Rec3 s_stage[kTile];                       // the tile in output order
+    __shared__ uint16_t s_sdig[kTile];
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const uint32_t* __restrict__ table_x = F.table_x;
@@ -635,23 +640,52 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
         dig[j] = d; lrank[j] = old + rank;
     }
     __syncthreads();
-    // phase 2: per bin, turn the per-wave counts into per-wave output bases
+    // phase 2: per bin, per-wave counts -> per-wave offsets inside the bin; tile count of the bin
     const uint32_t* row = table_x + (size_t)blockIdx.x * nb;
-    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) {
-        uint32_t run = s_base[b] + row[b];
+    constexpr int kPer = (kBins + kBlock - 1) / kBlock;
+    uint32_t tcnt[kPer];
+    uint32_t tsum = 0;
 #pragma unroll
-        for (int q = 0; q < kWavesPerBlock; ++q) {
-            const uint32_t t = s_hist[q * nb + b];
-            s_hist[q * nb + b] = run;
-            run += t;
+    for (int k = 0; k < kPer; ++k) {
+        const uint32_t b = threadIdx.x * kPer + k;
+        tcnt[k] = 0;
+        if (b < nb) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int q = 0; q < kWavesPerBlock; ++q) {
+                const uint32_t t = s_hist[q * nb + b];
+                s_hist[q * nb + b] = run;
+                run += t;
+            }
+            tcnt[k] = run;
+            s_gstart[b] = s_base[b] + row[b];
         }
+        tsum += tcnt[k];
+    }
+    uint32_t ttot;
+    uint32_t lrun = block_excl_scan(tsum, s_w, &ttot);   // bins of one thread are consecutive
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const uint32_t b = threadIdx.x * kPer + k;
+        if (b < nb) s_lbase[b] = lrun;
+        lrun += tcnt[k];
     }
     __syncthreads();
-    // phase 3: scatter
+    // phase 3: stage the tile in output order (bin-major, stable inside a bin)
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
         const uint32_t i = wbase + j * kWave;
-        if (i < pi.count) out[hist_w[dig[j]] + lrank[j]] = rec[j];
+        if (i < pi.count) {
+            const uint32_t lp = s_lbase[dig[j]] + hist_w[dig[j]] + lrank[j];
+            s_stage[lp] = rec[j];
+            s_sdig[lp] = (uint16_t)dig[j];
+        }
+    }
+    __syncthreads();
+    // phase 4: consecutive staged records of a bin go to consecutive global positions
+    for (uint32_t e = threadIdx.x; e < ttot; e += kBlock) {
+        const uint32_t d = s_sdig[e];
+        out[s_gstart[d] + (e - s_lbase[d])] = s_stage[e];
     }
 }
 
