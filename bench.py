@@ -44,7 +44,7 @@ def kernel_alg_bytes(name, occurrence, n, m, n_cells):
         return 12 * m + 8 * m
     if name == "k_cell_place":
         return 12 * m + 8 * m + 16 * m
-    if name in ("k_cell_union", "k_cell_hook"):
+    if name in ("k_cell_union", "k_cell_hook", "k_cell_check"):
         return 12 * m + 4 * m          # neighbour + cluster pass reads 12·M, writes 4·M
     if name == "k_cell_flatten":
         return 8 * m

@@ -88,6 +88,7 @@ struct pcop_ctx {
     int radix_bits_target = 8;    // preferred digit width when choosing pass counts
     int maxbits = kNarrowBits;    // digit limit of the kernel variant in use (8: small LDS, 11: wide)
     bool use_graph = true;
+    bool debug_skip_union = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
 
     // profiling
@@ -242,7 +243,7 @@ int enqueue_batch(pcop_ctx* c) {
         a.inv_leaf = inv_leaf; a.r2 = r2;
         a.inv_cell = trivial ? 1.0 : 1.99 / std::fabs((double)p.tol);
         a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
-        a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.pad = 0;
+        a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.debug_skip_union = c->debug_skip_union ? 1u : 0u;
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         nmax = std::max(nmax, sl.n);
     }
@@ -446,7 +447,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
     TRY(dev_alloc(c, &f.hkey, hcap)); TRY(dev_alloc(c, &f.hcount, hcap)); TRY(dev_alloc(c, &f.hmin, hcap));
     TRY(dev_alloc(c, &f.cell_start, hcap)); TRY(dev_alloc(c, &f.parent, hcap));
     TRY(dev_alloc(c, &f.comp_size, hcap)); TRY(dev_alloc(c, &f.comp_rank, hcap)); TRY(dev_alloc(c, &f.cell_list, n + 1));
-    TRY(dev_alloc(c, &f.slot_meta, hcap)); TRY(dev_alloc(c, &f.cell_info, 2 * (n + 1)));
+    TRY(dev_alloc(c, &f.slot_meta, hcap)); TRY(dev_alloc(c, &f.cell_info, 2 * (n + 1))); TRY(dev_alloc(c, &f.todo, n + 2));
     TRY(dev_alloc(c, &f.pt_slot, n + 1)); TRY(dev_alloc(c, &f.pt_rank, n + 1)); TRY(dev_alloc(c, &f.pt_root, n + 1));
     TRY(dev_alloc(c, &f.idx_a, n + 1)); TRY(dev_alloc(c, &f.idx_b, n + 1)); TRY(dev_alloc(c, &f.d_offsets, n + 2));
     TRY(dev_alloc(c, &f.d_xyzr, n + 1));
@@ -518,6 +519,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     }
     c->maxbits = c->radix_bits_target <= kNarrowBits ? kNarrowBits : kMaxBits;
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
+    if (const char* e = getenv("PCOP_DEBUG_SKIP_UNION")) c->debug_skip_union = atoi(e) != 0;
     const size_t nbk = bucket_of(c, (uint32_t)max_points);           // launch sizes round up to this
     const size_t n = std::max<size_t>(max_points, nbk);
     const size_t ntiles = (n + kTile - 1) / kTile + 1;
@@ -758,6 +760,7 @@ int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* byt
         {"comp_rank", f.comp_rank, h * 4}, {"pt_slot", f.pt_slot, n * 4}, {"pt_rank", f.pt_rank, n * 4},
         {"pt_root", f.pt_root, n * 4}, {"idx_a", f.idx_a, n * 4}, {"idx_b", f.idx_b, n * 4},
         {"d_offsets", f.d_offsets, (n + 1) * 4}, {"bin_total", f.bin_total, (size_t)kMaxBins * 4},
+        {"todo", f.todo, (n + 1) * 4}, {"cell_list", f.cell_list, n * 4},
     };
     for (const Ent& e : tab) {
         if (std::strcmp(e.nm, name) == 0) { *dev_ptr = e.p; *bytes = e.b; return PCOP_OK; }

@@ -72,7 +72,7 @@ struct FrameArgs {
     float inv_leaf, r2;
     double inv_cell;                          // 1.99 / |tol|
     uint32_t min_cluster, max_cluster;
-    uint32_t emit_cloud, out_layout, out_soa_stride, pad;
+    uint32_t emit_cloud, out_layout, out_soa_stride, debug_skip_union;
     const float* src_x; const float* src_y; const float* src_z;
 };
 
@@ -104,7 +104,8 @@ struct DevState {
     uint32_t n_kept;        // clusters with min <= size <= max
     uint32_t n_kept_pts;    // sum of their sizes
     RadixPlan plan_csr;
-    uint32_t pad[2];
+    uint32_t debug_skip_union;   // diagnostics: leave the hook forest untouched
+    uint32_t pad[1];
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState layout");
 
@@ -126,6 +127,7 @@ struct Frame {
     unsigned long long* hkey;         // cell hash table: key+1 (0 = empty)
     uint32_t *hcount, *hmin;          //                  points, smallest point index (= priority)
     uint32_t *cell_start, *cell_list, *parent, *comp_size, *comp_rank;
+    uint32_t* todo;                   // cells whose forward neighbourhood still holds a foreign root; todo[0] = count
     uint4* slot_meta;                 // per occupied slot: {first record, points, smallest point index, 0}
     uint4* cell_info;                 // per cell (dense), 2 x uint4: {key lo, key hi, first record, points}, {min idx, slot, 0, 0}
     uint32_t *pt_slot, *pt_rank, *pt_root;
@@ -297,6 +299,7 @@ __global__ void k_frame_init(Frame* frames) {
         s.inv_leaf = a.inv_leaf; s.r2 = a.r2; s.inv_cell = a.inv_cell;
         s.min_cluster = a.min_cluster; s.max_cluster = a.max_cluster;
         s.src_x = a.src_x; s.src_y = a.src_y; s.src_z = a.src_z;
+        s.debug_skip_union = a.debug_skip_union;
         if (a.kind == kFrameClusterOnly) {   // no voxel stage: cluster the input cloud as it is
             s.c_from_input = 1; s.c_n = a.n; s.n_valid = a.n;
             uint32_t cap = 1024;
@@ -1208,6 +1211,11 @@ __global__ __launch_bounds__(kBlock) void k_cell_compress(const Frame* frames) {
     }
 }
 
+// One wave per cell, lane = one of the 62 forward offsets.  After hook + compress almost every
+// neighbour already points at the cell's root (one load decides).  Lanes whose neighbour is in
+// another set run the pair test; the wave then unites ONE hit at a time and re-reads the roots,
+// because in practice all hits of a wave lead to the same one or two foreign trees and a CAS per
+// lane would only hammer the same root word.
 __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
     const Frame& F = frames[blockIdx.y];
@@ -1217,7 +1225,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
     const uint32_t* __restrict__ hmin = F.hmin;
     const uint4* __restrict__ slot_meta = F.slot_meta; const uint4* __restrict__ cell_info = F.cell_info;
     uint32_t* __restrict__ parent = F.parent;
-    if (cluster_stage_off(st)) return;
+    if (cluster_stage_off(st) || st->debug_skip_union) return;
     const uint32_t mask = st->hash_mask, ncell = st->n_cells;
     const float r2 = st->r2;
     const uint32_t w = threadIdx.x / kWave;
@@ -1228,7 +1236,6 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
         const unsigned long long ka = (((unsigned long long)i0.y << 32) | i0.x) - 1ull;
         const uint32_t a0 = i0.z, an = i0.w, a = i1.y;
         const uint32_t b = stencil_neighbour(hkey, mask, ka, lane, +1);
-        // after hook + compress almost every neighbour already points at A's root: one load decides
         uint32_t ra = 0;
         if (lane == 0) ra = uf_find(parent, a);
         ra = __shfl(ra, 0, kWave);
@@ -1245,17 +1252,26 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
         if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
             if (lane < an) s_pa[w][lane] = rec[a0 + lane];
             __builtin_amdgcn_wave_barrier();
-            if (need && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2)) uf_union(parent, hmin, a, b);
+            const bool hit = need && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2);
+            uint64_t pending = __ballot(hit);
+            while (pending) {
+                const int t = __ffsll((unsigned long long)pending) - 1;
+                const uint32_t cb = __shfl(b, t, kWave);
+                if (lane == 0) { uf_union(parent, hmin, a, cb); ra = uf_find(parent, a); }
+                ra = __shfl(ra, 0, kWave);
+                const bool still = ((pending >> lane) & 1ull) && (int)lane != t && uf_find(parent, b) != ra;
+                pending = __ballot(still);
+            }
             __builtin_amdgcn_wave_barrier();
         } else {
             while (need_mask) {
                 const int t = __ffsll((unsigned long long)need_mask) - 1;
                 need_mask &= need_mask - 1;
                 const uint32_t cb = __shfl(b, t, kWave), cb0 = __shfl(b0, t, kWave), cbn = __shfl(bn, t, kWave);
-                uint32_t ra = 0, rb = 1;
-                if (lane == 0) { ra = uf_find(parent, a); rb = uf_find(parent, cb); }
-                ra = __shfl(ra, 0, kWave); rb = __shfl(rb, 0, kWave);
-                if (ra == rb) continue;
+                uint32_t rra = 0, rrb = 1;
+                if (lane == 0) { rra = uf_find(parent, a); rrb = uf_find(parent, cb); }
+                rra = __shfl(rra, 0, kWave); rrb = __shfl(rrb, 0, kWave);
+                if (rra == rrb) continue;
                 if (wave_pair_hit(rec, a0, an, cb0, cbn, r2) && lane == 0) uf_union(parent, hmin, a, cb);
             }
         }
