@@ -7,7 +7,10 @@ import torch  # noqa
 from pointcloud_obstacle_processing_amd import capi, synth
 p = synth.params_of("C3")
 clouds = [synth.make_cloud("C3", seed=3000 + i) for i in range(4)]
-for B, NC in [(1, 1), (1, 2), (2, 1), (4, 1), (8, 1), (8, 2), (16, 1), (16, 2), (32, 1)]:
+combos = [(1, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 3), (8, 4), (16, 2), (6, 3)]
+if len(sys.argv) > 1:
+    combos = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+for B, NC in combos:
     ctxs = []
     for ci in range(NC):
         c = capi.Context(1_000_000, max_frames=B); c.set_params(publish_clouds=0, **p)
@@ -16,7 +19,7 @@ for B, NC in [(1, 1), (1, 2), (2, 1), (4, 1), (8, 1), (8, 2), (16, 1), (16, 2), 
     for _ in range(3):
         for c, pp, nn in ctxs: c.submit_batch_device(pp, nn)
         for c, _, _ in ctxs: c.wait_batch(want_arrays=False)
-    steps = max(3, 64 // (B * NC))
+    steps = max(4, 128 // (B * NC))
     t0 = time.perf_counter()
     for _ in range(steps):
         for c, pp, nn in ctxs: c.submit_batch_device(pp, nn)
