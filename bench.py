@@ -85,8 +85,13 @@ def main():
             print("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus), file=sys.stderr)
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # PCOP_BENCH_FORCE_DIST=1 exercises the RCCL path (init, broadcast, barrier, all-reduce) with one rank too
+    use_dist = world > 1 or os.environ.get("PCOP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from pointcloud_obstacle_processing_amd import capi, sharding, synth
@@ -94,7 +99,7 @@ def main():
     # ---- parameters: rank 0 decides, everyone else receives the 32-byte struct over RCCL ----------
     p = synth.params_of(args.config)
     params = capi.Params(np.float32(p["leaf"]), np.float32(p["tol"]), p["min_cluster"], p["max_cluster"], 0)
-    if world > 1:
+    if use_dist:
         params = sharding.broadcast_params(params if rank == 0 else None, src=0, device=torch.device("cuda", local_rank))
 
     # ---- frames: F per rank, seeds sharded by rank --------------------------------------------------
@@ -119,7 +124,7 @@ def main():
         return out
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -131,7 +136,7 @@ def main():
         last = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -237,7 +242,7 @@ def main():
 
     for c in ctxs:
         c.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
