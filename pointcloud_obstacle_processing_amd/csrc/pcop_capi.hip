@@ -201,7 +201,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
         mark(c, "k_cell_hook");
         k_cell_compress<<<tg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_compress");
-        k_cell_union<<<wg, kBlock, 0, s>>>(fr);
+        k_cell_union<<<dim3(std::min(8192u, std::max(1u, div_up(nb, 2 * kWavesPerBlock))), nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_union");
         k_cell_flatten<<<dim3(64, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_flatten");

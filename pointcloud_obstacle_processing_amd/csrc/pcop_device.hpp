@@ -1211,11 +1211,51 @@ __global__ __launch_bounds__(kBlock) void k_cell_compress(const Frame* frames) {
     }
 }
 
-// One wave per cell, lane = one of the 62 forward offsets.  After hook + compress almost every
-// neighbour already points at the cell's root (one load decides).  Lanes whose neighbour is in
-// another set run the pair test; the wave then unites ONE hit at a time and re-reads the roots,
-// because in practice all hits of a wave lead to the same one or two foreign trees and a CAS per
-// lane would only hammer the same root word.
+// The slow part of the union for one cell: lanes whose forward neighbour is in another set run the
+// pair test; the wave then unites ONE hit at a time and re-reads the roots, because in practice all
+// hits of a wave lead to the same one or two foreign trees and a CAS per lane would only hammer
+// the same root word.
+__device__ __forceinline__ void union_fixup(const float4* __restrict__ rec, const uint4* __restrict__ slot_meta,
+                                            const uint32_t* __restrict__ hmin, uint32_t* parent, float4* s_pa,
+                                            uint32_t a, uint32_t a0, uint32_t an, uint32_t b, bool need, float r2) {
+    const uint32_t lane = lane_id();
+    uint64_t need_mask = __ballot(need);
+    uint32_t b0 = 0, bn = 0;
+    if (need) { const uint4 mb = slot_meta[b]; b0 = mb.x; bn = mb.y; }
+    const uint32_t bn_max = wave_max(bn);
+    if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
+        if (lane < an) s_pa[lane] = rec[a0 + lane];
+        __builtin_amdgcn_wave_barrier();
+        const bool hit = need && lane_pair_hit(s_pa, an, rec, b0, bn, r2);
+        uint64_t pending = __ballot(hit);
+        uint32_t ra = 0;
+        while (pending) {
+            const int t = __ffsll((unsigned long long)pending) - 1;
+            const uint32_t cb = __shfl(b, t, kWave);
+            if (lane == 0) { uf_union(parent, hmin, a, cb); ra = uf_find(parent, a); }
+            ra = __shfl(ra, 0, kWave);
+            const bool still = ((pending >> lane) & 1ull) && (int)lane != t && uf_find(parent, b) != ra;
+            pending = __ballot(still);
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        while (need_mask) {
+            const int t = __ffsll((unsigned long long)need_mask) - 1;
+            need_mask &= need_mask - 1;
+            const uint32_t cb = __shfl(b, t, kWave), cb0 = __shfl(b0, t, kWave), cbn = __shfl(bn, t, kWave);
+            uint32_t rra = 0, rrb = 1;
+            if (lane == 0) { rra = uf_find(parent, a); rrb = uf_find(parent, cb); }
+            rra = __shfl(rra, 0, kWave); rrb = __shfl(rrb, 0, kWave);
+            if (rra == rrb) continue;
+            if (wave_pair_hit(rec, a0, an, cb0, cbn, r2) && lane == 0) uf_union(parent, hmin, a, cb);
+        }
+    }
+}
+
+// One wave per cell, lane = one of the 62 forward offsets of the 5x5x5 stencil.  After hook +
+// compress almost every neighbour already points at the cell's root, so the common case is three
+// dependent loads (cell info -> hash probe -> parent word) and no arithmetic; two cells are kept in
+// flight per wave iteration (both chains are issued before either is consumed) to hide that latency.
 __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
     const Frame& F = frames[blockIdx.y];
@@ -1231,50 +1271,41 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
     const uint32_t w = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
-    for (uint32_t ai = blockIdx.x * kWavesPerBlock + w; ai < ncell; ai += nwaves) {
+    long long off = 0;
+    if (lane < (uint32_t)kStencil) {
+        int dx, dy, dz;
+        stencil_offset(lane, &dx, &dy, &dz);
+        off = (long long)dx + ((long long)dy << 21) + ((long long)dz << 42);
+    }
+    for (uint32_t ai = 2 * (blockIdx.x * kWavesPerBlock + w); ai < ncell; ai += 2 * nwaves) {
+        const bool two = ai + 1 < ncell;
+        const uint32_t aj = two ? ai + 1 : ai;
+        // both cells' info, then both first probes, then both parent words: issue before use
         const uint4 i0 = cell_info[2 * (size_t)ai], i1 = cell_info[2 * (size_t)ai + 1];
+        const uint4 j0 = cell_info[2 * (size_t)aj], j1 = cell_info[2 * (size_t)aj + 1];
         const unsigned long long ka = (((unsigned long long)i0.y << 32) | i0.x) - 1ull;
-        const uint32_t a0 = i0.z, an = i0.w, a = i1.y;
-        const uint32_t b = stencil_neighbour(hkey, mask, ka, lane, +1);
-        uint32_t ra = 0;
-        if (lane == 0) ra = uf_find(parent, a);
-        ra = __shfl(ra, 0, kWave);
-        bool need = false;
-        if (b != kNoSlot) {
-            const uint32_t pb = ld_agent(parent + b);
-            if (pb != ra) need = uf_find(parent, b) != ra;
-        }
-        uint64_t need_mask = __ballot(need);
-        if (need_mask == 0) continue;
-        uint32_t b0 = 0, bn = 0;
-        if (need) { const uint4 mb = slot_meta[b]; b0 = mb.x; bn = mb.y; }
-        const uint32_t bn_max = wave_max(bn);
-        if (an <= (uint32_t)kCellPtsCap && bn_max <= (uint32_t)kCellPtsCap) {
-            if (lane < an) s_pa[w][lane] = rec[a0 + lane];
-            __builtin_amdgcn_wave_barrier();
-            const bool hit = need && lane_pair_hit(s_pa[w], an, rec, b0, bn, r2);
-            uint64_t pending = __ballot(hit);
-            while (pending) {
-                const int t = __ffsll((unsigned long long)pending) - 1;
-                const uint32_t cb = __shfl(b, t, kWave);
-                if (lane == 0) { uf_union(parent, hmin, a, cb); ra = uf_find(parent, a); }
-                ra = __shfl(ra, 0, kWave);
-                const bool still = ((pending >> lane) & 1ull) && (int)lane != t && uf_find(parent, b) != ra;
-                pending = __ballot(still);
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            while (need_mask) {
-                const int t = __ffsll((unsigned long long)need_mask) - 1;
-                need_mask &= need_mask - 1;
-                const uint32_t cb = __shfl(b, t, kWave), cb0 = __shfl(b0, t, kWave), cbn = __shfl(bn, t, kWave);
-                uint32_t rra = 0, rrb = 1;
-                if (lane == 0) { rra = uf_find(parent, a); rrb = uf_find(parent, cb); }
-                rra = __shfl(rra, 0, kWave); rrb = __shfl(rrb, 0, kWave);
-                if (rra == rrb) continue;
-                if (wave_pair_hit(rec, a0, an, cb0, cbn, r2) && lane == 0) uf_union(parent, hmin, a, cb);
-            }
-        }
+        const unsigned long long kb = (((unsigned long long)j0.y << 32) | j0.x) - 1ull;
+        const uint32_t a = i1.y, c = j1.y;
+        const bool in = lane < (uint32_t)kStencil;
+        const unsigned long long wa = (unsigned long long)((long long)ka + off) + 1ull, wc = (unsigned long long)((long long)kb + off) + 1ull;
+        uint32_t sa = in ? cell_home(wa - 1ull, mask) : 0u, sc = in ? cell_home(wc - 1ull, mask) : 0u;
+        unsigned long long va = in ? hkey[sa] : 0ull, vc = in ? hkey[sc] : 0ull;
+        uint32_t pa_root = ld_agent(parent + a), pc_root = ld_agent(parent + c);   // uniform loads
+        while (va != wa && va != 0ull) { sa = (sa + 64u) & mask; va = hkey[sa]; }
+        while (vc != wc && vc != 0ull) { sc = (sc + 64u) & mask; vc = hkey[sc]; }
+        const uint32_t ba = va == wa ? sa : kNoSlot, bc = vc == wc ? sc : kNoSlot;
+        uint32_t pba = 0, pbc = 0;
+        if (ba != kNoSlot) pba = ld_agent(parent + ba);
+        if (bc != kNoSlot) pbc = ld_agent(parent + bc);
+        // roots of A and C (after compress parent[x] is the root unless a union moved it since)
+        uint32_t ra = pa_root, rc = pc_root;
+        if (ld_agent(parent + ra) != ra) ra = uf_find(parent, ra);
+        if (ld_agent(parent + rc) != rc) rc = uf_find(parent, rc);
+        bool need_a = false, need_c = false;
+        if (ba != kNoSlot && pba != ra) need_a = uf_find(parent, ba) != ra;
+        if (two && bc != kNoSlot && pbc != rc) need_c = uf_find(parent, bc) != rc;
+        if (__any(need_a)) union_fixup(rec, slot_meta, hmin, parent, s_pa[w], a, i0.z, i0.w, ba, need_a, r2);
+        if (__any(need_c)) union_fixup(rec, slot_meta, hmin, parent, s_pa[w], c, j0.z, j0.w, bc, need_c, r2);
     }
 }
 
