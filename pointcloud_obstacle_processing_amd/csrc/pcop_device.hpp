@@ -1140,7 +1140,7 @@ __device__ __forceinline__ long long hook_offset(uint32_t t) {
     return (long long)dx + ((long long)dy << 21) + ((long long)dz << 42);
 }
 
-__global__ __launch_bounds__(kBlock) void k_cell_hook(const Frame* frames) {
+__global__ __launch_bounds__(kBlock, 8) void k_cell_hook(const Frame* frames) {
     __shared__ float4 s_pa[kBlock / kHookGroup][kHookPtsCap];
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
