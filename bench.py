@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="frames per context, processed in the same launches")
-    ap.add_argument("--contexts", type=int, default=2, help="contexts (streams) in flight per GPU")
+    ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) in flight per GPU")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
@@ -115,13 +115,26 @@ def main():
         ctxs.append(c)
         ptrs.append(([p for p, _ in mine], [n for _, n in mine]))
 
+    # One step = every context's batch processed once.  Submission is rolling: a context's previous batch
+    # is collected (results on the host) right before its next one is queued, so the other contexts' batches
+    # keep the GPU busy meanwhile; drain() collects what is still in flight.  Every frame counted in a timed
+    # region is submitted and collected inside it.
+    pending = [False] * NC
+    last_out = [None]
+
     def step():
-        for c, (pp, nn) in zip(ctxs, ptrs):
+        for ci, (c, (pp, nn)) in enumerate(zip(ctxs, ptrs)):
+            if pending[ci]:
+                last_out[0] = c.wait_batch(want_arrays=False)[-1]
             c.submit_batch_device(pp, nn)
-        out = None
-        for c in ctxs:
-            out = c.wait_batch(want_arrays=False)[-1]
-        return out
+            pending[ci] = True
+
+    def drain():
+        for ci, c in enumerate(ctxs):
+            if pending[ci]:
+                last_out[0] = c.wait_batch(want_arrays=False)[-1]
+                pending[ci] = False
+        return last_out[0]
 
     def fence():
         if use_dist:
@@ -129,11 +142,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        last = step()
+        step()
+    last = drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        last = step()
+        step()
+    last = drain()
     fence()
     dt = time.perf_counter() - t0
     if use_dist:

@@ -119,6 +119,13 @@ int dev_alloc(pcop_ctx* c, T** p, size_t count) {
     return PCOP_OK;
 }
 template <class T>
+int dev_alloc(pcop_ctx* c, DevPtr<T>* p, size_t count) {
+    T* q = nullptr;
+    const int rc = dev_alloc(c, &q, count);
+    *p = q;
+    return rc;
+}
+template <class T>
 int host_alloc(pcop_ctx* c, T** p, size_t count) {
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
     c->host_allocs.push_back(*p);

@@ -50,6 +50,28 @@ constexpr int kReduceBlocks = 256;               // grid of the min/max kernel: 
 constexpr int kCellBias = 1 << 20;               // cell coordinates are stored biased, 21 bits per axis
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
+// Pointers that live in device-visible structs (Frame, DevState, the mailbox).  A pointer loaded from
+// memory is a generic ("flat") pointer to the compiler, and every access through it becomes a
+// flat_load/flat_store, which counts against both the vector-memory and the LDS counter and forces
+// full s_waitcnt drains.  DevPtr stores the same 8 bytes but, in the device pass, types them as
+// address space 1, so the kernels get global_load/global_store.  The host pass sees a plain pointer.
+template <class T>
+struct DevPtr {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(1))) T* gptr;
+    gptr p;
+    __host__ __device__ DevPtr& operator=(T* q) { p = (gptr)q; return *this; }
+    __host__ __device__ operator gptr() const { return p; }
+    __host__ __device__ T* get() const { return (T*)p; }
+#else
+    T* p;
+    DevPtr& operator=(T* q) { p = q; return *this; }
+    operator T*() const { return p; }
+    T* get() const { return p; }
+#endif
+};
+static_assert(sizeof(DevPtr<float>) == sizeof(float*), "DevPtr is layout-compatible with a pointer");
+
 enum ErrBits : uint32_t {
     kErrNonFinite = 1u,    // NaN/Inf where the reference is undefined
     kErrReplanVoxel = 2u,  // voxel key needs more radix passes than were launched
@@ -73,7 +95,7 @@ struct FrameArgs {
     double inv_cell;                          // 1.99 / |tol|
     uint32_t min_cluster, max_cluster;
     uint32_t emit_cloud, out_layout, out_soa_stride, debug_skip_union;
-    const float* src_x; const float* src_y; const float* src_z;
+    DevPtr<const float> src_x, src_y, src_z;
 };
 
 // Device-resident frame state; k_emit copies it to pinned host memory at the end of a frame.
@@ -92,7 +114,7 @@ struct DevState {
     int32_t  min_b[3], div_b[3];
     uint32_t mul[3];
     RadixPlan plan_voxel;
-    const float* src_x; const float* src_y; const float* src_z;
+    DevPtr<const float> src_x, src_y, src_z;
     // cluster stage
     double   inv_cell;
     uint32_t c_n;           // points entering clustering
@@ -119,25 +141,25 @@ struct MinMaxPartial {
 // are the same for every launch and the batch replays as one hipGraph.
 struct Frame {
     DevState st;
-    const FrameArgs* args;            // pinned host mailbox
-    float *cen_x, *cen_y, *cen_z;     // voxel centroids (SoA)
-    float4 *rec_a, *rec_b;            // partition ping-pong / cell-sorted records
-    uint32_t *table, *table_x, *bin_total, *tile_a, *tile_b;
-    MinMaxPartial* partials;
-    unsigned long long* hkey;         // cell hash table: key+1 (0 = empty)
-    uint32_t *hcount, *hmin;          //                  points, smallest point index (= priority)
-    uint32_t *cell_start, *cell_list, *parent, *comp_size, *comp_rank;
-    uint32_t* todo;                   // cells whose forward neighbourhood still holds a foreign root; todo[0] = count
-    uint4* slot_meta;                 // per occupied slot: {first record, points, smallest point index, 0}
-    uint4* cell_info;                 // per cell (dense), 2 x uint4: {key lo, key hi, first record, points}, {min idx, slot, 0, 0}
-    uint32_t *pt_slot, *pt_rank, *pt_root;
-    uint32_t *idx_a, *idx_b, *d_offsets;
-    float4* d_xyzr;
+    DevPtr<const FrameArgs> args;     // pinned host mailbox
+    DevPtr<float> cen_x, cen_y, cen_z;   // voxel centroids (SoA)
+    DevPtr<float4> rec_a, rec_b;      // partition ping-pong / cell-sorted records
+    DevPtr<uint32_t> table, table_x, bin_total, tile_a, tile_b;
+    DevPtr<MinMaxPartial> partials;
+    DevPtr<unsigned long long> hkey;  // cell hash table: key+1 (0 = empty)
+    DevPtr<uint32_t> hcount, hmin;    //                  points, smallest point index (= priority)
+    DevPtr<uint32_t> cell_start, cell_list, parent, comp_size, comp_rank;
+    DevPtr<uint32_t> todo;            // unused
+    DevPtr<uint4> slot_meta;          // per occupied slot: {first record, points, smallest point index, 0}
+    DevPtr<uint4> cell_info;          // per cell (dense), 2 x uint4: {key lo, key hi, first record, points}, {min idx, slot, 0, 0}
+    DevPtr<uint32_t> pt_slot, pt_rank, pt_root;
+    DevPtr<uint32_t> idx_a, idx_b, d_offsets;
+    DevPtr<float4> d_xyzr;
     // pinned host outputs
-    DevState* h_state;
-    uint32_t* h_offsets;              // n_kept + 1, discovery order
-    uint32_t* h_indices;              // n_kept_pts
-    float* h_cloud;                   // voxel cloud in st.out_layout
+    DevPtr<DevState> h_state;
+    DevPtr<uint32_t> h_offsets;       // n_kept + 1, discovery order
+    DevPtr<uint32_t> h_indices;       // n_kept_pts
+    DevPtr<float> h_cloud;            // voxel cloud in st.out_layout
 };
 
 // ------------------------------------------------------------------------------------------
@@ -458,12 +480,12 @@ __global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t 
 __device__ __forceinline__ RecSrc rec_source(const Frame& F, int pass) {
     RecSrc s;
     s.x = F.st.src_x; s.y = F.st.src_y; s.z = F.st.src_z;
-    s.r = pass == 0 ? nullptr : reinterpret_cast<const Rec3*>(((pass - 1) & 1) ? F.rec_b : F.rec_a);
+    s.r = pass == 0 ? nullptr : reinterpret_cast<const Rec3*>(((pass - 1) & 1) ? F.rec_b.get() : F.rec_a.get());
     return s;
 }
 // output of the last of npass partition passes
 __device__ __forceinline__ const Rec3* sorted_records(const Frame& F, uint32_t npass) {
-    return reinterpret_cast<const Rec3*>(((npass - 1) & 1) ? F.rec_b : F.rec_a);
+    return reinterpret_cast<const Rec3*>(((npass - 1) & 1) ? F.rec_b.get() : F.rec_a.get());
 }
 
 struct PassInfo {
@@ -607,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
     const DevState* st = &F.st;
     const uint32_t* __restrict__ table_x = F.table_x;
     const uint32_t* __restrict__ bin_total = F.bin_total;
-    Rec3* __restrict__ out = reinterpret_cast<Rec3*>((pass & 1) ? F.rec_b : F.rec_a);
+    Rec3* __restrict__ out = reinterpret_cast<Rec3*>((pass & 1) ? F.rec_b.get() : F.rec_a.get());
     if (voxel_stage_off(st)) return;
     const PassInfo pi = pass_info(st, pass);
     const uint32_t tile_base = blockIdx.x * kTile;

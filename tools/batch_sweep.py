@@ -25,5 +25,14 @@ for B, NC in combos:
         for c, pp, nn in ctxs: c.submit_batch_device(pp, nn)
         for c, _, _ in ctxs: c.wait_batch(want_arrays=False)
     dt = time.perf_counter() - t0
+    # rolling: every context always has a batch queued; wait for the oldest, resubmit it at once
+    for c, pp, nn in ctxs: c.submit_batch_device(pp, nn)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for c, pp, nn in ctxs:
+            c.wait_batch(want_arrays=False); c.submit_batch_device(pp, nn)
+    dtr = time.perf_counter() - t0
+    for c, _, _ in ctxs: c.wait_batch(want_arrays=False)
+    print("   rolling: %8.1f frames/s" % (steps * B * NC / dtr), flush=True)
     print("batch %2d x ctx %d: %8.1f frames/s  (%.1f us/frame, step %.2f ms)" % (B, NC, steps * B * NC / dt, 1e6 * dt / (steps * B * NC), 1e3 * dt / steps), flush=True)
     for c, _, _ in ctxs: c.close()
