@@ -88,7 +88,9 @@ struct pcop_ctx {
     int radix_bits_target = 8;    // preferred digit width when choosing pass counts
     int maxbits = kNarrowBits;    // digit limit of the kernel variant in use (8: small LDS, 11: wide)
     bool use_graph = true;
-    bool debug_skip_union = false;
+    uint32_t cell_blocks = 2560;      // total blocks per launch of the wave-per-cell kernels (whole batch)
+    uint32_t stride_blocks = 4096;    // total blocks per launch of the grid-strided point kernels
+    uint32_t debug_skip_union = 0;    // diagnostics: 1 = no union kernel, 2 = union scans but never fixes up
     std::map<GraphKey, hipGraphExec_t> graphs;
 
     // profiling
@@ -173,7 +175,12 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
     mark(c, "k_frame_init");
     const dim3 pg(std::max(1u, div_up(nb, kTile)), nf);        // partition tiles
     const dim3 sg(std::max(1u, div_up(nb, kScanTile)), nf);    // scan tiles over points
-    const dim3 tg(stride_grid(nb), nf);
+    // Grid-strided kernels: the counts they loop over (voxels, cells) are only known on the device and are
+    // usually far below the bucket, and a block that finds nothing to do still costs its launch and its
+    // prologue (kernarg -> Frame -> DevState loads).  So their grids are sized to fill the chip a few times
+    // over for the whole batch, not to cover the bucket.
+    const dim3 tg(std::min(stride_grid(nb), std::max(64u, c->stride_blocks / nf)), nf);
+    const uint32_t cell_blocks = std::max(64u, c->cell_blocks / nf);
     if (kind != kFrameClusterOnly) {
         k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_minmax");
@@ -195,7 +202,6 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
     if (kind != kFrameVoxelOnly) {
         const uint32_t hcap = hash_cap_for(nb);
         const dim3 hg(std::max(1u, hcap / kScanTile), nf);       // scan tiles over hash slots
-        const dim3 wg(std::min(8192u, std::max(1u, div_up(nb, kWavesPerBlock))), nf);   // one wave per cell, grid-strided
         k_cell_insert<<<tg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_insert");
         k_slot_count<<<hg, kBlock, 0, s>>>(fr);
@@ -204,11 +210,11 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
         mark(c, "k_slot_apply");
         k_cell_place<<<tg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_place");
-        k_cell_hook<<<dim3(std::min(8192u, std::max(1u, div_up(nb, kBlock / kHookGroup))), nf), kBlock, 0, s>>>(fr);
+        k_cell_hook<<<dim3(std::min(cell_blocks, std::max(1u, div_up(nb, kBlock / kHookGroup))), nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_hook");
         k_cell_compress<<<tg, kBlock, 0, s>>>(fr);
         mark(c, "k_cell_compress");
-        k_cell_union<<<dim3(std::min(8192u, std::max(1u, div_up(nb, 2 * kWavesPerBlock))), nf), kBlock, 0, s>>>(fr);
+        k_cell_union<<<dim3(std::min(cell_blocks, std::max(1u, div_up(nb, 2 * kWavesPerBlock))), nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_union");
         k_cell_flatten<<<dim3(64, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_flatten");
@@ -250,7 +256,7 @@ int enqueue_batch(pcop_ctx* c) {
         a.inv_leaf = inv_leaf; a.r2 = r2;
         a.inv_cell = trivial ? 1.0 : 1.99 / std::fabs((double)p.tol);
         a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
-        a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.debug_skip_union = c->debug_skip_union ? 1u : 0u;
+        a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.debug_skip_union = c->debug_skip_union;
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         nmax = std::max(nmax, sl.n);
     }
@@ -526,7 +532,9 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     }
     c->maxbits = c->radix_bits_target <= kNarrowBits ? kNarrowBits : kMaxBits;
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
-    if (const char* e = getenv("PCOP_DEBUG_SKIP_UNION")) c->debug_skip_union = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_CELL_BLOCKS")) c->cell_blocks = (uint32_t)std::max(64, atoi(e));
+    if (const char* e = getenv("PCOP_STRIDE_BLOCKS")) c->stride_blocks = (uint32_t)std::max(64, atoi(e));
+    if (const char* e = getenv("PCOP_DEBUG_SKIP_UNION")) c->debug_skip_union = (uint32_t)atoi(e);
     const size_t nbk = bucket_of(c, (uint32_t)max_points);           // launch sizes round up to this
     const size_t n = std::max<size_t>(max_points, nbk);
     const size_t ntiles = (n + kTile - 1) / kTile + 1;

@@ -615,6 +615,22 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint32_t nbits, bool
     return m;
 }
 
+// The same peer mask through LDS instead of one ballot per digit bit: every lane ORs its lane bit into
+// the 64-bit word of its digit (ds_or_b64), reads the word back, and the first peer clears it for the
+// next step.  A wave's LDS operations execute in program order, so the read sees all 64 ORs.  About ten
+// VALU instructions per record instead of about sixty; `match_w` must be all zero on entry and is left so.
+__device__ __forceinline__ uint64_t match_digit_lds(unsigned long long* match_w, uint32_t d, bool active) {
+    unsigned long long peers = 0ull;
+    if (active) atomicOr(match_w + d, 1ull << lane_id());
+    __builtin_amdgcn_wave_barrier();
+    if (active) peers = *(volatile unsigned long long*)(match_w + d);
+    __builtin_amdgcn_wave_barrier();
+    if (active && (peers & lanemask_lt()) == 0ull) match_w[d] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    return peers;
+}
+constexpr int kMatchBins(int maxb) { return maxb <= kNarrowBits ? (1 << maxb) + 1 : 1; }   // wide digits keep the ballots
+
 template <int MAXB>
 __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, int pass) {
     constexpr int kBins = (1 << MAXB) + 1;
@@ -623,7 +639,11 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
     __shared__ uint32_t s_lbase[kBins];                   // start of the bin inside the staged tile
     __shared__ uint32_t s_gstart[kBins];                  // global position of the tile's first record of the bin
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    __shared__ Rec3 s_stage[kTile];                       // the tile in output order
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTile * sizeof(Rec3)];
+    Rec3* s_stage = reinterpret_cast<Rec3*>(s_raw);       // the tile in output order (phases 3-4)
+    // the peer-mask words of phase 1 live in the staging area, which nothing touches before phase 3
+    unsigned long long* s_match = reinterpret_cast<unsigned long long*>(s_raw);
+    static_assert(sizeof(unsigned long long) * kWavesPerBlock * kMatchBins(MAXB) <= sizeof(s_raw), "peer masks fit the staging area");
     __shared__ uint16_t s_sdig[kTile];
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
@@ -638,6 +658,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
     VoxelKey key; key.init(st);
     const uint32_t nb = pi.nb;
     for (uint32_t b = threadIdx.x; b < kWavesPerBlock * nb; b += kBlock) s_hist[b] = 0;
+    for (uint32_t b = threadIdx.x; b < (uint32_t)(kWavesPerBlock * kMatchBins(MAXB)); b += kBlock) s_match[b] = 0ull;
     scan_bins_to_lds<MAXB>(bin_total, nb, s_base, s_w);   // ends with a barrier
 
     // phase 1: each wave walks its contiguous sub-tile in order; ranks are stable by construction
@@ -657,7 +678,9 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
             if (pi.drop_nonfinite && !finite3(rec[j].x, rec[j].y, rec[j].z)) d = nb - 1;
             else d = (key(rec[j]) >> pi.shift) & mask;
         }
-        const uint64_t peers = match_digit(d, pi.bits + 1, active);
+        uint64_t peers;
+        if constexpr (MAXB <= kNarrowBits) peers = match_digit_lds(s_match + w * kBins, d, active);
+        else peers = match_digit(d, pi.bits + 1, active);
         const uint32_t rank = __popcll(peers & lanemask_lt());
         uint32_t old = 0;
         if (active) old = hist_w[d];
@@ -1275,9 +1298,23 @@ __device__ __forceinline__ void union_fixup(const float4* __restrict__ rec, cons
 }
 
 // One wave per cell, lane = one of the 62 forward offsets of the 5x5x5 stencil.  After hook +
-// compress almost every neighbour already points at the cell's root, so the common case is three
-// dependent loads (cell info -> hash probe -> parent word) and no arithmetic; two cells are kept in
-// flight per wave iteration (both chains are issued before either is consumed) to hide that latency.
+// compress almost every neighbour already points at the cell's root, so the common case is a chain
+// of dependent loads (cell info -> hash probe -> parent word) and no arithmetic.  The loop is
+// software-pipelined over that chain: two cells per step, and while the parent words of step k are
+// in flight the hash probes of step k+1 and the cell info of step k+2 are already issued.
+// parent[b] == parent[a] proves "same set" without knowing the root (a parent is always a member of
+// the same set), so the fast path never walks the tree.
+struct UnionCells {          // the two cells of one step
+    uint4 i0, i1, j0, j1;    // cell_info of A and of C
+};
+__device__ __forceinline__ UnionCells union_load_cells(const uint4* __restrict__ cell_info, uint32_t ai, uint32_t ncell) {
+    UnionCells u;
+    const uint32_t a = min(ai, ncell - 1u), c = min(ai + 1u, ncell - 1u);   // clamped: never read past the list
+    u.i0 = cell_info[2 * (size_t)a]; u.i1 = cell_info[2 * (size_t)a + 1];
+    u.j0 = cell_info[2 * (size_t)c]; u.j1 = cell_info[2 * (size_t)c + 1];
+    return u;
+}
+
 __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
     const Frame& F = frames[blockIdx.y];
@@ -1287,47 +1324,66 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
     const uint32_t* __restrict__ hmin = F.hmin;
     const uint4* __restrict__ slot_meta = F.slot_meta; const uint4* __restrict__ cell_info = F.cell_info;
     uint32_t* __restrict__ parent = F.parent;
-    if (cluster_stage_off(st) || st->debug_skip_union) return;
+    if (cluster_stage_off(st) || st->debug_skip_union == 1u) return;
+    const bool scan_only = st->debug_skip_union == 2u;   // diagnostics: time the scan without the fix-ups
     const uint32_t mask = st->hash_mask, ncell = st->n_cells;
     const float r2 = st->r2;
-    const uint32_t w = threadIdx.x / kWave;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));   // wave-uniform: cell info goes through scalar loads
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    const bool in = lane < (uint32_t)kStencil;
     long long off = 0;
-    if (lane < (uint32_t)kStencil) {
+    if (in) {
         int dx, dy, dz;
         stencil_offset(lane, &dx, &dy, &dz);
         off = (long long)dx + ((long long)dy << 21) + ((long long)dz << 42);
     }
-    for (uint32_t ai = 2 * (blockIdx.x * kWavesPerBlock + w); ai < ncell; ai += 2 * nwaves) {
+    uint32_t ai = 2 * (blockIdx.x * kWavesPerBlock + w);
+    if (ai >= ncell) return;
+    const uint32_t step = 2 * nwaves;
+    // prologue: info(0) -> probes(0) issued, info(1) issued
+    UnionCells cur = union_load_cells(cell_info, ai, ncell);
+    UnionCells nxt = union_load_cells(cell_info, ai + step, ncell);
+    unsigned long long wa = (unsigned long long)((long long)((((unsigned long long)cur.i0.y << 32) | cur.i0.x) - 1ull) + off) + 1ull;
+    unsigned long long wc = (unsigned long long)((long long)((((unsigned long long)cur.j0.y << 32) | cur.j0.x) - 1ull) + off) + 1ull;
+    uint32_t sa = in ? cell_home(wa - 1ull, mask) : 0u, sc = in ? cell_home(wc - 1ull, mask) : 0u;
+    unsigned long long va = in ? hkey[sa] : 0ull, vc = in ? hkey[sc] : 0ull;
+    uint32_t pa = ld_agent(parent + cur.i1.y), pc = ld_agent(parent + cur.j1.y);
+    for (; ai < ncell; ai += step) {
         const bool two = ai + 1 < ncell;
-        const uint32_t aj = two ? ai + 1 : ai;
-        // both cells' info, then both first probes, then both parent words: issue before use
-        const uint4 i0 = cell_info[2 * (size_t)ai], i1 = cell_info[2 * (size_t)ai + 1];
-        const uint4 j0 = cell_info[2 * (size_t)aj], j1 = cell_info[2 * (size_t)aj + 1];
-        const unsigned long long ka = (((unsigned long long)i0.y << 32) | i0.x) - 1ull;
-        const unsigned long long kb = (((unsigned long long)j0.y << 32) | j0.x) - 1ull;
-        const uint32_t a = i1.y, c = j1.y;
-        const bool in = lane < (uint32_t)kStencil;
-        const unsigned long long wa = (unsigned long long)((long long)ka + off) + 1ull, wc = (unsigned long long)((long long)kb + off) + 1ull;
-        uint32_t sa = in ? cell_home(wa - 1ull, mask) : 0u, sc = in ? cell_home(wc - 1ull, mask) : 0u;
-        unsigned long long va = in ? hkey[sa] : 0ull, vc = in ? hkey[sc] : 0ull;
-        uint32_t pa_root = ld_agent(parent + a), pc_root = ld_agent(parent + c);   // uniform loads
+        const uint32_t a = cur.i1.y, c = cur.j1.y;
+        // finish the probes of this step, then ask for the neighbours' parent words
         while (va != wa && va != 0ull) { sa = (sa + 64u) & mask; va = hkey[sa]; }
         while (vc != wc && vc != 0ull) { sc = (sc + 64u) & mask; vc = hkey[sc]; }
-        const uint32_t ba = va == wa ? sa : kNoSlot, bc = vc == wc ? sc : kNoSlot;
-        uint32_t pba = 0, pbc = 0;
+        const uint32_t ba = va == wa ? sa : kNoSlot, bc = (two && vc == wc) ? sc : kNoSlot;
+        uint32_t pba = pa, pbc = pc;
         if (ba != kNoSlot) pba = ld_agent(parent + ba);
         if (bc != kNoSlot) pbc = ld_agent(parent + bc);
-        // roots of A and C (after compress parent[x] is the root unless a union moved it since)
-        uint32_t ra = pa_root, rc = pc_root;
-        if (ld_agent(parent + ra) != ra) ra = uf_find(parent, ra);
-        if (ld_agent(parent + rc) != rc) rc = uf_find(parent, rc);
-        bool need_a = false, need_c = false;
-        if (ba != kNoSlot && pba != ra) need_a = uf_find(parent, ba) != ra;
-        if (two && bc != kNoSlot && pbc != rc) need_c = uf_find(parent, bc) != rc;
-        if (__any(need_a)) union_fixup(rec, slot_meta, hmin, parent, s_pa[w], a, i0.z, i0.w, ba, need_a, r2);
-        if (__any(need_c)) union_fixup(rec, slot_meta, hmin, parent, s_pa[w], c, j0.z, j0.w, bc, need_c, r2);
+        // meanwhile: probes of the next step, cell info of the one after
+        const UnionCells here = cur;
+        const uint32_t pa_here = pa, pc_here = pc;
+        const bool more = ai + step < ncell;
+        cur = nxt;
+        if (more) {
+            wa = (unsigned long long)((long long)((((unsigned long long)cur.i0.y << 32) | cur.i0.x) - 1ull) + off) + 1ull;
+            wc = (unsigned long long)((long long)((((unsigned long long)cur.j0.y << 32) | cur.j0.x) - 1ull) + off) + 1ull;
+            sa = in ? cell_home(wa - 1ull, mask) : 0u; sc = in ? cell_home(wc - 1ull, mask) : 0u;
+            va = in ? hkey[sa] : 0ull; vc = in ? hkey[sc] : 0ull;
+            pa = ld_agent(parent + cur.i1.y); pc = ld_agent(parent + cur.j1.y);
+            nxt = union_load_cells(cell_info, ai + 2 * step, ncell);
+        }
+        // neighbours whose parent word differs from the cell's may be in another set: look properly
+        bool need_a = pba != pa_here && !scan_only, need_c = pbc != pc_here && !scan_only;
+        if (__any(need_a)) {
+            const uint32_t ra = uf_find(parent, a);
+            need_a = need_a && uf_find(parent, ba) != ra;
+            if (__any(need_a)) union_fixup(rec, slot_meta, hmin, parent, s_pa[w], a, here.i0.z, here.i0.w, ba, need_a, r2);
+        }
+        if (__any(need_c)) {
+            const uint32_t rc = uf_find(parent, c);
+            need_c = need_c && uf_find(parent, bc) != rc;
+            if (__any(need_c)) union_fixup(rec, slot_meta, hmin, parent, s_pa[w], c, here.j0.z, here.j0.w, bc, need_c, r2);
+        }
     }
 }
 
@@ -1533,6 +1589,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_scatter(const Frame* frames, int
             pt[j] = pass == 0 ? i : idx_in[i];
             d = (point_label(pt[j], pt_root, comp_rank, trash) >> shift) & mask;
         }
+        // few tiles, latency-bound: the ballots (pure ALU) beat the LDS round trips of match_digit_lds here
         const uint64_t peers = match_digit(d, bits, active);
         const uint32_t rank = __popcll(peers & lanemask_lt());
         uint32_t old = 0;
