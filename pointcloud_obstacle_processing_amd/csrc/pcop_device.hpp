@@ -784,6 +784,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     __shared__ Rec3 s_rec[kScanTile];
     __shared__ uint32_t s_key[kScanTile + 1];
+    __shared__ uint16_t s_hpos[kScanTile + 2];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     const Rec3* __restrict__ rec = sorted_records(F, npass);
@@ -813,47 +814,44 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
     }
     if (threadIdx.x == 0) s_key[0] = base > 0 ? key(rec[base - 1]) : 0u;
     __syncthreads();
-    uint32_t kcur[kScanItems];
+    // run heads of the tile, compacted: s_hpos[h] = tile position of the h-th head, s_hpos[tot] = cnt
     bool head[kScanItems];
     uint32_t c = 0;
     const uint32_t j0 = threadIdx.x * kScanItems;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t j = j0 + k;
-        head[k] = false;
-        if (j < cnt) {
-            kcur[k] = s_key[j + 1];
-            head[k] = (base + j == 0) || (kcur[k] != s_key[j]);
-            c += head[k] ? 1u : 0u;
-        }
+        head[k] = j < cnt && ((base + j == 0) || (s_key[j + 1] != s_key[j]));
+        c += head[k] ? 1u : 0u;
     }
     uint32_t tot;
-    uint32_t rank = before + block_excl_scan(c, s_w, &tot);
+    uint32_t h0 = block_excl_scan(c, s_w, &tot);
     if (threadIdx.x == 0 && base + kScanTile >= n) finish_voxel(st, before + tot);   // the last tile
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const uint32_t j = j0 + k;
-        if (j < cnt && head[k]) {
-            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-            uint32_t jj = j;
-            do {   // the part of the run inside this tile
-                const Rec3 r = s_rec[jj];
-                sx += r.x; sy += r.y; sz += r.z;
-                ++jj;
-            } while (jj < cnt && s_key[jj + 1] == kcur[k]);
-            uint32_t len = jj - j;
-            if (jj == cnt) {   // the run may continue in the next tile(s)
-                for (uint32_t g = base + cnt; g < n; ++g) {
-                    const Rec3 r = rec[g];
-                    if (key(r) != kcur[k]) break;
-                    sx += r.x; sy += r.y; sz += r.z;
-                    ++len;
-                }
-            }
-            const float fc = (float)len;
-            cx[rank] = sx / fc; cy[rank] = sy / fc; cz[rank] = sz / fc;
-            ++rank;
+    for (int k = 0; k < kScanItems; ++k)
+        if (head[k]) s_hpos[h0++] = (uint16_t)(j0 + k);
+    if (threadIdx.x == 0) s_hpos[tot] = (uint16_t)cnt;
+    __syncthreads();
+    // one thread per head: every lane has a run to sum (a thread per record would leave most lanes idle)
+    for (uint32_t h = threadIdx.x; h < tot; h += kBlock) {
+        const uint32_t j = s_hpos[h], e = s_hpos[h + 1];
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (uint32_t jj = j; jj < e; ++jj) {   // the part of the run inside this tile
+            const Rec3 r = s_rec[jj];
+            sx += r.x; sy += r.y; sz += r.z;
         }
+        uint32_t len = e - j;
+        if (e == cnt) {   // the tile's last run may continue in the next tile(s)
+            const uint32_t kc = s_key[j + 1];
+            for (uint32_t g = base + cnt; g < n; ++g) {
+                const Rec3 r = rec[g];
+                if (key(r) != kc) break;
+                sx += r.x; sy += r.y; sz += r.z;
+                ++len;
+            }
+        }
+        const float fc = (float)len;
+        cx[before + h] = sx / fc; cy[before + h] = sy / fc; cz[before + h] = sz / fc;
     }
 }
 
