@@ -534,8 +534,9 @@ __global__ __launch_bounds__(kBlock) void k_radix_hist(const Frame* frames, int 
         }
     }
     __syncthreads();
-    uint32_t* row = table + (size_t)blockIdx.x * pi.nb;
-    for (uint32_t b = threadIdx.x; b < pi.nb; b += kBlock) row[b] = s_h[b];
+    // bin-major table (table[bin * ntiles + tile]): the scan kernel then reads and writes whole rows
+    const uint32_t ntiles = (pi.count + kTile - 1) / kTile;
+    for (uint32_t b = threadIdx.x; b < pi.nb; b += kBlock) table[(size_t)b * ntiles + blockIdx.x] = s_h[b];
 }
 
 // which = 0: voxel partition pass, 2: CSR partition pass
@@ -554,7 +555,7 @@ __device__ __forceinline__ bool table_dims(const DevState* st, int which, int pa
     return true;
 }
 
-// Exclusive scan down each column of the tile-count table: block b owns bin b.
+// Exclusive scan along each row of the bin-major tile-count table: block b owns bin b.
 // grid = kMaxBins blocks (blocks past the pass's bin count exit at once).
 __global__ __launch_bounds__(kBlock) void k_table_scan(const Frame* frames, int which, int pass) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
@@ -570,10 +571,10 @@ __global__ __launch_bounds__(kBlock) void k_table_scan(const Frame* frames, int 
     uint32_t carry = 0;
     for (uint32_t base = 0; base < ntiles; base += kBlock) {
         const uint32_t t = base + threadIdx.x;
-        const uint32_t v = t < ntiles ? table[(size_t)t * nb + b] : 0u;
+        const uint32_t v = t < ntiles ? table[(size_t)b * ntiles + t] : 0u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan(v, s_w, &tot);
-        if (t < ntiles) table_x[(size_t)t * nb + b] = carry + ex;
+        if (t < ntiles) table_x[(size_t)b * ntiles + t] = carry + ex;
         carry += tot;
     }
     if (threadIdx.x == 0) bin_total[b] = carry;
@@ -637,14 +638,14 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
     __shared__ uint32_t s_hist[kWavesPerBlock * kBins];   // per wave and bin: count, then offset inside the bin
     __shared__ uint32_t s_base[kBins];                    // global start of the bin
     __shared__ uint32_t s_lbase[kBins];                   // start of the bin inside the staged tile
-    __shared__ uint32_t s_gstart[kBins];                  // global position of the tile's first record of the bin
+    __shared__ uint32_t s_delta[kBins];                   // global position minus staged position, per bin
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTile * sizeof(Rec3)];
-    Rec3* s_stage = reinterpret_cast<Rec3*>(s_raw);       // the tile in output order (phases 3-4)
+    // the tile in output order (phases 3-4): {x, y, z, global position - staged position}, one 16-byte LDS
+    // access per record on either side
+    __shared__ float4 s_stage[kTile];
     // the peer-mask words of phase 1 live in the staging area, which nothing touches before phase 3
-    unsigned long long* s_match = reinterpret_cast<unsigned long long*>(s_raw);
-    static_assert(sizeof(unsigned long long) * kWavesPerBlock * kMatchBins(MAXB) <= sizeof(s_raw), "peer masks fit the staging area");
-    __shared__ uint16_t s_sdig[kTile];
+    unsigned long long* s_match = reinterpret_cast<unsigned long long*>(s_stage);
+    static_assert(sizeof(unsigned long long) * kWavesPerBlock * kMatchBins(MAXB) <= sizeof(float4) * kTile, "peer masks fit the staging area");
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const uint32_t* __restrict__ table_x = F.table_x;
@@ -689,14 +690,14 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
     }
     __syncthreads();
     // phase 2: per bin, per-wave counts -> per-wave offsets inside the bin; tile count of the bin
-    const uint32_t* row = table_x + (size_t)blockIdx.x * nb;
+    const uint32_t ntiles = (pi.count + kTile - 1) / kTile;
     constexpr int kPer = (kBins + kBlock - 1) / kBlock;
-    uint32_t tcnt[kPer];
+    uint32_t tcnt[kPer], gstart[kPer];
     uint32_t tsum = 0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const uint32_t b = threadIdx.x * kPer + k;
-        tcnt[k] = 0;
+        tcnt[k] = 0; gstart[k] = 0;
         if (b < nb) {
             uint32_t run = 0;
 #pragma unroll
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
                 run += t;
             }
             tcnt[k] = run;
-            s_gstart[b] = s_base[b] + row[b];
+            gstart[k] = s_base[b] + table_x[(size_t)b * ntiles + blockIdx.x];
         }
         tsum += tcnt[k];
     }
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const uint32_t b = threadIdx.x * kPer + k;
-        if (b < nb) s_lbase[b] = lrun;
+        if (b < nb) { s_lbase[b] = lrun; s_delta[b] = gstart[k] - lrun; }
         lrun += tcnt[k];
     }
     __syncthreads();
@@ -725,15 +726,15 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
         const uint32_t i = wbase + j * kWave;
         if (i < pi.count) {
             const uint32_t lp = s_lbase[dig[j]] + hist_w[dig[j]] + lrank[j];
-            s_stage[lp] = rec[j];
-            s_sdig[lp] = (uint16_t)dig[j];
+            s_stage[lp] = make_float4(rec[j].x, rec[j].y, rec[j].z, u2f(s_delta[dig[j]]));
         }
     }
     __syncthreads();
     // phase 4: consecutive staged records of a bin go to consecutive global positions
     for (uint32_t e = threadIdx.x; e < ttot; e += kBlock) {
-        const uint32_t d = s_sdig[e];
-        out[s_gstart[d] + (e - s_lbase[d])] = s_stage[e];
+        const float4 v = s_stage[e];
+        Rec3 r; r.x = v.x; r.y = v.y; r.z = v.z;
+        out[e + f2u(v.w)] = r;
     }
 }
 
@@ -1550,8 +1551,8 @@ __global__ __launch_bounds__(kBlock) void k_csr_hist(const Frame* frames, int pa
         }
     }
     __syncthreads();
-    uint32_t* row = table + (size_t)blockIdx.x * nb;
-    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) row[b] = s_h[b];
+    const uint32_t ntiles = (count + kTile - 1) / kTile;
+    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) table[(size_t)b * ntiles + blockIdx.x] = s_h[b];
 }
 
 template <int MAXB>
@@ -1596,9 +1597,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_scatter(const Frame* frames, int
         dig[j] = d; lrank[j] = old + rank;
     }
     __syncthreads();
-    const uint32_t* row = table_x + (size_t)blockIdx.x * nb;
+    const uint32_t ntiles = (count + kTile - 1) / kTile;
     for (uint32_t b = threadIdx.x; b < nb; b += kBlock) {
-        uint32_t run = s_base[b] + row[b];
+        uint32_t run = s_base[b] + table_x[(size_t)b * ntiles + blockIdx.x];
 #pragma unroll
         for (int q = 0; q < kWavesPerBlock; ++q) {
             const uint32_t t = s_hist[q * nb + b];
