@@ -36,8 +36,6 @@ def kernel_alg_bytes(name, occurrence, n, m, n_cells):
         return 12 * n                   # xyz planes (pass 0) or packed 12-byte records
     if name == "k_radix_scatter":
         return (12 + 12) * n            # read every record once, write it once
-    if name == "k_heads_count":
-        return 12 * n
     if name == "k_voxel_reduce":
         return 12 * n + 12 * m
     if name == "k_cell_insert":

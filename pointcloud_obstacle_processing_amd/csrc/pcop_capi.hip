@@ -194,8 +194,6 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
             k_radix_scatter<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
             mark(c, "k_radix_scatter");
         }
-        k_heads_count<<<sg, kBlock, 0, s>>>(fr, c->npass_voxel);
-        mark(c, "k_heads_count");
         k_voxel_reduce<<<sg, kBlock, 0, s>>>(fr, c->npass_voxel);
         mark(c, "k_voxel_reduce");
     }
@@ -364,6 +362,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         }
         if (e & kErrNonFinite) { c->in_flight = false; c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
         if (e & kErrRange) { c->in_flight = false; c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
+        if (e & kErrInternal) { c->in_flight = false; c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
         if (e & (kErrReplanVoxel | kErrReplanCsr)) {
             if (attempt >= 4) { c->in_flight = false; c->err = "radix replanning did not converge"; return PCOP_ERR_STATE; }
             if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));

@@ -8,7 +8,7 @@
 //                             the overflow rule and the radix plan
 //     k_radix_hist / k_table_scan / k_radix_scatter   (x passes) stable LSD radix partition of
 //                             {x,y,z,idx} records by PCL's linear voxel index
-//     k_heads_count, k_voxel_reduce   run heads -> rank; in-order float32 sums -> centroids
+//     k_voxel_reduce          run heads -> rank; in-order float32 sums -> centroids
 //   cell grid (replaces the FLANN kd-tree built at od.cpp:791-792)
 //     k_cell_insert           points -> hash table of cells (edge tol/1.99), rank inside the cell
 //     k_slot_count, k_slot_apply, k_cell_place   counting sort of the points by cell
@@ -77,6 +77,7 @@ enum ErrBits : uint32_t {
     kErrReplanVoxel = 2u,  // voxel key needs more radix passes than were launched
     kErrReplanCsr = 8u,    // cluster-rank key needs more radix passes than were launched
     kErrRange = 16u,       // a cell coordinate leaves +-2^20 cells (|p| / tol too large)
+    kErrInternal = 32u,    // a bounded wait inside a kernel ran out (never expected)
 };
 
 enum FrameKind : uint32_t { kFrameChain = 0, kFrameVoxelOnly = 1, kFrameClusterOnly = 2 };
@@ -469,6 +470,10 @@ __global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t 
     s_p[threadIdx.x] = q;
     reduce_partials_lds(s_p);
     if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass, maxbits);
+    // k_voxel_reduce publishes "heads of tile t, plus one" here; zero = not yet published
+    uint32_t* __restrict__ tile_heads = F.tile_a;
+    const uint32_t ntiles = (st->n_in + kScanTile - 1) / kScanTile;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock) tile_heads[t] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -741,33 +746,6 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
 // ------------------------------------------------------------------------------------------
 // run heads over the sorted records -> voxel rank; centroids
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_heads_count(const Frame* frames, uint32_t npass) {
-    __shared__ uint32_t s_w[kWavesPerBlock];
-    const Frame& F = frames[blockIdx.y];
-    const DevState* st = &F.st;
-    const Rec3* __restrict__ rec = sorted_records(F, npass);
-    uint32_t* __restrict__ tile_heads = F.tile_a;
-    if (voxel_stage_off(st)) return;
-    const uint32_t n = st->n_valid;
-    const uint32_t base = blockIdx.x * kScanTile;
-    if (base >= n) return;
-    VoxelKey key; key.init(st);
-    uint32_t c = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const uint32_t i = base + threadIdx.x * kScanItems + k;
-        if (i < n) c += (i == 0 || key(rec[i]) != key(rec[i - 1])) ? 1u : 0u;
-    }
-    c = wave_sum(c);
-    if (lane_id() == 0) s_w[threadIdx.x / kWave] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int i = 0; i < kWavesPerBlock; ++i) t += s_w[i];
-        tile_heads[blockIdx.x] = t;
-    }
-}
-
 // End of the voxel stage: M, and what the cluster stage reads.
 __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
     st->m = m;
@@ -778,9 +756,15 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
     st->hash_mask = cap - 1u;
 }
 
-// Voxel centroids (voxel_grid.hpp "Fourth pass", PCL >= 1.8 CentroidPoint / AccumulatorXYZ):
-// the thread that owns a run head sums the run in order (= ascending point index, the
-// partition is stable) starting from 0.0f and divides by float(count).
+// Voxel centroids (voxel_grid.hpp "Fourth pass", PCL >= 1.8 CentroidPoint / AccumulatorXYZ): one
+// thread per run head sums the run in order (= ascending point index, the partition is stable)
+// starting from 0.0f and divides by float(count).
+// The rank of a tile's first voxel is the number of run heads in the tiles before it.  Each block
+// publishes its own count (plus one) as soon as it knows it and reads the counts of the lower tiles
+// after its sums are done; a lower tile never waits for a higher one and blocks are dispatched in
+// index order, so the lower tiles are always running or finished (the wait is bounded anyway).
+constexpr uint32_t kSpinLimit = 1u << 24;
+
 __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t npass) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     __shared__ Rec3 s_rec[kScanTile];
@@ -789,7 +773,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     const Rec3* __restrict__ rec = sorted_records(F, npass);
-    const uint32_t* __restrict__ tile_heads = F.tile_a;
+    uint32_t* __restrict__ tile_heads = F.tile_a;
     float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
     if (st->err || st->kind == kFrameClusterOnly) return;
     if (st->passthrough) {   // "output = *input_": the voxel cloud is the input cloud, every point kept
@@ -803,7 +787,6 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
     }
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= n) return;
-    const uint32_t before = tiles_before(tile_heads, blockIdx.x, s_w);
     VoxelKey key; key.init(st);
     // stage the tile's records and keys in LDS (coalesced), so that the in-order run sums below
     // chase LDS, not L2
@@ -827,32 +810,57 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
     }
     uint32_t tot;
     uint32_t h0 = block_excl_scan(c, s_w, &tot);
-    if (threadIdx.x == 0 && base + kScanTile >= n) finish_voxel(st, before + tot);   // the last tile
+    if (threadIdx.x == 0) st_agent(tile_heads + blockIdx.x, tot + 1u);   // publish
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
         if (head[k]) s_hpos[h0++] = (uint16_t)(j0 + k);
     if (threadIdx.x == 0) s_hpos[tot] = (uint16_t)cnt;
     __syncthreads();
     // one thread per head: every lane has a run to sum (a thread per record would leave most lanes idle)
-    for (uint32_t h = threadIdx.x; h < tot; h += kBlock) {
-        const uint32_t j = s_hpos[h], e = s_hpos[h + 1];
-        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        for (uint32_t jj = j; jj < e; ++jj) {   // the part of the run inside this tile
-            const Rec3 r = s_rec[jj];
-            sx += r.x; sy += r.y; sz += r.z;
-        }
-        uint32_t len = e - j;
-        if (e == cnt) {   // the tile's last run may continue in the next tile(s)
-            const uint32_t kc = s_key[j + 1];
-            for (uint32_t g = base + cnt; g < n; ++g) {
-                const Rec3 r = rec[g];
-                if (key(r) != kc) break;
+    float ox[kScanItems], oy[kScanItems], oz[kScanItems];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t h = k * kBlock + threadIdx.x;
+        ox[k] = oy[k] = oz[k] = 0.0f;
+        if (h < tot) {
+            const uint32_t j = s_hpos[h], e = s_hpos[h + 1];
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            for (uint32_t jj = j; jj < e; ++jj) {   // the part of the run inside this tile
+                const Rec3 r = s_rec[jj];
                 sx += r.x; sy += r.y; sz += r.z;
-                ++len;
             }
+            uint32_t len = e - j;
+            if (e == cnt) {   // the tile's last run may continue in the next tile(s)
+                const uint32_t kc = s_key[j + 1];
+                for (uint32_t g = base + cnt; g < n; ++g) {
+                    const Rec3 r = rec[g];
+                    if (key(r) != kc) break;
+                    sx += r.x; sy += r.y; sz += r.z;
+                    ++len;
+                }
+            }
+            const float fc = (float)len;
+            ox[k] = sx / fc; oy[k] = sy / fc; oz[k] = sz / fc;
         }
-        const float fc = (float)len;
-        cx[before + h] = sx / fc; cy[before + h] = sy / fc; cz[before + h] = sz / fc;
+    }
+    // heads in the tiles before this one
+    uint32_t mine = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
+        uint32_t v = ld_agent(tile_heads + t), spins = 0;
+        while (v == 0u) {
+            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
+            __builtin_amdgcn_s_sleep(2);
+            v = ld_agent(tile_heads + t);
+        }
+        mine += v - 1u;
+    }
+    __syncthreads();   // s_w is reused
+    const uint32_t before = block_sum(mine, s_w);
+    if (threadIdx.x == 0 && base + kScanTile >= n) finish_voxel(st, before + tot);   // the last tile
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t h = k * kBlock + threadIdx.x;
+        if (h < tot) { cx[before + h] = ox[k]; cy[before + h] = oy[k]; cz[before + h] = oz[k]; }
     }
 }
 
