@@ -60,7 +60,8 @@ class DevState(C.Structure):
                 ("src_x", C.c_void_p), ("src_y", C.c_void_p), ("src_z", C.c_void_p), ("inv_cell", C.c_double),
                 ("c_n", C.c_uint32), ("c_from_input", C.c_uint32), ("r2", C.c_float), ("min_cluster", C.c_uint32),
                 ("max_cluster", C.c_uint32), ("hash_mask", C.c_uint32), ("n_cells", C.c_uint32),
-                ("n_kept", C.c_uint32), ("n_kept_pts", C.c_uint32), ("plan_csr", RadixPlan), ("debug_skip_union", C.c_uint32), ("pad", C.c_uint32 * 1)]
+                ("n_kept", C.c_uint32), ("n_kept_pts", C.c_uint32), ("plan_csr", RadixPlan), ("debug_skip_union", C.c_uint32),
+                ("vpath", C.c_uint32), ("vmap_words", C.c_uint32), ("vshift", C.c_uint32), ("nbuckets", C.c_uint32), ("vcap", C.c_uint32)]
 
 
 _lib = None

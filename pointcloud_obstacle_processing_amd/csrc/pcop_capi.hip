@@ -32,7 +32,11 @@ inline bool compare_clusters(const ClusterRef& a, const ClusterRef& b) { return 
 
 struct GraphKey {
     uint32_t kind, bucket, npass_voxel, npass_csr, nframes;
+    uint32_t stream, vcap, vtiles;   // streaming voxel path: on?, voxels per bucket (LDS), occupancy tiles (grid)
     bool operator<(const GraphKey& o) const {
+        if (stream != o.stream) return stream < o.stream;
+        if (vcap != o.vcap) return vcap < o.vcap;
+        if (vtiles != o.vtiles) return vtiles < o.vtiles;
         if (kind != o.kind) return kind < o.kind;
         if (bucket != o.bucket) return bucket < o.bucket;
         if (npass_voxel != o.npass_voxel) return npass_voxel < o.npass_voxel;
@@ -91,6 +95,12 @@ struct pcop_ctx {
     uint32_t cell_blocks = 2560;      // total blocks per launch of the wave-per-cell kernels (whole batch)
     uint32_t stride_blocks = 4096;    // total blocks per launch of the grid-strided point kernels
     uint32_t debug_skip_union = 0;    // diagnostics: 1 = no union kernel, 2 = union scans but never fixes up
+    // streaming voxel path (pcop_device.hpp): on unless PCOP_VOXEL_PATH=sort; a frame it does not fit
+    // (grid > kVmapCells cells, or > 256 * kVcapMax voxels) is re-run on the sort path and the context stays there
+    // until the parameters change
+    bool voxel_stream = true, stream_ok = true;
+    uint32_t vcap = kVcapMin;                               // voxels per bucket the launch provides LDS for (grows on demand)
+    uint32_t vtiles = kVmapCells / 32u / kVmapTile;         // occupancy tiles launched (adapts to the grid seen)
     std::map<GraphKey, hipGraphExec_t> graphs;
 
     // profiling
@@ -150,6 +160,8 @@ void mark(pcop_ctx* c, const char* name) {
     ++c->ev_used;
 }
 
+uint32_t pow2_at_least(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
 uint32_t stride_grid(uint32_t n) { return std::min(2048u, std::max(1u, div_up(n, kBlock))); }
 
 uint32_t bucket_of(const pcop_ctx* c, uint32_t n) {   // launch-size bucket: next power of two, at most cap
@@ -163,6 +175,8 @@ uint32_t hash_cap_for(uint32_t n) {
     while (cap < 2u * n && cap < 0x80000000u) cap <<= 1;
     return cap;
 }
+
+bool stream_on(const pcop_ctx* c) { return c->voxel_stream && c->stream_ok && c->kind != kFrameClusterOnly; }
 
 // The launch sequence of one batch.  nb = launch-size bucket (>= every frame's point count), nf =
 // frames; all real counts are read on the device.  Everything here is capturable into a hipGraph.
@@ -184,18 +198,34 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
     if (kind != kFrameClusterOnly) {
         k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_minmax");
-        k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB);
+        const bool stream = stream_on(c);
+        k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, stream ? 1u : 0u);
         mark(c, "k_voxel_setup");
-        for (uint32_t p = 0; p < c->npass_voxel; ++p) {
-            k_radix_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
-            mark(c, "k_radix_hist");
-            k_table_scan<<<dim3(kBinsGrid, nf), kBlock, 0, s>>>(fr, 0, (int)p);
+        if (stream) {
+            k_vox_mark<<<dim3(stride_grid(nb), nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_vox_mark");
+            k_vmap_scan<<<dim3(c->vtiles, nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_vmap_scan");
+            k_vid_hist<kNarrowBits><<<pg, kBlock, 0, s>>>(fr);
+            mark(c, "k_vid_hist");
+            k_table_scan<<<dim3(kStreamBuckets + 1u, nf), kBlock, 0, s>>>(fr, 1, 0);
             mark(c, "k_table_scan");
-            k_radix_scatter<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
-            mark(c, "k_radix_scatter");
+            k_vid_scatter<kNarrowBits><<<pg, kBlock, 0, s>>>(fr);
+            mark(c, "k_vid_scatter");
+            k_voxel_stream<<<dim3(kStreamBuckets, nf), kWave, (size_t)c->vcap * 24u, s>>>(fr);
+            mark(c, "k_voxel_stream");
+        } else {
+            for (uint32_t p = 0; p < c->npass_voxel; ++p) {
+                k_radix_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
+                mark(c, "k_radix_hist");
+                k_table_scan<<<dim3(kBinsGrid, nf), kBlock, 0, s>>>(fr, 0, (int)p);
+                mark(c, "k_table_scan");
+                k_radix_scatter<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
+                mark(c, "k_radix_scatter");
+            }
+            k_voxel_reduce<<<sg, kBlock, 0, s>>>(fr, c->npass_voxel);
+            mark(c, "k_voxel_reduce");
         }
-        k_voxel_reduce<<<sg, kBlock, 0, s>>>(fr, c->npass_voxel);
-        mark(c, "k_voxel_reduce");
     }
     if (kind != kFrameVoxelOnly) {
         const uint32_t hcap = hash_cap_for(nb);
@@ -255,6 +285,7 @@ int enqueue_batch(pcop_ctx* c) {
         a.inv_cell = trivial ? 1.0 : 1.99 / std::fabs((double)p.tol);
         a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
         a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.debug_skip_union = c->debug_skip_union;
+        a.voxel_stream = stream_on(c) ? 1u : 0u; a.vcap = c->vcap;
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         nmax = std::max(nmax, sl.n);
     }
@@ -266,7 +297,8 @@ int enqueue_batch(pcop_ctx* c) {
         enqueue_launches(c, c->kind, nb, c->nframes);
         HIPCHK(c, hipGetLastError());
     } else {
-        const GraphKey key{c->kind, nb, c->npass_voxel, c->npass_csr, c->nframes};
+        const bool st_on = stream_on(c);
+        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? 1u : 0u, st_on ? c->vcap : 0u, st_on ? c->vtiles : 0u};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -347,6 +379,13 @@ void order_frame(pcop_ctx* c, Slot& sl, pcop_result* out) {
     }
 }
 
+// A batch given up half-way may leave occupancy flags set: the streaming voxel path needs them all zero.
+void scrub_flags(pcop_ctx* c) {
+    if (!c->voxel_stream) return;
+    for (Slot& sl : c->slots) if (sl.f.vflag.get()) hipMemsetAsync(sl.f.vflag.get(), 0, (size_t)kVmapCells, c->stream);
+    hipStreamSynchronize(c->stream);
+}
+
 // Waits for the batch (re-running it when a radix plan was too short) and puts every frame's
 // clusters in PCL's order.  The kernels have already written everything into pinned host memory.
 int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
@@ -362,11 +401,23 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         }
         if (e & kErrNonFinite) { c->in_flight = false; c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
         if (e & kErrRange) { c->in_flight = false; c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
-        if (e & kErrInternal) { c->in_flight = false; c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
-        if (e & (kErrReplanVoxel | kErrReplanCsr)) {
-            if (attempt >= 4) { c->in_flight = false; c->err = "radix replanning did not converge"; return PCOP_ERR_STATE; }
+        if (e & kErrInternal) { c->in_flight = false; scrub_flags(c); c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
+        if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap)) {
+            if (attempt >= 6) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
             if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));
             if (kb_csr) c->npass_csr = std::max(c->npass_csr, passes_for(c, kb_csr));
+            if (e & kErrReplanPath) {
+                c->stream_ok = false;            // this cloud does not fit the streaming voxel path: sort path from here on
+                c->npass_voxel = kMaxPasses;     // (its own plan check then trims the pass count)
+            } else if (e & kErrReplanVcap) {
+                for (uint32_t f = 0; f < c->nframes; ++f) {
+                    const DevState* hs = c->slots[f].h_state;
+                    if (!(hs->err & kErrReplanVcap)) continue;
+                    const uint32_t tiles = div_up(hs->vmap_words, kVmapTile);
+                    if (tiles > c->vtiles) c->vtiles = std::min(kVmapCells / 32u / kVmapTile, pow2_at_least(tiles) * 2u);
+                    else c->vcap = std::max(c->vcap, 1u << hs->vshift);
+                }
+            }
             int rc = enqueue_batch(c);
             if (rc) return rc;
             continue;
@@ -384,6 +435,15 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
     }
     if (kb_voxel) c->npass_voxel = passes_for(c, kb_voxel);
     if (kb_csr) c->npass_csr = passes_for(c, kb_csr);
+    if (stream_on(c)) {   // occupancy-scan grid of the next batch: 2x what this one needed, shrunk only when 4x too large
+        uint32_t tiles = 0;
+        for (uint32_t f = 0; f < c->nframes; ++f)
+            if (c->slots[f].h_state->vpath) tiles = std::max(tiles, div_up(c->slots[f].h_state->vmap_words, kVmapTile));
+        if (tiles) {
+            const uint32_t want = std::min(kVmapCells / 32u / kVmapTile, pow2_at_least(tiles) * 2u);
+            if (c->vtiles > 2u * want) c->vtiles = want;
+        }
+    }
     for (uint32_t f = 0; f < c->nframes; ++f) order_frame(c, c->slots[f], (out && f < nout) ? out + f : nullptr);
     return PCOP_OK;
 }
@@ -463,6 +523,13 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
     TRY(dev_alloc(c, &f.pt_slot, n + 1)); TRY(dev_alloc(c, &f.pt_rank, n + 1)); TRY(dev_alloc(c, &f.pt_root, n + 1));
     TRY(dev_alloc(c, &f.idx_a, n + 1)); TRY(dev_alloc(c, &f.idx_b, n + 1)); TRY(dev_alloc(c, &f.d_offsets, n + 2));
     TRY(dev_alloc(c, &f.d_xyzr, n + 1));
+    if (c->voxel_stream) {
+        TRY(dev_alloc(c, &f.vflag, (size_t)kVmapCells));
+        HIPCHK(c, hipMemset(f.vflag.get(), 0, (size_t)kVmapCells));   // the kernels keep it all zero between frames
+        TRY(dev_alloc(c, &f.vmap, (size_t)kVmapCells / 32u));
+        TRY(dev_alloc(c, &f.vkey, n + 1));
+        TRY(dev_alloc(c, &f.vtile, (size_t)kVmapCells / 32u / kVmapTile));
+    }
     TRY(host_alloc(c, &sl.h_args, 1));
     TRY(host_alloc(c, &sl.h_state, 1));
     TRY(host_alloc(c, &sl.h_offsets_disc, n + 2)); TRY(host_alloc(c, &sl.h_indices_disc, n + 1));
@@ -531,6 +598,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     }
     c->maxbits = c->radix_bits_target <= kNarrowBits ? kNarrowBits : kMaxBits;
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
+    if (const char* e = getenv("PCOP_VOXEL_PATH")) c->voxel_stream = std::string(e) != "sort";
     if (const char* e = getenv("PCOP_CELL_BLOCKS")) c->cell_blocks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_STRIDE_BLOCKS")) c->stride_blocks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_DEBUG_SKIP_UNION")) c->debug_skip_union = (uint32_t)atoi(e);
@@ -577,6 +645,7 @@ int pcop_max_frames(const pcop_ctx* c) { return c ? (int)c->max_frames : 0; }
 
 int pcop_set_params(pcop_ctx* c, const pcop_params* p) {
     if (!c || !p) return PCOP_ERR_ARG;
+    if (!c->params_set || p->leaf != c->params.leaf) c->stream_ok = true;   // a new leaf size is a new voxel grid
     c->params = *p;
     c->params_set = true;
     return PCOP_OK;
@@ -775,6 +844,7 @@ int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* byt
         {"pt_root", f.pt_root, n * 4}, {"idx_a", f.idx_a, n * 4}, {"idx_b", f.idx_b, n * 4},
         {"d_offsets", f.d_offsets, (n + 1) * 4}, {"bin_total", f.bin_total, (size_t)kMaxBins * 4},
         {"todo", f.todo, (n + 1) * 4}, {"cell_list", f.cell_list, n * 4},
+        {"vkey", f.vkey, n * 4}, {"vflag", f.vflag, f.vflag.get() ? (size_t)kVmapCells : 0},
     };
     for (const Ent& e : tab) {
         if (std::strcmp(e.nm, name) == 0) { *dev_ptr = e.p; *bytes = e.b; return PCOP_OK; }

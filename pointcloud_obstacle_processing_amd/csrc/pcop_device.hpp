@@ -49,6 +49,11 @@ constexpr int kScanTile = kBlock * kScanItems;
 constexpr int kReduceBlocks = 256;               // grid of the min/max kernel: one block per CU, short ticket queue
 constexpr int kCellBias = 1 << 20;               // cell coordinates are stored biased, 21 bits per axis
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+constexpr uint32_t kVmapCells = 1u << 26;       // streaming voxel path: largest voxel grid (cells) with an occupancy map
+constexpr uint32_t kVmapTile = 1024;            // occupancy words per block of k_vmap_scan
+constexpr uint32_t kStreamBuckets = 256;        // buckets of the streaming voxel path (one 8-bit partition pass)
+constexpr uint32_t kVcapMin = 512, kVcapMax = 2048;   // voxels per bucket (LDS accumulators: 24 bytes per voxel)
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;        // voxel key / id of a dropped (non-finite) point
 
 // Pointers that live in device-visible structs (Frame, DevState, the mailbox).  A pointer loaded from
 // memory is a generic ("flat") pointer to the compiler, and every access through it becomes a
@@ -78,6 +83,8 @@ enum ErrBits : uint32_t {
     kErrReplanCsr = 8u,    // cluster-rank key needs more radix passes than were launched
     kErrRange = 16u,       // a cell coordinate leaves +-2^20 cells (|p| / tol too large)
     kErrInternal = 32u,    // a bounded wait inside a kernel ran out (never expected)
+    kErrReplanPath = 64u,  // the streaming voxel path does not apply to this frame (grid or voxel count too large)
+    kErrReplanVcap = 128u, // the streaming voxel path needs more voxels per bucket than the launch provided LDS for
 };
 
 enum FrameKind : uint32_t { kFrameChain = 0, kFrameVoxelOnly = 1, kFrameClusterOnly = 2 };
@@ -96,6 +103,7 @@ struct FrameArgs {
     double inv_cell;                          // 1.99 / |tol|
     uint32_t min_cluster, max_cluster;
     uint32_t emit_cloud, out_layout, out_soa_stride, debug_skip_union;
+    uint32_t voxel_stream, vcap;              // streaming voxel path requested; voxels per bucket the launch has LDS for
     DevPtr<const float> src_x, src_y, src_z;
 };
 
@@ -128,7 +136,12 @@ struct DevState {
     uint32_t n_kept_pts;    // sum of their sizes
     RadixPlan plan_csr;
     uint32_t debug_skip_union;   // diagnostics: leave the hook forest untouched
-    uint32_t pad[1];
+    // streaming voxel path
+    uint32_t vpath;         // 1: this frame's voxel stage runs the streaming path
+    uint32_t vmap_words;    // occupancy words in use = ceil(cells / 32)
+    uint32_t vshift;        // bucket of a voxel = id >> vshift
+    uint32_t nbuckets;
+    uint32_t vcap;          // voxels per bucket the launch has LDS for
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState layout");
 
@@ -156,6 +169,11 @@ struct Frame {
     DevPtr<uint32_t> pt_slot, pt_rank, pt_root;
     DevPtr<uint32_t> idx_a, idx_b, d_offsets;
     DevPtr<float4> d_xyzr;
+    // streaming voxel path (null when the context was created without it)
+    DevPtr<uint8_t> vflag;            // one byte per voxel-grid cell: occupied?  all zero between frames
+    DevPtr<uint2> vmap;               // per 32 cells: {occupancy bits, occupied cells before this word}
+    DevPtr<uint32_t> vkey;            // per input point: voxel key, then voxel id (rank among occupied cells)
+    DevPtr<uint32_t> vtile;           // per occupancy tile: its popcount + 1 once known (0 = not yet)
     // pinned host outputs
     DevPtr<DevState> h_state;
     DevPtr<uint32_t> h_offsets;       // n_kept + 1, discovery order
@@ -323,6 +341,7 @@ __global__ void k_frame_init(Frame* frames) {
         s.min_cluster = a.min_cluster; s.max_cluster = a.max_cluster;
         s.src_x = a.src_x; s.src_y = a.src_y; s.src_z = a.src_z;
         s.debug_skip_union = a.debug_skip_union;
+        s.vcap = a.vcap;
         if (a.kind == kFrameClusterOnly) {   // no voxel stage: cluster the input cloud as it is
             s.c_from_input = 1; s.c_n = a.n; s.n_valid = a.n;
             uint32_t cap = 1024;
@@ -358,13 +377,18 @@ __global__ __launch_bounds__(kBlock) void k_unpack_points(const uint8_t* __restr
 // min / max (pcl::getMinMax3D) + grid set-up by the last block to arrive
 // ------------------------------------------------------------------------------------------
 // VoxelGrid::applyFilter up to "divb_mul_ = ..." (SURVEY.md §8a-1 steps 1-4).
-__device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p, uint32_t npass, uint32_t maxbits) {
+__device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m);
+
+__device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p, uint32_t npass, uint32_t maxbits, bool stream) {
     if (st->is_dense && p.nonfinite) { atomicOr(&st->err, (uint32_t)kErrNonFinite); return; }
     st->n_valid = p.valid;
     for (int a = 0; a < 3; ++a) { st->vmin[a] = p.mn[a]; st->vmax[a] = p.mx[a]; }
     for (int a = 0; a < 3; ++a) { st->min_b[a] = 0; st->div_b[a] = 1; st->mul[a] = 1; }
     make_plan(&st->plan_voxel, 1, npass, maxbits);
-    if (p.valid == 0) return;   // empty cloud -> empty output
+    if (p.valid == 0) {   // empty cloud -> empty output
+        if (stream) finish_voxel(st, 0);
+        return;
+    }
     const float inv = st->inv_leaf;
     // dx = (int64)((max - min) * inv) + 1; overflow rule: dx*dy*dz > INT32_MAX -> output = input
     long long d[3];
@@ -378,7 +402,11 @@ __device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p
         const long long dxy = d[0] * d[1];
         if (dxy > lim || dxy * d[2] > lim) ok = false;
     }
-    if (!ok) { st->passthrough = 1; return; }
+    if (!ok) {
+        st->passthrough = 1;
+        if (stream) finish_voxel(st, st->n_in);   // "output = *input_": the sort path does this in k_voxel_reduce
+        return;
+    }
     int32_t div[3];
     for (int a = 0; a < 3; ++a) {
         const int32_t lo = (int32_t)floorf(p.mn[a] * inv);
@@ -390,7 +418,14 @@ __device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p
     st->mul[0] = 1u; st->mul[1] = (uint32_t)div[0]; st->mul[2] = (uint32_t)div[0] * (uint32_t)div[1];
     const uint64_t cells = (uint64_t)(uint32_t)div[0] * (uint32_t)div[1] * (uint32_t)div[2];
     const uint32_t kb = cells > 0xFFFFFFFFull ? 32u : bits_for(cells);
-    if (!make_plan(&st->plan_voxel, kb, npass, maxbits)) atomicOr(&st->err, (uint32_t)kErrReplanVoxel);
+    const bool fits = make_plan(&st->plan_voxel, kb, npass, maxbits);
+    if (stream) {
+        if (cells > (uint64_t)kVmapCells) { atomicOr(&st->err, (uint32_t)kErrReplanPath); return; }
+        st->vpath = 1u;
+        st->vmap_words = (uint32_t)((cells + 31u) / 32u);
+    } else if (!fits) {
+        atomicOr(&st->err, (uint32_t)kErrReplanVoxel);
+    }
 }
 
 __device__ __forceinline__ void reduce_partials_lds(MinMaxPartial* s_p) {   // kBlock entries -> s_p[0]
@@ -452,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_minmax(Frame* frames) {
 }
 
 // one block per frame: reduce the block partials and derive the voxel grid
-__global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t nblocks, uint32_t npass, uint32_t maxbits) {
+__global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t nblocks, uint32_t npass, uint32_t maxbits, uint32_t stream) {
     __shared__ MinMaxPartial s_p[kBlock];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
@@ -469,7 +504,12 @@ __global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t 
     }
     s_p[threadIdx.x] = q;
     reduce_partials_lds(s_p);
-    if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass, maxbits);
+    if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass, maxbits, stream != 0u);
+    if (stream) {   // k_vmap_scan publishes its tile counts in vtile
+        uint32_t* __restrict__ vtile = F.vtile;
+        for (uint32_t t = threadIdx.x; t < kVmapCells / 32u / kVmapTile; t += kBlock) vtile[t] = 0u;
+        return;
+    }
     // k_voxel_reduce publishes "heads of tile t, plus one" here; zero = not yet published
     uint32_t* __restrict__ tile_heads = F.tile_a;
     const uint32_t ntiles = (st->n_in + kScanTile - 1) / kScanTile;
@@ -544,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_hist(const Frame* frames, int 
     for (uint32_t b = threadIdx.x; b < pi.nb; b += kBlock) table[(size_t)b * ntiles + blockIdx.x] = s_h[b];
 }
 
-// which = 0: voxel partition pass, 2: CSR partition pass
+// which = 0: voxel partition pass, 1: bucket partition of the streaming voxel path, 2: CSR partition pass
 __device__ __forceinline__ bool table_dims(const DevState* st, int which, int pass, uint32_t* ntiles, uint32_t* nb) {
     if (st->err) return false;
     if (which == 2) {
@@ -554,6 +594,12 @@ __device__ __forceinline__ bool table_dims(const DevState* st, int which, int pa
         return st->n_kept != 0;
     }
     if (voxel_stage_off(st)) return false;
+    if (which == 1) {   // the bucket partition of the streaming voxel path
+        if (!st->vpath || st->n_valid == 0) return false;
+        *nb = st->nbuckets + 1u;
+        *ntiles = (st->n_in + kTile - 1) / kTile;
+        return true;
+    }
     const PassInfo pi = pass_info(st, pass);
     *nb = pi.nb;
     *ntiles = (pi.count + kTile - 1) / kTile;
@@ -861,6 +907,316 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t h = k * kBlock + threadIdx.x;
         if (h < tot) { cx[before + h] = ox[k]; cy[before + h] = oy[k]; cz[before + h] = oz[k]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming voxel path (default when the voxel grid has at most kVmapCells cells and the frame at
+// most kStreamBuckets * kVcapMax voxels; otherwise the host re-runs the frame on the sort path).
+//
+// PCL sorts the points by voxel key and sums every run in order.  What that needs is (a) the
+// rank of every occupied voxel in key order and (b) for every voxel its points in index order.
+//   k_vox_mark     : key of every point; one byte per grid cell set for the occupied ones
+//   k_vmap_scan    : bytes -> occupancy bits + running popcount  =>  voxel id = rank in key order, M
+//   k_vid_hist / k_table_scan / k_vid_scatter : ONE stable 8-bit partition of {x,y,z,id} records
+//                    by bucket = id >> vshift (up to 256 buckets of up to vcap voxels)
+//   k_voxel_stream : one wave per bucket walks the bucket's records in order (= index order) and
+//                    adds each to its voxel's accumulator in LDS, starting from 0.0f; lanes that
+//                    hit the same voxel in one step go in lane order.  cen[id] = sum / float(count).
+// Same float operations in the same order as the sort path, at about half of its HBM traffic.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool stream_off(const DevState* st) {
+    return voxel_stage_off(st) || !st->vpath || st->n_valid == 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_vox_mark(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    uint8_t* __restrict__ vflag = F.vflag; uint32_t* __restrict__ vkey = F.vkey;
+    if (stream_off(st)) return;
+    const float* __restrict__ x = st->src_x; const float* __restrict__ y = st->src_y; const float* __restrict__ z = st->src_z;
+    const uint32_t n = st->n_in;
+    const bool drop = st->is_dense == 0;
+    VoxelKey key; key.init(st);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Rec3 r; r.x = x[i]; r.y = y[i]; r.z = z[i];
+        uint32_t k = kNoKey;
+        if (!drop || finite3(r.x, r.y, r.z)) {
+            k = key(r);
+            vflag[k] = 1;   // every writer stores the same value: no atomic needed
+        }
+        vkey[i] = k;
+    }
+}
+
+// 16 flag bytes (each 0 or 1) -> 16 bits
+__device__ __forceinline__ uint32_t flags_to_bits(const uint4& v) {
+    const uint32_t a = ((v.x & 0x01010101u) * 0x01020408u) >> 24, b = ((v.y & 0x01010101u) * 0x01020408u) >> 24;
+    const uint32_t c = ((v.z & 0x01010101u) * 0x01020408u) >> 24, d = ((v.w & 0x01010101u) * 0x01020408u) >> 24;
+    return (a & 15u) | ((b & 15u) << 4) | ((c & 15u) << 8) | ((d & 15u) << 12);
+}
+
+// One block per kVmapTile occupancy words: bytes -> bits (and the bytes are zeroed again for the
+// next frame), popcount scan; the tile publishes its count and adds up the counts of the lower
+// tiles (same publish / bounded-wait scheme as k_voxel_reduce).  The last tile knows M.
+__global__ __launch_bounds__(kBlock) void k_vmap_scan(Frame* frames) {
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    __shared__ uint16_t s_half[2 * kVmapTile];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    uint4* __restrict__ flags = reinterpret_cast<uint4*>(F.vflag.get());
+    uint2* __restrict__ vmap = F.vmap; uint32_t* __restrict__ vtile = F.vtile;
+    // Runs whenever k_vox_mark ran (the replan bits this kernel raises itself must not stop its other
+    // tiles: every tile has flag bytes to turn back to zero).
+    const uint32_t own = (uint32_t)(kErrReplanPath | kErrReplanVcap | kErrInternal);
+    if ((st->err & ~own) || st->passthrough || st->kind == kFrameClusterOnly || !st->vpath || st->n_valid == 0) return;
+    const uint32_t words = st->vmap_words;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && words > gridDim.x * kVmapTile)
+        atomicOr(&st->err, (uint32_t)kErrReplanVcap);   // the host sized this grid from the previous frame: re-run with more tiles
+    const uint32_t base = blockIdx.x * kVmapTile;
+    if (base >= words) return;
+    const uint32_t cnt = min(kVmapTile, words - base);
+    // a word = 32 cells = two 16-byte loads; the flag array is padded to whole tiles
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * kVmapTile / kBlock; ++k) {
+        const uint32_t h = k * kBlock + threadIdx.x;   // half-word of the tile
+        uint32_t bits = 0;
+        if (h < 2 * cnt) {
+            const size_t at = (size_t)base * 2 + h;
+            bits = flags_to_bits(flags[at]);
+            if (bits) flags[at] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        s_half[h] = (uint16_t)bits;
+    }
+    __syncthreads();
+    constexpr uint32_t kPer = kVmapTile / kBlock;   // consecutive words per thread
+    uint32_t w[kPer];
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+        const uint32_t j = threadIdx.x * kPer + k;
+        w[k] = (uint32_t)s_half[2 * j] | ((uint32_t)s_half[2 * j + 1] << 16);
+        c += __popc(w[k]);
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan(c, s_w, &tot);
+    if (threadIdx.x == 0) st_agent(vtile + blockIdx.x, tot + 1u);   // publish
+    uint32_t mine = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
+        uint32_t v = ld_agent(vtile + t), spins = 0;
+        while (v == 0u) {
+            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
+            __builtin_amdgcn_s_sleep(2);
+            v = ld_agent(vtile + t);
+        }
+        mine += v - 1u;
+    }
+    __syncthreads();   // s_w is reused
+    const uint32_t before = block_sum(mine, s_w);
+    run += before;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+        const uint32_t j = threadIdx.x * kPer + k;
+        if (j < cnt) vmap[base + j] = make_uint2(w[k], run);
+        run += __popc(w[k]);
+    }
+    if (threadIdx.x == 0 && base + kVmapTile >= words) {   // the last tile: M and the bucket plan
+        const uint32_t m = before + tot;
+        finish_voxel(st, m);
+        uint32_t sh = 0;
+        while (((uint64_t)kStreamBuckets << sh) < (uint64_t)m) ++sh;   // 256 buckets of 2^sh voxels cover M
+        st->vshift = sh;
+        st->nbuckets = m ? ((m - 1u) >> sh) + 1u : 0u;
+        if ((1u << sh) > kVcapMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
+        else if ((1u << sh) > st->vcap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
+    }
+}
+
+// voxel id of a key: occupied cells before it in key order
+__device__ __forceinline__ uint32_t voxel_id(const uint2* __restrict__ vmap, uint32_t key) {
+    const uint2 e = vmap[key >> 5];
+    return e.y + __popc(e.x & ((1u << (key & 31u)) - 1u));
+}
+
+template <int MAXB>
+__global__ __launch_bounds__(kBlock) void k_vid_hist(const Frame* frames) {
+    __shared__ uint32_t s_h[(1 << MAXB) + 1];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    uint32_t* __restrict__ table = F.table; uint32_t* __restrict__ vkey = F.vkey;
+    const uint2* __restrict__ vmap = F.vmap;
+    if (stream_off(st)) return;
+    const uint32_t n = st->n_in;
+    const uint32_t tile_base = blockIdx.x * kTile;
+    if (tile_base >= n) return;
+    const uint32_t nb = st->nbuckets + 1u, sh = st->vshift;
+    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) s_h[b] = 0;
+    __syncthreads();
+    const uint32_t wbase = tile_base + (threadIdx.x / kWave) * (kItems * kWave) + lane_id();
+    uint32_t k[kItems];
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) { const uint32_t i = wbase + j * kWave; k[j] = i < n ? vkey[i] : kNoKey; }
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+        const uint32_t i = wbase + j * kWave;
+        if (i < n) {
+            uint32_t d = nb - 1u;
+            if (k[j] != kNoKey) {
+                const uint32_t id = voxel_id(vmap, k[j]);
+                vkey[i] = id;   // key -> id, in place
+                d = id >> sh;
+            }
+            atomicAdd(&s_h[d], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t ntiles = (n + kTile - 1) / kTile;
+    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) table[(size_t)b * ntiles + blockIdx.x] = s_h[b];
+}
+
+// The partition of the streaming path: records {x, y, z, id} go to rec_b, stable, bucket-major.
+template <int MAXB>
+__global__ __launch_bounds__(kBlock) void k_vid_scatter(const Frame* frames) {
+    constexpr int kBins = (1 << MAXB) + 1;
+    __shared__ uint32_t s_hist[kWavesPerBlock * kBins];
+    __shared__ uint32_t s_base[kBins];
+    __shared__ uint32_t s_lbase[kBins];
+    __shared__ uint32_t s_delta[kBins];
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    __shared__ float4 s_stage[kTile];
+    unsigned long long* s_match = reinterpret_cast<unsigned long long*>(s_stage);
+    static_assert(MAXB <= kNarrowBits, "the streaming path partitions on an 8-bit digit");
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint32_t* __restrict__ table_x = F.table_x; const uint32_t* __restrict__ bin_total = F.bin_total;
+    const uint32_t* __restrict__ vkey = F.vkey;
+    float4* __restrict__ out = F.rec_b;
+    if (stream_off(st)) return;
+    const uint32_t n = st->n_in;
+    const uint32_t tile_base = blockIdx.x * kTile;
+    if (tile_base >= n) return;
+    const float* __restrict__ x = st->src_x; const float* __restrict__ y = st->src_y; const float* __restrict__ z = st->src_z;
+    const uint32_t nb = st->nbuckets + 1u, sh = st->vshift;
+    for (uint32_t b = threadIdx.x; b < kWavesPerBlock * nb; b += kBlock) s_hist[b] = 0;
+    for (uint32_t b = threadIdx.x; b < (uint32_t)(kWavesPerBlock * kBins); b += kBlock) s_match[b] = 0ull;
+    scan_bins_to_lds<MAXB>(bin_total, nb, s_base, s_w);   // ends with a barrier
+    const uint32_t w = threadIdx.x / kWave;
+    uint32_t* hist_w = s_hist + w * nb;
+    const uint32_t wbase = tile_base + w * (kItems * kWave) + lane_id();
+    float4 rec[kItems];
+    uint32_t dig[kItems], lrank[kItems];
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+        const uint32_t i = wbase + j * kWave;
+        if (i < n) rec[j] = make_float4(x[i], y[i], z[i], u2f(vkey[i]));
+    }
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+        const uint32_t i = wbase + j * kWave;
+        const bool active = i < n;
+        uint32_t d = 0;
+        if (active) { const uint32_t id = f2u(rec[j].w); d = id == kNoKey ? nb - 1u : id >> sh; }
+        const uint64_t peers = match_digit_lds(s_match + w * kBins, d, active);
+        const uint32_t rank = __popcll(peers & lanemask_lt());
+        uint32_t old = 0;
+        if (active) old = hist_w[d];
+        if (active && rank == 0) hist_w[d] = old + (uint32_t)__popcll(peers);
+        dig[j] = d; lrank[j] = old + rank;
+    }
+    __syncthreads();
+    const uint32_t ntiles = (n + kTile - 1) / kTile;
+    constexpr int kPer = (kBins + kBlock - 1) / kBlock;
+    uint32_t tcnt[kPer], gstart[kPer];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const uint32_t b = threadIdx.x * kPer + k;
+        tcnt[k] = 0; gstart[k] = 0;
+        if (b < nb) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int q = 0; q < kWavesPerBlock; ++q) {
+                const uint32_t t = s_hist[q * nb + b];
+                s_hist[q * nb + b] = run;
+                run += t;
+            }
+            tcnt[k] = run;
+            gstart[k] = s_base[b] + table_x[(size_t)b * ntiles + blockIdx.x];
+        }
+        tsum += tcnt[k];
+    }
+    uint32_t ttot;
+    uint32_t lrun = block_excl_scan(tsum, s_w, &ttot);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const uint32_t b = threadIdx.x * kPer + k;
+        if (b < nb) { s_lbase[b] = lrun; s_delta[b] = gstart[k] - lrun; }
+        lrun += tcnt[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+        const uint32_t i = wbase + j * kWave;
+        if (i < n) s_stage[s_lbase[dig[j]] + hist_w[dig[j]] + lrank[j]] = rec[j];
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < ttot; e += kBlock) {
+        const float4 v = s_stage[e];
+        const uint32_t id = f2u(v.w);
+        const uint32_t d = id == kNoKey ? nb - 1u : id >> sh;
+        out[e + s_delta[d]] = v;
+    }
+}
+
+// One wave per bucket.  Dynamic LDS: float4 acc[vcap] {sum x, sum y, sum z, count} and
+// unsigned long long peers[vcap].
+__global__ __launch_bounds__(kWave) void k_voxel_stream(const Frame* frames) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = F.rec_b;
+    const uint32_t* __restrict__ bin_total = F.bin_total;
+    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
+    if (stream_off(st)) return;
+    const uint32_t b = blockIdx.x;
+    if (b >= st->nbuckets) return;
+    const uint32_t vcap = st->vcap, sh = st->vshift, m = st->m;
+    float4* acc = reinterpret_cast<float4*>(s_dyn);
+    unsigned long long* peers_w = reinterpret_cast<unsigned long long*>(s_dyn + (size_t)vcap * sizeof(float4));
+    const uint32_t lane = lane_id();
+    // records of the bucket: [start, start + count)
+    uint32_t before = 0;
+    for (uint32_t t = lane; t < b; t += kWave) before += bin_total[t];
+    const uint32_t start = wave_sum(before), count = bin_total[b];
+    const uint32_t id0 = b << sh;
+    const uint32_t nv = min(1u << sh, m - id0);   // voxels of this bucket
+    for (uint32_t v = lane; v < nv; v += kWave) { acc[v] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u)); peers_w[v] = 0ull; }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t steps = (count + kWave - 1) / kWave;
+    float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (lane < count) nxt = rec[start + lane];
+    for (uint32_t sidx = 0; sidx < steps; ++sidx) {
+        const float4 r = nxt;
+        const uint32_t i = sidx * kWave + lane;
+        const bool active = i < count;
+        if (i + kWave < count) nxt = rec[start + i + kWave];   // next step's records are in flight during this one
+        const uint32_t lv = active ? f2u(r.w) - id0 : 0u;
+        const uint64_t peers = match_digit_lds(peers_w, lv, active);
+        const uint32_t rank = __popcll(peers & lanemask_lt());
+        const uint32_t rounds = wave_max(active ? rank + 1u : 0u);
+        for (uint32_t q = 0; q < rounds; ++q) {   // same voxel: lane order = index order
+            if (active && rank == q) {
+                float4 a = acc[lv];
+                a.x += r.x; a.y += r.y; a.z += r.z; a.w = u2f(f2u(a.w) + 1u);
+                acc[lv] = a;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    for (uint32_t v = lane; v < nv; v += kWave) {
+        const float4 a = acc[v];
+        const float fc = (float)f2u(a.w);
+        cx[id0 + v] = a.x / fc; cy[id0 + v] = a.y / fc; cz[id0 + v] = a.z / fc;
     }
 }
 

@@ -19,9 +19,21 @@ def capi():
     return m
 
 
-@pytest.fixture(scope="module")
-def ctx(capi):
-    c = capi.Context(1_100_000)
+@pytest.fixture(scope="module", params=["stream", "sort"])
+def ctx(capi, request):
+    """Every test that takes `ctx` runs on both voxel paths: the streaming one (default) and the sort one
+    (PCOP_VOXEL_PATH=sort, read when the context is created; also the fallback of the streaming one)."""
+    import os
+    old = os.environ.get("PCOP_VOXEL_PATH")
+    os.environ["PCOP_VOXEL_PATH"] = request.param
+    try:
+        c = capi.Context(1_100_000)
+    finally:
+        if old is None:
+            os.environ.pop("PCOP_VOXEL_PATH", None)
+        else:
+            os.environ["PCOP_VOXEL_PATH"] = old
+    c.voxel_path = request.param
     yield c
     c.close()
 
@@ -198,16 +210,44 @@ def test_voxel_stage_matches_oracle(ctx, oracle, layout, seed, n, leaf):
 
 def test_voxel_stage_sorted_records_are_stable(ctx, oracle):
     """Stage-wise: after the partition passes the 12-byte records are ordered by (voxel key, point index)."""
+    if ctx.voxel_path != "sort":
+        pytest.skip("records of the sort path")
     pts = synth.uniform_field(30_000, 9)
     ctx.set_params(leaf=0.1, tol=0.1)
     ctx.voxel_downsample(pts)
     st = ctx.debug_state()
+    assert st.vpath == 0
     npass = st.plan_voxel.npass
     rec = ctx.debug_buffer("rec_a" if npass % 2 == 1 else "rec_b", np.float32, 3 * len(pts)).reshape(-1, 3)
     keys, grid, _ = oracle.voxel_keys(pts, 0.1)
     assert list(grid[:3]) == list(st.min_b) and list(grid[3:6]) == list(st.div_b)
     order = np.lexsort((np.arange(len(pts)), keys.astype(np.int64)))      # by key, ties by point index
     assert rec.tobytes() == pts[order].tobytes()
+
+
+def test_voxel_stage_stream_ids_and_records(ctx, oracle):
+    """Stage-wise, streaming path: every point's voxel id is the rank of its key among the occupied cells, the
+    partitioned records are ordered by (bucket, point index), and the occupancy flags are all zero again."""
+    if ctx.voxel_path != "stream":
+        pytest.skip("buffers of the streaming path")
+    pts = synth.uniform_field(30_000, 9)
+    ctx.set_params(leaf=0.1, tol=0.1)
+    ctx.voxel_downsample(pts)
+    st = ctx.debug_state()
+    assert st.vpath == 1 and st.m > 0
+    keys, grid, _ = oracle.voxel_keys(pts, 0.1)
+    assert list(grid[:3]) == list(st.min_b) and list(grid[3:6]) == list(st.div_b)
+    uniq, ids_ref = np.unique(keys.astype(np.int64), return_inverse=True)
+    assert st.m == len(uniq)
+    ids = ctx.debug_buffer("vkey", np.uint32, len(pts))
+    assert np.array_equal(ids, ids_ref.astype(np.uint32))
+    assert st.nbuckets == ((st.m - 1) >> st.vshift) + 1 and st.nbuckets <= 256 and (1 << st.vshift) <= st.vcap
+    rec = ctx.debug_buffer("rec_b", np.float32, 4 * len(pts)).reshape(-1, 4)
+    order = np.lexsort((np.arange(len(pts)), ids_ref >> st.vshift))       # by bucket, ties by point index
+    assert rec[:, :3].tobytes() == pts[order].tobytes()
+    assert np.array_equal(rec[:, 3].copy().view(np.uint32), ids_ref[order].astype(np.uint32))
+    flags = ctx.debug_buffer("vflag", np.uint8, 1 << 26)
+    assert not flags.any()
 
 
 @pytest.mark.parametrize("cfg,n,mn,mx", [("C1", 10_000, 5, 20000), ("C1", 10_000, 1, 10**9), ("C2", 30_000, 5, 10**9),
@@ -379,6 +419,7 @@ def test_radix_replanning_and_digit_widths(capi, oracle, monkeypatch):
     p = synth.params_of("C3")
     pts = synth.make_cloud("C3", n=150_000, seed=77)
     ref = oracle.process_xyz(pts, **p)
+    monkeypatch.setenv("PCOP_VOXEL_PATH", "sort")   # the pass plan under test belongs to the sort path
     for bits in ("5", "8", "11"):
         monkeypatch.setenv("PCOP_RADIX_BITS", bits)
         c = capi.Context(len(pts))
@@ -395,3 +436,86 @@ def test_radix_replanning_and_digit_widths(capi, oracle, monkeypatch):
         assert_same_cloud(got["voxel_xyz"], refb["voxel_xyz"])
         assert_same_clusters(got["offsets"], got["indices"], refb["offsets"], refb["indices"])
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# streaming voxel path: its own re-planning (LDS per bucket, occupancy grid) and its fallbacks
+# ---------------------------------------------------------------------------------------------
+def test_stream_path_grows_and_falls_back(capi, oracle, monkeypatch):
+    monkeypatch.setenv("PCOP_VOXEL_PATH", "stream")
+    c = capi.Context(1_000_000)
+    # (1) small cloud: streaming path, smallest bucket size
+    p = synth.params_of("C3")
+    pts = synth.make_cloud("C3", n=150_000, seed=5)
+    c.set_params(publish_clouds=1, **p)
+    got = c.process_xyz(pts)
+    ref = oracle.process_xyz(pts, **p)
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    st = c.debug_state()
+    assert st.vpath == 1 and st.vcap == 512
+    # (2) more than 256 * 512 voxels: one re-run with more LDS per bucket, then it stays there
+    big = synth.make_cloud("C3L10", n=1_000_000, seed=3)
+    pl = synth.params_of("C3L10")
+    c.set_params(publish_clouds=1, **pl)
+    refb = oracle.process_xyz(big, **pl)
+    for rep in range(2):
+        got = c.process_xyz(big)
+        assert_same_cloud(got["voxel_xyz"], refb["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], refb["offsets"], refb["indices"])
+    st = c.debug_state()
+    assert st.vpath == 1 and st.m > 256 * 512 and st.vcap == 2048
+    # (3) the small cloud again on the grown context
+    c.set_params(publish_clouds=1, **p)
+    got = c.process_xyz(pts)
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    # (4) more than 256 * 2048 voxels: falls back to the sort path (and stays on it for this leaf size)
+    dense = synth.uniform_field(700_000, 11) * f32(2.0)         # grid below 2^26 cells, voxels above 256 * 2048
+    c.set_params(publish_clouds=1, leaf=0.012, tol=0.05, min_cluster=2, max_cluster=20000)
+    refd = oracle.process_xyz(dense, leaf=0.012, tol=0.05, min_cluster=2, max_cluster=20000)
+    assert len(refd["voxel_xyz"]) > 256 * 2048
+    for rep in range(2):
+        got = c.process_xyz(dense)
+        assert_same_cloud(got["voxel_xyz"], refd["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], refd["offsets"], refd["indices"])
+    assert c.debug_state().vpath == 0
+    # (5) a new leaf size puts the context back on the streaming path
+    c.set_params(publish_clouds=1, **p)
+    got = c.process_xyz(pts)
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert c.debug_state().vpath == 1
+    assert not c.debug_buffer("vflag", np.uint8, 1 << 26).any()
+    c.close()
+
+
+def test_stream_path_grid_too_large_falls_back(capi, oracle, monkeypatch):
+    """A voxel grid of more than 2^26 cells has no occupancy map: sort path, same answer."""
+    monkeypatch.setenv("PCOP_VOXEL_PATH", "stream")
+    c = capi.Context(200_000)
+    pts = synth.uniform_field(100_000, 21) * f32(10.0)          # tens of metres at leaf 0.02: > 2^26 cells
+    c.set_params(publish_clouds=1, leaf=0.02, tol=0.1, min_cluster=2, max_cluster=20000)
+    ref = oracle.process_xyz(pts, leaf=0.02, tol=0.1, min_cluster=2, max_cluster=20000)
+    got = c.process_xyz(pts)
+    st = c.debug_state()
+    assert st.vpath == 0 and int(st.div_b[0]) * int(st.div_b[1]) * int(st.div_b[2]) > (1 << 26)
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    assert not c.debug_buffer("vflag", np.uint8, 1 << 26).any()
+    c.close()
+
+
+def test_stream_path_nonfinite_points_dropped(capi, oracle, monkeypatch):
+    monkeypatch.setenv("PCOP_VOXEL_PATH", "stream")
+    c = capi.Context(100_000)
+    pts = synth.make_cloud("C3", n=60_000, seed=8).copy()
+    pts[::97, 1] = np.nan
+    pts[5::211, 0] = np.inf
+    p = synth.params_of("C3")
+    c.set_params(publish_clouds=1, **p)
+    got = c.process_xyz(pts, is_dense=False)
+    ref = oracle.process_xyz(pts, is_dense=False, **p)
+    assert c.debug_state().vpath == 1
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    c.close()
