@@ -675,7 +675,7 @@ __device__ __forceinline__ uint64_t match_digit_lds(unsigned long long* match_w,
     unsigned long long peers = 0ull;
     if (active) atomicOr(match_w + d, 1ull << lane_id());
     __builtin_amdgcn_wave_barrier();
-    if (active) peers = *(volatile unsigned long long*)(match_w + d);
+    if (active) peers = match_w[d];   // not forwardable: the atomic OR above changed the word
     __builtin_amdgcn_wave_barrier();
     if (active && (peers & lanemask_lt()) == 0ull) match_w[d] = 0ull;
     __builtin_amdgcn_wave_barrier();
@@ -1193,24 +1193,40 @@ __global__ __launch_bounds__(kWave) void k_voxel_stream(const Frame* frames) {
     for (uint32_t v = lane; v < nv; v += kWave) { acc[v] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u)); peers_w[v] = 0ull; }
     __builtin_amdgcn_wave_barrier();
     const uint32_t steps = (count + kWave - 1) / kWave;
-    float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (lane < count) nxt = rec[start + lane];
-    for (uint32_t sidx = 0; sidx < steps; ++sidx) {
-        const float4 r = nxt;
-        const uint32_t i = sidx * kWave + lane;
+    // records two steps ahead are in flight while a step runs (clamped, unconditional loads: a load
+    // under a branch would be waited for at the branch's join)
+    const uint32_t last = start + count - 1u;
+    auto step = [&](const float4& r, uint32_t i) {
         const bool active = i < count;
-        if (i + kWave < count) nxt = rec[start + i + kWave];   // next step's records are in flight during this one
         const uint32_t lv = active ? f2u(r.w) - id0 : 0u;
         const uint64_t peers = match_digit_lds(peers_w, lv, active);
-        const uint32_t rank = __popcll(peers & lanemask_lt());
-        const uint32_t rounds = wave_max(active ? rank + 1u : 0u);
-        for (uint32_t q = 0; q < rounds; ++q) {   // same voxel: lane order = index order
-            if (active && rank == q) {
+        const uint32_t rank = active ? (uint32_t)__popcll(peers & lanemask_lt()) : 0xFFFFFFFFu;
+        for (uint32_t q = 0; __any(active && rank >= q); ++q) {   // same voxel: lane order = index order
+            if (rank == q) {
                 float4 a = acc[lv];
                 a.x += r.x; a.y += r.y; a.z += r.z; a.w = u2f(f2u(a.w) + 1u);
                 acc[lv] = a;
             }
             __builtin_amdgcn_wave_barrier();
+        }
+    };
+    // kStreamDepth register sets, each refilled right after it is consumed: a record is requested
+    // kStreamDepth - 1 steps (a few thousand cycles) before it is needed, and no set is ever copied
+    constexpr uint32_t kStreamDepth = 8;
+    float4 rs[kStreamDepth];
+#pragma unroll
+    for (uint32_t k = 0; k < kStreamDepth; ++k) {
+        rs[k] = rec[min(start + k * kWave + lane, last)];
+        __builtin_amdgcn_sched_barrier(0);   // keep the issue order = the order of use (the waits count loads in order)
+    }
+    for (uint32_t sidx = 0; sidx < steps; sidx += kStreamDepth) {
+#pragma unroll
+        for (uint32_t k = 0; k < kStreamDepth; ++k) {
+            const uint32_t i = (sidx + k) * kWave + lane;
+            if (sidx + k < steps) step(rs[k], i);   // wave-uniform
+            // not under the branch: a load issued inside it would be waited for at its join
+            rs[k] = rec[min(start + i + kStreamDepth * kWave, last)];
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     for (uint32_t v = lane; v < nv; v += kWave) {
