@@ -213,6 +213,18 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         frame_bytes = 12 * n0 + 28 * m_vox
         prof.close()
+        # the same figures for every kernel that takes at least 5 % of the batch, largest first
+        total_ms = sum(totals.values())
+        by_kernel = []
+        for nm in sorted(totals, key=lambda k: -totals[k]):
+            if not nm.startswith("k_") or totals[nm] < 0.05 * total_ms:
+                continue
+            ls = by_name[nm]
+            ms = sum(t for _, t in ls) / len(ls)
+            nbytes = B * sum(kernel_alg_bytes(nm, occ, n0, m_vox, n_cells) for occ, _ in ls) / len(ls)
+            by_kernel.append({"kernel": nm, "launches_per_batch": len(ls), "avg_launch_ms": round(ms, 5),
+                              "alg_bytes_per_launch": nbytes, "achieved_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                              "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         # HBM bytes per launch from the committed PMC passes of this command (profiles/), if they match
         traffic = None
         try:
@@ -238,6 +250,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes,
                          "frames_per_launch": B, "peak_measured_copy": 6290.0},
+            "roofline_by_kernel": by_kernel,
             "frame_roofline": {"alg_bytes_per_frame": frame_bytes,
                                "achieved_GBs_pipelined": frame_bytes * fps / world / 1e9,
                                "frac_pipelined": frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS,

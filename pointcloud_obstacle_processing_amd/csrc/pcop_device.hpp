@@ -4,10 +4,14 @@
 //
 //   voxel grid (replaces pcl::VoxelGrid::applyFilter, called at od.cpp:282-285)
 //     k_frame_init            mailbox -> DevState
-//     k_minmax_voxel_setup    pcl::getMinMax3D; the last block derives min_b/div_b/divb_mul,
-//                             the overflow rule and the radix plan
+//     k_minmax, k_voxel_setup pcl::getMinMax3D; min_b/div_b/divb_mul, the overflow rule, the plan
+//    streaming path (default):
+//     k_vox_mark, k_vmap_scan occupied grid cells -> voxel id = rank of the key, M
+//     k_vid_hist / k_table_scan / k_vid_scatter   one stable 8-bit partition of {x,y,z,id} by bucket
+//     k_voxel_stream          per bucket: in-order float32 sums in LDS accumulators -> centroids
+//    sort path (fallback for grids or voxel counts the streaming path does not cover):
 //     k_radix_hist / k_table_scan / k_radix_scatter   (x passes) stable LSD radix partition of
-//                             {x,y,z,idx} records by PCL's linear voxel index
+//                             packed xyz records by PCL's linear voxel index
 //     k_voxel_reduce          run heads -> rank; in-order float32 sums -> centroids
 //   cell grid (replaces the FLANN kd-tree built at od.cpp:791-792)
 //     k_cell_insert           points -> hash table of cells (edge tol/1.99), rank inside the cell

@@ -37,7 +37,9 @@ for cfg in cfgs:
     fps = reps * B / (time.perf_counter() - t)
     st = ctx.debug_state()
     print("%-6s N=%8d M=%8d K=%4d cells=%7d | centroids bit-exact %s (max abs err %.1e) indices bit-exact %s | "
-          "GPU latency %.3f ms, %8.1f frames/s (batch %d, 1 ctx) | oracle 1 core %.2f s = %.3f frames/s | passes voxel %d csr %d"
+          "GPU latency %.3f ms, %8.1f frames/s (batch %d, 1 ctx) | oracle 1 core %.2f s = %.3f frames/s | voxel path %s, csr passes %d"
           % (cfg, n, got["num_voxels"], len(got["offsets"]) - 1, st.n_cells, ok_vox, err, ok_idx,
-             1e3 * float(np.median(lat)), fps, B, t_or, 1.0 / t_or, st.plan_voxel.npass, st.plan_csr.npass), flush=True)
+             1e3 * float(np.median(lat)), fps, B, t_or, 1.0 / t_or,
+             "stream (%d buckets x %d voxels)" % (st.nbuckets, 1 << st.vshift) if st.vpath else "sort (%d passes)" % st.plan_voxel.npass,
+             st.plan_csr.npass), flush=True)
     ctx.close()
