@@ -33,7 +33,10 @@ inline bool compare_clusters(const ClusterRef& a, const ClusterRef& b) { return 
 struct GraphKey {
     uint32_t kind, bucket, npass_voxel, npass_csr, nframes;
     uint32_t stream, vcap, vtiles;   // streaming voxel path: on?, voxels per bucket (LDS), occupancy tiles (grid)
+    uint32_t cgrid, ctiles;          // dense cell grid: on?, occupancy tiles (grid)
     bool operator<(const GraphKey& o) const {
+        if (cgrid != o.cgrid) return cgrid < o.cgrid;
+        if (ctiles != o.ctiles) return ctiles < o.ctiles;
         if (stream != o.stream) return stream < o.stream;
         if (vcap != o.vcap) return vcap < o.vcap;
         if (vtiles != o.vtiles) return vtiles < o.vtiles;
@@ -101,6 +104,10 @@ struct pcop_ctx {
     bool voxel_stream = true, stream_ok = true;
     uint32_t vcap = kVcapMin;                               // voxels per bucket the launch provides LDS for (grows on demand)
     uint32_t vtiles = kVmapCells / 32u / kVmapTile;         // occupancy tiles launched (adapts to the grid seen)
+    // dense cell grid: on unless PCOP_CELL_PATH=hash; a frame whose grid exceeds kCmapCells is re-run on the hash
+    // table and the context stays there until the tolerance changes
+    bool cell_grid = true, cgrid_ok = true;
+    uint32_t ctiles = kCmapCells / 32u / kVmapTile;
     std::map<GraphKey, hipGraphExec_t> graphs;
 
     // profiling
@@ -176,6 +183,7 @@ uint32_t hash_cap_for(uint32_t n) {
     return cap;
 }
 
+bool grid_on(const pcop_ctx* c) { return c->cell_grid && c->cgrid_ok && c->kind != kFrameVoxelOnly; }
 bool stream_on(const pcop_ctx* c) { return c->voxel_stream && c->stream_ok && c->kind != kFrameClusterOnly; }
 
 // The launch sequence of one batch.  nb = launch-size bucket (>= every frame's point count), nf =
@@ -204,7 +212,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
         if (stream) {
             k_vox_mark<<<dim3(stride_grid(nb), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_vox_mark");
-            k_vmap_scan<<<dim3(c->vtiles, nf), kBlock, 0, s>>>(fr);
+            k_occ_scan<0><<<dim3(c->vtiles, nf), kBlock, 0, s>>>(fr);
             mark(c, "k_vmap_scan");
             k_vid_hist<kNarrowBits><<<pg, kBlock, 0, s>>>(fr);
             mark(c, "k_vid_hist");
@@ -228,22 +236,50 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
         }
     }
     if (kind != kFrameVoxelOnly) {
-        const uint32_t hcap = hash_cap_for(nb);
-        const dim3 hg(std::max(1u, hcap / kScanTile), nf);       // scan tiles over hash slots
-        k_cell_insert<<<tg, kBlock, 0, s>>>(fr);
-        mark(c, "k_cell_insert");
-        k_slot_count<<<hg, kBlock, 0, s>>>(fr);
-        mark(c, "k_slot_count");
-        k_slot_apply<<<hg, kBlock, 0, s>>>(fr);
-        mark(c, "k_slot_apply");
-        k_cell_place<<<tg, kBlock, 0, s>>>(fr);
-        mark(c, "k_cell_place");
-        k_cell_hook<<<dim3(std::min(cell_blocks, std::max(1u, div_up(nb, kBlock / kHookGroup))), nf), kBlock, 0, s>>>(fr);
-        mark(c, "k_cell_hook");
-        k_cell_compress<<<tg, kBlock, 0, s>>>(fr);
-        mark(c, "k_cell_compress");
-        k_cell_union<<<dim3(std::min(cell_blocks, std::max(1u, div_up(nb, 2 * kWavesPerBlock))), nf), kBlock, 0, s>>>(fr);
-        mark(c, "k_cell_union");
+        const dim3 cg(std::max(1u, std::min(cell_blocks, div_up(nb, kBlock))), nf);   // lane = cell, grid-strided
+        if (grid_on(c)) {
+            if (kind == kFrameClusterOnly) {   // the bounding box of the cloud (a chain frame has it from the voxel stage)
+                k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr);
+                mark(c, "k_minmax");
+                k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, 0u);
+                mark(c, "k_voxel_setup");
+            }
+            k_cgrid_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_cgrid_setup");
+            k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_mark");
+            k_occ_scan<1><<<dim3(c->ctiles, nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_cmap_scan");
+            k_cell_count<<<tg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_count");
+            k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_starts");
+            k_cell_place<<<tg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_place");
+            k_cgrid_hook<<<cg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cgrid_hook");
+            k_cell_compress<<<tg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_compress");
+            k_cgrid_union<<<cg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cgrid_union");
+        } else {
+            const uint32_t hcap = hash_cap_for(nb);
+            const dim3 hg(std::max(1u, hcap / kScanTile), nf);       // scan tiles over hash slots
+            k_cell_insert<<<tg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_insert");
+            k_slot_count<<<hg, kBlock, 0, s>>>(fr);
+            mark(c, "k_slot_count");
+            k_slot_apply<<<hg, kBlock, 0, s>>>(fr);
+            mark(c, "k_slot_apply");
+            k_cell_place<<<tg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_place");
+            k_cell_hook<<<dim3(std::min(cell_blocks, std::max(1u, div_up(nb, kBlock / kHookGroup))), nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_hook");
+            k_cell_compress<<<tg, kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_compress");
+            k_cell_union<<<dim3(std::min(cell_blocks, std::max(1u, div_up(nb, 2 * kWavesPerBlock))), nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_cell_union");
+        }
         k_cell_flatten<<<dim3(64, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_flatten");
         k_kept_count<<<sg, kBlock, 0, s>>>(fr);
@@ -285,7 +321,7 @@ int enqueue_batch(pcop_ctx* c) {
         a.inv_cell = trivial ? 1.0 : 1.99 / std::fabs((double)p.tol);
         a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
         a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.debug_skip_union = c->debug_skip_union;
-        a.voxel_stream = stream_on(c) ? 1u : 0u; a.vcap = c->vcap;
+        a.voxel_stream = stream_on(c) ? 1u : 0u; a.vcap = c->vcap; a.cell_grid = grid_on(c) ? 1u : 0u; a.pad0 = 0;
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         nmax = std::max(nmax, sl.n);
     }
@@ -298,7 +334,8 @@ int enqueue_batch(pcop_ctx* c) {
         HIPCHK(c, hipGetLastError());
     } else {
         const bool st_on = stream_on(c);
-        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? 1u : 0u, st_on ? c->vcap : 0u, st_on ? c->vtiles : 0u};
+        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? 1u : 0u, st_on ? c->vcap : 0u, st_on ? c->vtiles : 0u,
+                           grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -381,8 +418,10 @@ void order_frame(pcop_ctx* c, Slot& sl, pcop_result* out) {
 
 // A batch given up half-way may leave occupancy flags set: the streaming voxel path needs them all zero.
 void scrub_flags(pcop_ctx* c) {
-    if (!c->voxel_stream) return;
-    for (Slot& sl : c->slots) if (sl.f.vflag.get()) hipMemsetAsync(sl.f.vflag.get(), 0, (size_t)kVmapCells, c->stream);
+    for (Slot& sl : c->slots) {
+        if (sl.f.vflag.get()) hipMemsetAsync(sl.f.vflag.get(), 0, (size_t)kVmapCells, c->stream);
+        if (sl.f.cflag.get()) hipMemsetAsync(sl.f.cflag.get(), 0, (size_t)kCmapCells, c->stream);
+    }
     hipStreamSynchronize(c->stream);
 }
 
@@ -402,10 +441,18 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (e & kErrNonFinite) { c->in_flight = false; c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
         if (e & kErrRange) { c->in_flight = false; c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
         if (e & kErrInternal) { c->in_flight = false; scrub_flags(c); c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
-        if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap)) {
+        if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanCpath | kErrReplanCtiles)) {
             if (attempt >= 6) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
             if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));
             if (kb_csr) c->npass_csr = std::max(c->npass_csr, passes_for(c, kb_csr));
+            if (e & kErrReplanCpath) {
+                c->cgrid_ok = false;             // the cell grid of this cloud is too large for an occupancy map: hash table from here on
+            } else if (e & kErrReplanCtiles) {
+                for (uint32_t f = 0; f < c->nframes; ++f) {
+                    const DevState* hs = c->slots[f].h_state;
+                    if (hs->err & kErrReplanCtiles) c->ctiles = std::max(c->ctiles, std::min(kCmapCells / 32u / kVmapTile, pow2_at_least(div_up(hs->cmap_words, kVmapTile)) * 2u));
+                }
+            }
             if (e & kErrReplanPath) {
                 c->stream_ok = false;            // this cloud does not fit the streaming voxel path: sort path from here on
                 c->npass_voxel = kMaxPasses;     // (its own plan check then trims the pass count)
@@ -435,6 +482,15 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
     }
     if (kb_voxel) c->npass_voxel = passes_for(c, kb_voxel);
     if (kb_csr) c->npass_csr = passes_for(c, kb_csr);
+    if (grid_on(c)) {
+        uint32_t tiles = 0;
+        for (uint32_t f = 0; f < c->nframes; ++f)
+            if (c->slots[f].h_state->cpath) tiles = std::max(tiles, div_up(c->slots[f].h_state->cmap_words, kVmapTile));
+        if (tiles) {
+            const uint32_t want = std::min(kCmapCells / 32u / kVmapTile, pow2_at_least(tiles) * 2u);
+            if (c->ctiles > 2u * want) c->ctiles = want;
+        }
+    }
     if (stream_on(c)) {   // occupancy-scan grid of the next batch: 2x what this one needed, shrunk only when 4x too large
         uint32_t tiles = 0;
         for (uint32_t f = 0; f < c->nframes; ++f)
@@ -523,6 +579,12 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
     TRY(dev_alloc(c, &f.pt_slot, n + 1)); TRY(dev_alloc(c, &f.pt_rank, n + 1)); TRY(dev_alloc(c, &f.pt_root, n + 1));
     TRY(dev_alloc(c, &f.idx_a, n + 1)); TRY(dev_alloc(c, &f.idx_b, n + 1)); TRY(dev_alloc(c, &f.d_offsets, n + 2));
     TRY(dev_alloc(c, &f.d_xyzr, n + 1));
+    if (c->cell_grid) {
+        TRY(dev_alloc(c, &f.cflag, (size_t)kCmapCells));
+        HIPCHK(c, hipMemset(f.cflag.get(), 0, (size_t)kCmapCells));   // the kernels keep it all zero between frames
+        TRY(dev_alloc(c, &f.cmap, (size_t)kCmapCells / 32u + 1u));
+        TRY(dev_alloc(c, &f.ctile, (size_t)kCmapCells / 32u / kVmapTile));
+    }
     if (c->voxel_stream) {
         TRY(dev_alloc(c, &f.vflag, (size_t)kVmapCells));
         HIPCHK(c, hipMemset(f.vflag.get(), 0, (size_t)kVmapCells));   // the kernels keep it all zero between frames
@@ -599,6 +661,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     c->maxbits = c->radix_bits_target <= kNarrowBits ? kNarrowBits : kMaxBits;
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char* e = getenv("PCOP_VOXEL_PATH")) c->voxel_stream = std::string(e) != "sort";
+    if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
     if (const char* e = getenv("PCOP_CELL_BLOCKS")) c->cell_blocks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_STRIDE_BLOCKS")) c->stride_blocks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_DEBUG_SKIP_UNION")) c->debug_skip_union = (uint32_t)atoi(e);
@@ -646,6 +709,7 @@ int pcop_max_frames(const pcop_ctx* c) { return c ? (int)c->max_frames : 0; }
 int pcop_set_params(pcop_ctx* c, const pcop_params* p) {
     if (!c || !p) return PCOP_ERR_ARG;
     if (!c->params_set || p->leaf != c->params.leaf) c->stream_ok = true;   // a new leaf size is a new voxel grid
+    if (!c->params_set || p->tol != c->params.tol) c->cgrid_ok = true;      // a new tolerance is a new cell grid
     c->params = *p;
     c->params_set = true;
     return PCOP_OK;
@@ -845,6 +909,7 @@ int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* byt
         {"d_offsets", f.d_offsets, (n + 1) * 4}, {"bin_total", f.bin_total, (size_t)kMaxBins * 4},
         {"todo", f.todo, (n + 1) * 4}, {"cell_list", f.cell_list, n * 4},
         {"vkey", f.vkey, n * 4}, {"vflag", f.vflag, f.vflag.get() ? (size_t)kVmapCells : 0},
+        {"cflag", f.cflag, f.cflag.get() ? (size_t)kCmapCells : 0}, {"slot_meta", f.slot_meta, h * 16},
     };
     for (const Ent& e : tab) {
         if (std::strcmp(e.nm, name) == 0) { *dev_ptr = e.p; *bytes = e.b; return PCOP_OK; }

@@ -57,7 +57,10 @@ constexpr uint32_t kVmapCells = 1u << 26;       // streaming voxel path: largest
 constexpr uint32_t kVmapTile = 1024;            // occupancy words per block of k_vmap_scan
 constexpr uint32_t kStreamBuckets = 256;        // buckets of the streaming voxel path (one 8-bit partition pass)
 constexpr uint32_t kVcapMin = 512, kVcapMax = 2048;   // voxels per bucket (LDS accumulators: 24 bytes per voxel)
-constexpr uint32_t kNoKey = 0xFFFFFFFFu;        // voxel key / id of a dropped (non-finite) point
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr uint32_t kCmapCells = 1u << 24;       // dense cell grid: largest grid (cells, margins included) with an occupancy map
+constexpr int kCellMargin = 3;                  // empty cells around the grid: 2 for the 5x5x5 stencil + 1 of slack (a centroid
+                                                // may round a hair outside the bounding box of its points)        // voxel key / id of a dropped (non-finite) point
 
 // Pointers that live in device-visible structs (Frame, DevState, the mailbox).  A pointer loaded from
 // memory is a generic ("flat") pointer to the compiler, and every access through it becomes a
@@ -89,6 +92,8 @@ enum ErrBits : uint32_t {
     kErrInternal = 32u,    // a bounded wait inside a kernel ran out (never expected)
     kErrReplanPath = 64u,  // the streaming voxel path does not apply to this frame (grid or voxel count too large)
     kErrReplanVcap = 128u, // the streaming voxel path needs more voxels per bucket than the launch provided LDS for
+    kErrReplanCpath = 256u,  // the dense cell grid does not apply to this frame (grid too large)
+    kErrReplanCtiles = 512u, // the occupancy scan of the dense cell grid was launched with too few tiles
 };
 
 enum FrameKind : uint32_t { kFrameChain = 0, kFrameVoxelOnly = 1, kFrameClusterOnly = 2 };
@@ -108,6 +113,7 @@ struct FrameArgs {
     uint32_t min_cluster, max_cluster;
     uint32_t emit_cloud, out_layout, out_soa_stride, debug_skip_union;
     uint32_t voxel_stream, vcap;              // streaming voxel path requested; voxels per bucket the launch has LDS for
+    uint32_t cell_grid, pad0;                 // dense cell grid requested (else: the hash table of cells)
     DevPtr<const float> src_x, src_y, src_z;
 };
 
@@ -146,6 +152,15 @@ struct DevState {
     uint32_t vshift;        // bucket of a voxel = id >> vshift
     uint32_t nbuckets;
     uint32_t vcap;          // voxels per bucket the launch has LDS for
+    // dense cell grid
+    uint32_t cgrid_req;     // requested by the host
+    uint32_t cpath;         // 1: this frame's cell stage runs on the dense grid
+    uint32_t cmap_words;    // occupancy words in use
+    uint32_t c_rowbits;     // bits per x-row (multiple of 32), margins included
+    uint32_t c_plane;       // bits per z-plane
+    int32_t  c0[3];         // cell coordinate of grid position 0 (margin included)
+    uint32_t c_dim[3];      // grid size per axis, margins included
+    uint32_t pad1;
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState layout");
 
@@ -178,6 +193,10 @@ struct Frame {
     DevPtr<uint2> vmap;               // per 32 cells: {occupancy bits, occupied cells before this word}
     DevPtr<uint32_t> vkey;            // per input point: voxel key, then voxel id (rank among occupied cells)
     DevPtr<uint32_t> vtile;           // per occupancy tile: its popcount + 1 once known (0 = not yet)
+    // dense cell grid (null when the context was created without it)
+    DevPtr<uint8_t> cflag;            // one byte per grid cell: occupied?  all zero between frames
+    DevPtr<uint2> cmap;               // per 32 cells: {occupancy bits, occupied cells before this word}
+    DevPtr<uint32_t> ctile;           // scan tiles: popcount + 1 once known
     // pinned host outputs
     DevPtr<DevState> h_state;
     DevPtr<uint32_t> h_offsets;       // n_kept + 1, discovery order
@@ -345,7 +364,7 @@ __global__ void k_frame_init(Frame* frames) {
         s.min_cluster = a.min_cluster; s.max_cluster = a.max_cluster;
         s.src_x = a.src_x; s.src_y = a.src_y; s.src_z = a.src_z;
         s.debug_skip_union = a.debug_skip_union;
-        s.vcap = a.vcap;
+        s.vcap = a.vcap; s.cgrid_req = a.cell_grid;
         if (a.kind == kFrameClusterOnly) {   // no voxel stage: cluster the input cloud as it is
             s.c_from_input = 1; s.c_n = a.n; s.n_valid = a.n;
             uint32_t cap = 1024;
@@ -451,7 +470,7 @@ __global__ __launch_bounds__(kBlock) void k_minmax(Frame* frames) {
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     MinMaxPartial* partials = F.partials;
-    if (st->kind == kFrameClusterOnly) return;
+    if (st->kind == kFrameClusterOnly && !st->cgrid_req) return;   // bounds of a cluster-only frame: for the dense cell grid
     const float* __restrict__ x = st->src_x;
     const float* __restrict__ y = st->src_y;
     const float* __restrict__ z = st->src_z;
@@ -495,7 +514,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t 
     __shared__ MinMaxPartial s_p[kBlock];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
-    if (st->kind == kFrameClusterOnly) return;
+    if (st->kind == kFrameClusterOnly && !st->cgrid_req) return;
     const MinMaxPartial* __restrict__ partials = F.partials;
     const float fmax = 3.402823466e+38f;
     MinMaxPartial q;
@@ -508,6 +527,14 @@ __global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t 
     }
     s_p[threadIdx.x] = q;
     reduce_partials_lds(s_p);
+    if (st->kind == kFrameClusterOnly) {   // only the bounds are wanted (radiusSearch on a non-finite point is undefined in PCL)
+        if (threadIdx.x == 0) {
+            const MinMaxPartial p = s_p[0];
+            if (p.nonfinite) atomicOr(&st->err, (uint32_t)kErrNonFinite);
+            for (int a = 0; a < 3; ++a) { st->vmin[a] = p.mn[a]; st->vmax[a] = p.mx[a]; }
+        }
+        return;
+    }
     if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass, maxbits, stream != 0u);
     if (stream) {   // k_vmap_scan publishes its tile counts in vtile
         uint32_t* __restrict__ vtile = F.vtile;
@@ -962,21 +989,34 @@ __device__ __forceinline__ uint32_t flags_to_bits(const uint4& v) {
 
 // One block per kVmapTile occupancy words: bytes -> bits (and the bytes are zeroed again for the
 // next frame), popcount scan; the tile publishes its count and adds up the counts of the lower
-// tiles (same publish / bounded-wait scheme as k_voxel_reduce).  The last tile knows M.
-__global__ __launch_bounds__(kBlock) void k_vmap_scan(Frame* frames) {
+// tiles (same publish / bounded-wait scheme as k_voxel_reduce).  The last tile knows the total.
+//   WHICH = 0: the voxel grid (k_vox_mark)   -> voxel ids, M, the bucket plan
+//   WHICH = 1: the dense cell grid (k_cell_mark) -> cell ids, n_cells; per-cell arrays initialised
+__device__ __forceinline__ bool cluster_stage_off(const DevState* st);
+
+template <int WHICH>
+__global__ __launch_bounds__(kBlock) void k_occ_scan(Frame* frames) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     __shared__ uint16_t s_half[2 * kVmapTile];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
-    uint4* __restrict__ flags = reinterpret_cast<uint4*>(F.vflag.get());
-    uint2* __restrict__ vmap = F.vmap; uint32_t* __restrict__ vtile = F.vtile;
-    // Runs whenever k_vox_mark ran (the replan bits this kernel raises itself must not stop its other
-    // tiles: every tile has flag bytes to turn back to zero).
-    const uint32_t own = (uint32_t)(kErrReplanPath | kErrReplanVcap | kErrInternal);
-    if ((st->err & ~own) || st->passthrough || st->kind == kFrameClusterOnly || !st->vpath || st->n_valid == 0) return;
-    const uint32_t words = st->vmap_words;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && words > gridDim.x * kVmapTile)
-        atomicOr(&st->err, (uint32_t)kErrReplanVcap);   // the host sized this grid from the previous frame: re-run with more tiles
+    uint4* __restrict__ flags = reinterpret_cast<uint4*>(WHICH == 0 ? F.vflag.get() : F.cflag.get());
+    uint2* __restrict__ omap = WHICH == 0 ? F.vmap.get() : F.cmap.get();
+    uint32_t* __restrict__ otile = WHICH == 0 ? F.vtile.get() : F.ctile.get();
+    // Runs whenever the marking kernel ran (the replan bits this kernel raises itself must not stop its
+    // other tiles: every tile has flag bytes to turn back to zero).
+    uint32_t words;
+    if (WHICH == 0) {
+        const uint32_t own = (uint32_t)(kErrReplanPath | kErrReplanVcap | kErrInternal);
+        if ((st->err & ~own) || st->passthrough || st->kind == kFrameClusterOnly || !st->vpath || st->n_valid == 0) return;
+        words = st->vmap_words;
+    } else {
+        const uint32_t own = (uint32_t)(kErrReplanCpath | kErrReplanCtiles | kErrInternal | kErrNonFinite);
+        if ((st->err & ~own) || st->trivial || st->kind == kFrameVoxelOnly || !st->cpath) return;
+        words = st->cmap_words;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && words > gridDim.x * kVmapTile)   // the host sized this grid from the previous frame
+        atomicOr(&st->err, (uint32_t)(WHICH == 0 ? kErrReplanVcap : kErrReplanCtiles));
     const uint32_t base = blockIdx.x * kVmapTile;
     if (base >= words) return;
     const uint32_t cnt = min(kVmapTile, words - base);
@@ -1004,14 +1044,14 @@ __global__ __launch_bounds__(kBlock) void k_vmap_scan(Frame* frames) {
     }
     uint32_t tot;
     uint32_t run = block_excl_scan(c, s_w, &tot);
-    if (threadIdx.x == 0) st_agent(vtile + blockIdx.x, tot + 1u);   // publish
+    if (threadIdx.x == 0) st_agent(otile + blockIdx.x, tot + 1u);   // publish
     uint32_t mine = 0;
     for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
-        uint32_t v = ld_agent(vtile + t), spins = 0;
+        uint32_t v = ld_agent(otile + t), spins = 0;
         while (v == 0u) {
             if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
             __builtin_amdgcn_s_sleep(2);
-            v = ld_agent(vtile + t);
+            v = ld_agent(otile + t);
         }
         mine += v - 1u;
     }
@@ -1021,18 +1061,32 @@ __global__ __launch_bounds__(kBlock) void k_vmap_scan(Frame* frames) {
 #pragma unroll
     for (uint32_t k = 0; k < kPer; ++k) {
         const uint32_t j = threadIdx.x * kPer + k;
-        if (j < cnt) vmap[base + j] = make_uint2(w[k], run);
+        if (j < cnt) omap[base + j] = make_uint2(w[k], run);
+        if (WHICH == 1) {   // cell id -> grid position; counters of the cell
+            uint32_t* __restrict__ cell_pos = F.cell_list; uint32_t* __restrict__ ccount = F.hcount; uint32_t* __restrict__ cmin = F.hmin;
+            uint32_t bits = w[k], id = run;
+            while (bits) {
+                const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
+                bits &= bits - 1u;
+                cell_pos[id] = (base + j) * 32u + b; ccount[id] = 0u; cmin[id] = 0xFFFFFFFFu;
+                ++id;
+            }
+        }
         run += __popc(w[k]);
     }
-    if (threadIdx.x == 0 && base + kVmapTile >= words) {   // the last tile: M and the bucket plan
+    if (threadIdx.x == 0 && base + kVmapTile >= words) {   // the last tile
         const uint32_t m = before + tot;
-        finish_voxel(st, m);
-        uint32_t sh = 0;
-        while (((uint64_t)kStreamBuckets << sh) < (uint64_t)m) ++sh;   // 256 buckets of 2^sh voxels cover M
-        st->vshift = sh;
-        st->nbuckets = m ? ((m - 1u) >> sh) + 1u : 0u;
-        if ((1u << sh) > kVcapMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
-        else if ((1u << sh) > st->vcap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
+        if (WHICH == 0) {   // M and the bucket plan
+            finish_voxel(st, m);
+            uint32_t sh = 0;
+            while (((uint64_t)kStreamBuckets << sh) < (uint64_t)m) ++sh;   // 256 buckets of 2^sh voxels cover M
+            st->vshift = sh;
+            st->nbuckets = m ? ((m - 1u) >> sh) + 1u : 0u;
+            if ((1u << sh) > kVcapMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
+            else if ((1u << sh) > st->vcap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
+        } else {
+            st->n_cells = m;
+        }
     }
 }
 
@@ -1632,8 +1686,9 @@ __global__ __launch_bounds__(kBlock) void k_cell_compress(const Frame* frames) {
     uint32_t* __restrict__ parent = F.parent;
     if (cluster_stage_off(st)) return;
     const uint32_t ncell = st->n_cells;
+    const bool dense = st->cpath != 0;   // dense cell grid: cell ids are the slots
     for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < ncell; ci += gridDim.x * blockDim.x) {
-        const uint32_t c = cell_list[ci];
+        const uint32_t c = dense ? ci : cell_list[ci];
         const uint32_t r = uf_find(parent, c);
         st_agent(parent + c, r);
     }
@@ -1766,6 +1821,286 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
             const uint32_t rc = uf_find(parent, c);
             need_c = need_c && uf_find(parent, bc) != rc;
             if (__any(need_c)) union_fixup(rec, slot_meta, hmin, parent, s_pa[w], c, here.j0.z, here.j0.w, bc, need_c, r2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense cell grid (default; the hash table above is the fallback for grids beyond kCmapCells).
+// Same cells (edge tol/1.99), same predicate, same union-find; only the way a neighbour cell is
+// found differs.  The bounding box of the cloud is known, so the cells form a dense 3-D array
+// with an occupancy bit each (x fastest, rows padded to 32 bits, kCellMargin empty cells all
+// round) and cell id = rank of the bit = occupied cells before it:
+//   * the neighbour at (dx,dy,dz) is the bit at a constant offset: no probing, no bounds checks;
+//   * the 5 (or 3) x-neighbours of a row sit in one or two 32-bit words, and their ids are
+//     consecutive, so one 8-byte load resolves a whole row of the stencil;
+//   * ids follow the grid, so cells that are neighbours in space are neighbours in every
+//     per-cell array and the lanes of a wave (64 consecutive cells) touch the same cache lines.
+//   k_cgrid_setup   grid origin / size from the bounding box (margins added), or "replan"
+//   k_cell_mark     grid position of every point; one byte per occupied cell
+//   k_occ_scan<1>   bytes -> occupancy bits + running popcount => cell ids, n_cells
+//   k_cell_count    points per cell, rank inside the cell, smallest point index (= priority)
+//   k_cell_starts   exclusive scan of the counts; per-cell metadata; union-find init
+//   k_cell_place    (shared with the hash path) records sorted by cell
+//   k_cgrid_hook / k_cell_compress / k_cgrid_union   components, lane = cell
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cgrid_off(const DevState* st) { return cluster_stage_off(st) || !st->cpath; }
+
+__global__ __launch_bounds__(kBlock) void k_cgrid_setup(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    if (cluster_stage_off(st) || !st->cgrid_req) return;
+    uint32_t* __restrict__ ctile = F.ctile; uint32_t* __restrict__ tile_pub = F.tile_a;
+    for (uint32_t t = threadIdx.x; t < kCmapCells / 32u / kVmapTile; t += kBlock) ctile[t] = 0u;
+    const uint32_t ntiles = (st->c_n + kScanTile - 1) / kScanTile;   // k_cell_starts publishes here
+    for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock) tile_pub[t] = 0u;
+    if (threadIdx.x != 0) return;
+    st->n_cells = 0;
+    if (st->c_n == 0) { st->cpath = 1u; st->cmap_words = 0u; return; }
+    const double ig = st->inv_cell;
+    long long dim[3];
+    for (int a = 0; a < 3; ++a) {
+        const double lo = floor((double)st->vmin[a] * ig), hi = floor((double)st->vmax[a] * ig);
+        if (!(fabs(lo) < 1e9 && fabs(hi) < 1e9)) { atomicOr(&st->err, (uint32_t)kErrReplanCpath); return; }
+        st->c0[a] = (int32_t)lo - kCellMargin;
+        dim[a] = (long long)hi - (long long)lo + 1 + 2 * kCellMargin;
+    }
+    const long long rowbits = (dim[0] + 31) / 32 * 32;
+    const long long plane = rowbits * dim[1], total = plane * dim[2];
+    if (dim[0] > (1 << 24) || dim[1] > (1 << 24) || dim[2] > (1 << 24) || plane > (long long)kCmapCells || total > (long long)kCmapCells) {
+        atomicOr(&st->err, (uint32_t)kErrReplanCpath);
+        return;
+    }
+    for (int a = 0; a < 3; ++a) st->c_dim[a] = (uint32_t)dim[a];
+    st->c_rowbits = (uint32_t)rowbits; st->c_plane = (uint32_t)plane;
+    st->cmap_words = (uint32_t)(total / 32);
+    st->cpath = 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const float* __restrict__ cen_x = F.cen_x; const float* __restrict__ cen_y = F.cen_y; const float* __restrict__ cen_z = F.cen_z;
+    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;   // pt_root is free until k_cell_flatten
+    if (cgrid_off(st)) return;
+    const bool from_in = st->c_from_input != 0;
+    const float* __restrict__ x = from_in ? st->src_x.get() : cen_x;
+    const float* __restrict__ y = from_in ? st->src_y.get() : cen_y;
+    const float* __restrict__ z = from_in ? st->src_z.get() : cen_z;
+    const uint32_t n = st->c_n;
+    const double ig = st->inv_cell;
+    const long long c0x = st->c0[0], c0y = st->c0[1], c0z = st->c0[2];
+    const long long d0 = st->c_dim[0], d1 = st->c_dim[1], d2 = st->c_dim[2];
+    const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float px = x[i], py = y[i], pz = z[i];
+        uint32_t pos = 0;
+        if (!finite3(px, py, pz)) {   // radiusSearch on a non-finite point is undefined in PCL
+            atomicOr(&st->err, (uint32_t)kErrNonFinite);
+        } else {
+            const long long gx = (long long)floor((double)px * ig) - c0x, gy = (long long)floor((double)py * ig) - c0y,
+                            gz = (long long)floor((double)pz * ig) - c0z;
+            // two free cells on every side keep the whole 5x5x5 stencil inside the array
+            if (gx < 2 || gy < 2 || gz < 2 || gx > d0 - 3 || gy > d1 - 3 || gz > d2 - 3) {
+                atomicOr(&st->err, (uint32_t)kErrReplanCpath);
+            } else {
+                pos = (uint32_t)gz * plane + (uint32_t)gy * rowbits + (uint32_t)gx;
+                cflag[pos] = 1;
+            }
+        }
+        pt_pos[i] = pos;
+    }
+}
+
+// id of the occupied cell at grid position pos
+__device__ __forceinline__ uint32_t cell_id_at(const uint2* __restrict__ cmap, uint32_t pos) {
+    const uint2 e = cmap[pos >> 5];
+    return e.y + __popc(e.x & ((1u << (pos & 31u)) - 1u));
+}
+
+__global__ __launch_bounds__(kBlock) void k_cell_count(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint2* __restrict__ cmap = F.cmap; const uint32_t* __restrict__ pt_pos = F.pt_root;
+    uint32_t* __restrict__ ccount = F.hcount; uint32_t* __restrict__ cmin = F.hmin;
+    uint32_t* __restrict__ pt_slot = F.pt_slot; uint32_t* __restrict__ pt_rank = F.pt_rank;
+    if (cgrid_off(st)) return;
+    const uint32_t n = st->c_n;
+    const uint32_t lane = lane_id();
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += nthreads) {
+        const uint32_t i = base + lane;
+        const bool valid = i < n;
+        uint32_t cid = 0xFFFFFFFFu;
+        if (valid) cid = cell_id_at(cmap, pt_pos[i]);
+        // runs of consecutive points in one cell (frequent: the points arrive in voxel order) share one set of atomics
+        const uint32_t cprev = __shfl_up(cid, 1, kWave);
+        const bool leader = valid && (lane == 0 || cid != cprev);
+        const uint64_t leaders = __ballot(leader);
+        const uint64_t breaks = __ballot(leader || !valid);
+        uint32_t rank0 = 0;
+        if (leader) {
+            const uint64_t later = lane == 63 ? 0ull : (breaks >> (lane + 1));
+            const uint32_t runlen = later ? (uint32_t)__ffsll((unsigned long long)later) : (uint32_t)(kWave - lane);
+            rank0 = atomicAdd(ccount + cid, runlen);
+            atomicMin(cmin + cid, i);
+        }
+        const uint64_t le = leaders & (lanemask_lt() | (1ull << lane));
+        const int ll = le ? 63 - __clzll((unsigned long long)le) : 0;
+        const uint32_t r = __shfl(rank0, ll, kWave);
+        if (valid) { pt_slot[i] = cid; pt_rank[i] = r + (lane - (uint32_t)ll); }
+    }
+}
+
+// cell_start = exclusive scan of the counts (tiles publish / add up the lower tiles); per-cell
+// metadata {first record, points, smallest point index, grid position}; union-find init
+__global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames) {
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const uint32_t* __restrict__ ccount = F.hcount; const uint32_t* __restrict__ cmin = F.hmin;
+    const uint32_t* __restrict__ cell_pos = F.cell_list;
+    uint32_t* __restrict__ tile_pub = F.tile_a;
+    uint32_t* __restrict__ cell_start = F.cell_start; uint32_t* __restrict__ parent = F.parent;
+    uint32_t* __restrict__ comp_size = F.comp_size; uint32_t* __restrict__ comp_rank = F.comp_rank;
+    uint4* __restrict__ slot_meta = F.slot_meta;
+    if (cgrid_off(st)) return;
+    const uint32_t nc = st->n_cells;
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= nc) return;
+    uint32_t v[kScanItems];
+    uint32_t c = 0;
+    const uint32_t s0 = base + threadIdx.x * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { v[k] = s0 + k < nc ? ccount[s0 + k] : 0u; c += v[k]; }
+    uint32_t tot;
+    uint32_t run = block_excl_scan(c, s_w, &tot);
+    if (threadIdx.x == 0) st_agent(tile_pub + blockIdx.x, tot + 1u);
+    uint32_t mine = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
+        uint32_t q = ld_agent(tile_pub + t), spins = 0;
+        while (q == 0u) {
+            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); q = 1u; break; }
+            __builtin_amdgcn_s_sleep(2);
+            q = ld_agent(tile_pub + t);
+        }
+        mine += q - 1u;
+    }
+    __syncthreads();
+    run += block_sum(mine, s_w);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t id = s0 + k;
+        if (id < nc) {
+            cell_start[id] = run;
+            parent[id] = id; comp_size[id] = 0u; comp_rank[id] = 0xFFFFFFFFu;
+            slot_meta[id] = make_uint4(run, v[k], cmin[id], cell_pos[id]);
+        }
+        run += v[k];
+    }
+}
+
+// One lane walks the cross pairs of two cells: is some pair within the radius?
+__device__ __forceinline__ bool lane_cells_hit(const float4* __restrict__ rec, uint32_t a0, uint32_t an, uint32_t b0,
+                                               uint32_t bn, float r2) {
+    for (uint32_t ia = 0; ia < an; ++ia) {
+        const float4 pa = rec[a0 + ia];
+        for (uint32_t ib = 0; ib < bn; ++ib)
+            if (l2_simple(pa, rec[b0 + ib]) < r2) return true;
+    }
+    return false;
+}
+
+// Occupied cells among `width` (<= 5) consecutive grid positions starting at `pos`: bit k of the result
+// is position pos + k; *id0 = id of the first occupied one, the others follow consecutively.
+__device__ __forceinline__ uint32_t row_window(const uint2* __restrict__ cmap, uint32_t pos, uint32_t width, uint32_t* id0) {
+    const uint32_t w = pos >> 5, sh = pos & 31u;
+    const uint2 e0 = cmap[w];
+    uint32_t bits = e0.x >> sh;
+    uint32_t before = e0.y + __popc(e0.x & ((1u << sh) - 1u));   // occupied cells before pos
+    if (sh + width > 32u) bits |= cmap[w + 1].x << (32u - sh);   // sh > 0 here
+    *id0 = before;
+    return bits & ((1u << width) - 1u);
+}
+
+// parent[c] = the adjacent cell of smallest priority among the 13 backward cells of the 3x3x3
+// neighbourhood (5 rows), if it has a smaller priority than c.  No atomics: a forest.
+__global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = F.rec_a;
+    const uint2* __restrict__ cmap = F.cmap;
+    const uint4* __restrict__ slot_meta = F.slot_meta;
+    uint32_t* __restrict__ parent = F.parent;
+    if (cgrid_off(st)) return;
+    const uint32_t nc = st->n_cells;
+    const float r2 = st->r2;
+    const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+        const uint4 ma = slot_meta[c];   // {first record, points, priority, grid position}
+        unsigned long long best = ~0ull;
+#pragma unroll 1
+        for (int r = 0; r < 5; ++r) {
+            // rows: (dy,dz) = (-1,-1) (0,-1) (1,-1) (-1,0) with dx = -1..1, and the cell's own row with dx = -1
+            uint32_t pos, width;
+            if (r < 3) { pos = ma.w - plane + (uint32_t)(r - 1) * rowbits - 1u; width = 3u; }
+            else if (r == 3) { pos = ma.w - rowbits - 1u; width = 3u; }
+            else { pos = ma.w - 1u; width = 1u; }
+            uint32_t id;
+            uint32_t win = row_window(cmap, pos, width, &id);
+            while (win) {
+                win &= win - 1u;   // the ids of a row's occupied cells are consecutive
+                const uint4 mb = slot_meta[id];
+                if (mb.z < ma.z && (((unsigned long long)mb.z << 32) | id) < best &&
+                    lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2))
+                    best = ((unsigned long long)mb.z << 32) | id;
+                ++id;
+            }
+        }
+        if (best != ~0ull) parent[c] = (uint32_t)best;
+    }
+}
+
+// Forward half of the 5x5x5 stencil (13 rows, 62 cells): neighbours whose parent word equals the
+// cell's are in its set already (one coalesced load each); the rest are looked at properly.
+__global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = F.rec_a;
+    const uint2* __restrict__ cmap = F.cmap;
+    const uint4* __restrict__ slot_meta = F.slot_meta;
+    const uint32_t* __restrict__ prio = F.hmin;
+    uint32_t* __restrict__ parent = F.parent;
+    if (cgrid_off(st) || st->debug_skip_union == 1u) return;
+    const bool scan_only = st->debug_skip_union == 2u;
+    const uint32_t nc = st->n_cells;
+    const float r2 = st->r2;
+    const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+        const uint4 ma = slot_meta[c];
+        uint32_t pa = ld_agent(parent + c);
+#pragma unroll 1
+        for (int r = 0; r < 13; ++r) {
+            // rows: own row dx = 1..2; (dy = 1..2, dz = 0) and (dy = -2..2, dz = 1..2) with dx = -2..2
+            uint32_t pos, width;
+            if (r == 0) { pos = ma.w + 1u; width = 2u; }
+            else if (r < 3) { pos = ma.w + (uint32_t)r * rowbits - 2u; width = 5u; }
+            else { const int q = r - 3; pos = ma.w + (uint32_t)(1 + q / 5) * plane + (uint32_t)(q % 5 - 2) * rowbits - 2u; width = 5u; }
+            uint32_t id;
+            uint32_t win = row_window(cmap, pos, width, &id);
+            while (win) {
+                win &= win - 1u;
+                const uint32_t pb = ld_agent(parent + id);
+                if (pb != pa && !scan_only) {
+                    const uint32_t ra = uf_find(parent, c), rb = uf_find(parent, id);
+                    if (ra != rb) {
+                        const uint4 mb = slot_meta[id];
+                        if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) uf_union(parent, prio, c, id);
+                    }
+                    pa = ld_agent(parent + c);
+                }
+                ++id;
+            }
         }
     }
 }
@@ -2020,7 +2355,11 @@ __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t n
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     // reset the cell table for the next frame: the occupied slots are listed in cell_list; after an
     // error the list may be incomplete, so everything below hash_mask + 1 is cleared instead
-    if (st->kind != kFrameVoxelOnly && !st->trivial && st->hash_mask) {
+    if (st->kind != kFrameVoxelOnly && !st->trivial && st->cpath) {
+        // dense cell grid: the per-cell counters borrowed the hash table's arrays; give them back clean
+        const uint32_t nc = st->err ? st->c_n : st->n_cells;
+        for (uint32_t i = tid; i < nc; i += nth) { tab.hcount[i] = 0u; tab.hmin[i] = 0xFFFFFFFFu; }
+    } else if (st->kind != kFrameVoxelOnly && !st->trivial && st->hash_mask) {
         if (st->err) {
             const uint32_t cap = st->hash_mask + 1u;
             for (uint32_t i = tid; i < cap; i += nth) { tab.hkey[i] = 0ull; tab.hcount[i] = 0u; tab.hmin[i] = 0xFFFFFFFFu; }

@@ -19,21 +19,25 @@ def capi():
     return m
 
 
-@pytest.fixture(scope="module", params=["stream", "sort"])
+@pytest.fixture(scope="module", params=["stream+grid", "sort+hash"])
 def ctx(capi, request):
-    """Every test that takes `ctx` runs on both voxel paths: the streaming one (default) and the sort one
-    (PCOP_VOXEL_PATH=sort, read when the context is created; also the fallback of the streaming one)."""
+    """Every test that takes `ctx` runs on both sets of paths: the defaults (streaming voxel path, dense cell
+    grid) and their fallbacks (PCOP_VOXEL_PATH=sort, PCOP_CELL_PATH=hash; read when the context is created)."""
     import os
-    old = os.environ.get("PCOP_VOXEL_PATH")
-    os.environ["PCOP_VOXEL_PATH"] = request.param
+    vox, cell = request.param.split("+")
+    old = {k: os.environ.get(k) for k in ("PCOP_VOXEL_PATH", "PCOP_CELL_PATH")}
+    os.environ["PCOP_VOXEL_PATH"] = vox
+    os.environ["PCOP_CELL_PATH"] = cell
     try:
         c = capi.Context(1_100_000)
     finally:
-        if old is None:
-            os.environ.pop("PCOP_VOXEL_PATH", None)
-        else:
-            os.environ["PCOP_VOXEL_PATH"] = old
-    c.voxel_path = request.param
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    c.voxel_path = vox
+    c.cell_path = cell
     yield c
     c.close()
 
@@ -517,5 +521,70 @@ def test_stream_path_nonfinite_points_dropped(capi, oracle, monkeypatch):
     ref = oracle.process_xyz(pts, is_dense=False, **p)
     assert c.debug_state().vpath == 1
     assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# dense cell grid: stage-wise check and its fallback to the hash table
+# ---------------------------------------------------------------------------------------------
+def test_cell_grid_ids_and_metadata(capi, oracle, monkeypatch):
+    """Cell ids are the ranks of the occupied cells in grid order; per-cell metadata holds count and priority."""
+    monkeypatch.setenv("PCOP_CELL_PATH", "grid")
+    c = capi.Context(100_000)
+    pts = synth.make_cloud("C3", n=50_000, seed=12)
+    tol = 0.1
+    c.set_params(leaf=0.02, tol=tol, min_cluster=1, max_cluster=10**9)
+    c.euclidean_clusters(pts)
+    st = c.debug_state()
+    assert st.cpath == 1 and st.n_cells > 0
+    ig = 1.99 / abs(np.float32(tol).astype(np.float64))
+    cell = np.floor(pts.astype(np.float64) * ig).astype(np.int64)
+    g = cell - np.array(list(st.c0), dtype=np.int64)
+    assert (g >= 3).all() and (g[:, 0] <= st.c_dim[0] - 4).all() and (g[:, 1] <= st.c_dim[1] - 4).all() and (g[:, 2] <= st.c_dim[2] - 4).all()
+    pos = g[:, 2] * st.c_plane + g[:, 1] * st.c_rowbits + g[:, 0]
+    upos, ids_ref, cnt_ref = np.unique(pos, return_inverse=True, return_counts=True)
+    assert st.n_cells == len(upos)
+    ids = c.debug_buffer("pt_slot", np.uint32, len(pts))
+    assert np.array_equal(ids, ids_ref.astype(np.uint32))
+    meta = c.debug_buffer("slot_meta", np.uint32, 4 * st.n_cells).reshape(-1, 4)
+    assert np.array_equal(meta[:, 1], cnt_ref.astype(np.uint32))                 # points per cell
+    assert np.array_equal(meta[:, 3], upos.astype(np.uint32))                    # grid position
+    first = np.full(len(upos), len(pts), dtype=np.int64)
+    np.minimum.at(first, ids_ref, np.arange(len(pts)))
+    assert np.array_equal(meta[:, 2], first.astype(np.uint32))                   # priority = smallest point index
+    assert np.array_equal(meta[:, 0], np.concatenate(([0], np.cumsum(cnt_ref)[:-1])).astype(np.uint32))
+    assert not c.debug_buffer("cflag", np.uint8, 1 << 24).any()
+    c.close()
+
+
+def test_cell_grid_too_large_falls_back_to_hash(capi, oracle, monkeypatch):
+    monkeypatch.setenv("PCOP_CELL_PATH", "grid")
+    c = capi.Context(100_000)
+    rng = np.random.default_rng(5)
+    # a few compact blobs spread over hundreds of metres: > 2^24 cells at tolerance 0.1
+    centres = rng.uniform(-300.0, 300.0, size=(40, 3)).astype(f32)
+    pts = (centres[rng.integers(0, 40, 60_000)] + rng.normal(0.0, 0.08, size=(60_000, 3))).astype(f32)
+    p = dict(leaf=0.02, tol=0.1, min_cluster=3, max_cluster=10**9)
+    c.set_params(publish_clouds=1, **p)
+    ref = oracle.process_xyz(pts, **p)
+    for rep in range(2):
+        got = c.process_xyz(pts)
+        assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    assert c.debug_state().cpath == 0
+    # a compact cloud with another tolerance: back on the grid, and the borrowed hash arrays were left clean
+    q = synth.params_of("C3")
+    small = synth.make_cloud("C3", n=80_000, seed=4)
+    q2 = dict(q, tol=0.11)
+    c.set_params(publish_clouds=1, **q2)
+    got = c.process_xyz(small)
+    ref2 = oracle.process_xyz(small, **q2)
+    assert c.debug_state().cpath == 1
+    assert_same_cloud(got["voxel_xyz"], ref2["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref2["offsets"], ref2["indices"])
+    # and the hash path once more on the same context (PCOP_ERR-free, same answers as the oracle)
+    c.set_params(publish_clouds=1, **p)
+    got = c.process_xyz(pts)
     assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
     c.close()
