@@ -991,7 +991,7 @@ __device__ __forceinline__ uint32_t flags_to_bits(const uint4& v) {
 // next frame), popcount scan; the tile publishes its count and adds up the counts of the lower
 // tiles (same publish / bounded-wait scheme as k_voxel_reduce).  The last tile knows the total.
 //   WHICH = 0: the voxel grid (k_vox_mark)   -> voxel ids, M, the bucket plan
-//   WHICH = 1: the dense cell grid (k_cell_mark) -> cell ids, n_cells; per-cell arrays initialised
+//   WHICH = 1: the dense cell grid (k_cell_mark) -> cell ids, n_cells
 __device__ __forceinline__ bool cluster_stage_off(const DevState* st);
 
 template <int WHICH>
@@ -1062,16 +1062,6 @@ __global__ __launch_bounds__(kBlock) void k_occ_scan(Frame* frames) {
     for (uint32_t k = 0; k < kPer; ++k) {
         const uint32_t j = threadIdx.x * kPer + k;
         if (j < cnt) omap[base + j] = make_uint2(w[k], run);
-        if (WHICH == 1) {   // cell id -> grid position; counters of the cell
-            uint32_t* __restrict__ cell_pos = F.cell_list; uint32_t* __restrict__ ccount = F.hcount; uint32_t* __restrict__ cmin = F.hmin;
-            uint32_t bits = w[k], id = run;
-            while (bits) {
-                const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
-                bits &= bits - 1u;
-                cell_pos[id] = (base + j) * 32u + b; ccount[id] = 0u; cmin[id] = 0xFFFFFFFFu;
-                ++id;
-            }
-        }
         run += __popc(w[k]);
     }
     if (threadIdx.x == 0 && base + kVmapTile >= words) {   // the last tile
@@ -1689,8 +1679,15 @@ __global__ __launch_bounds__(kBlock) void k_cell_compress(const Frame* frames) {
     const bool dense = st->cpath != 0;   // dense cell grid: cell ids are the slots
     for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < ncell; ci += gridDim.x * blockDim.x) {
         const uint32_t c = dense ? ci : cell_list[ci];
-        const uint32_t r = uf_find(parent, c);
-        st_agent(parent + c, r);
+        // pointer jumping on the cell's own word: every cell does this at the same time, so the distance a
+        // pointer spans doubles per round and a chain of depth d is flat after about log2(d) rounds
+        uint32_t p = ld_agent(parent + c);
+        while (true) {
+            const uint32_t gp = ld_agent(parent + p);
+            if (gp == p) break;
+            st_agent(parent + c, gp);
+            p = gp;
+        }
     }
 }
 
@@ -1924,15 +1921,17 @@ __global__ __launch_bounds__(kBlock) void k_cell_count(Frame* frames) {
     const uint2* __restrict__ cmap = F.cmap; const uint32_t* __restrict__ pt_pos = F.pt_root;
     uint32_t* __restrict__ ccount = F.hcount; uint32_t* __restrict__ cmin = F.hmin;
     uint32_t* __restrict__ pt_slot = F.pt_slot; uint32_t* __restrict__ pt_rank = F.pt_rank;
+    uint32_t* __restrict__ cell_pos = F.cell_list;
     if (cgrid_off(st)) return;
     const uint32_t n = st->c_n;
     const uint32_t lane = lane_id();
     const uint32_t nthreads = gridDim.x * blockDim.x;
+    // ccount is all zero and cmin all ones on entry: k_emit leaves the borrowed arrays that way
     for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += nthreads) {
         const uint32_t i = base + lane;
         const bool valid = i < n;
-        uint32_t cid = 0xFFFFFFFFu;
-        if (valid) cid = cell_id_at(cmap, pt_pos[i]);
+        uint32_t cid = 0xFFFFFFFFu, pos = 0;
+        if (valid) { pos = pt_pos[i]; cid = cell_id_at(cmap, pos); }
         // runs of consecutive points in one cell (frequent: the points arrive in voxel order) share one set of atomics
         const uint32_t cprev = __shfl_up(cid, 1, kWave);
         const bool leader = valid && (lane == 0 || cid != cprev);
@@ -1944,6 +1943,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_count(Frame* frames) {
             const uint32_t runlen = later ? (uint32_t)__ffsll((unsigned long long)later) : (uint32_t)(kWave - lane);
             rank0 = atomicAdd(ccount + cid, runlen);
             atomicMin(cmin + cid, i);
+            cell_pos[cid] = pos;   // every writer of a cell stores the same value
         }
         const uint64_t le = leaders & (lanemask_lt() | (1ull << lane));
         const int ll = le ? 63 - __clzll((unsigned long long)le) : 0;
@@ -2061,8 +2061,18 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
     }
 }
 
-// Forward half of the 5x5x5 stencil (13 rows, 62 cells): neighbours whose parent word equals the
-// cell's are in its set already (one coalesced load each); the rest are looked at properly.
+// Forward half of the 5x5x5 stencil (13 rows, 62 cells).  Neighbours whose parent word equals the
+// cell's are in its set already, and after hook + compress that is nearly all of them, so the common
+// case is made of two rounds of independent loads: the 13 row windows, then the parent words of
+// every occupied neighbour.  Only a cell that sees a different parent word walks its rows again and
+// looks properly (roots, pair test, union by CAS).
+__device__ __forceinline__ void union_row(int r, uint32_t at, uint32_t rowbits, uint32_t plane, uint32_t* pos, uint32_t* width) {
+    // rows: own row dx = 1..2; (dy = 1..2, dz = 0) and (dy = -2..2, dz = 1..2) with dx = -2..2
+    if (r == 0) { *pos = at + 1u; *width = 2u; }
+    else if (r < 3) { *pos = at + (uint32_t)r * rowbits - 2u; *width = 5u; }
+    else { const int q = r - 3; *pos = at + (uint32_t)(1 + q / 5) * plane + (uint32_t)(q % 5 - 2) * rowbits - 2u; *width = 5u; }
+}
+
 __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames) {
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
@@ -2078,28 +2088,68 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames) {
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
         const uint4 ma = slot_meta[c];
-        uint32_t pa = ld_agent(parent + c);
+        const uint32_t pa = ld_agent(parent + c);
+        // round 1: the windows of all rows.  Every load is issued before any is used and none sits under a
+        // branch (the second word of a window is fetched whether it is needed or not).
+        uint2 e0[13];
+        uint32_t e1[13], sh[13], wd[13];
+#pragma unroll
+        for (int r = 0; r < 13; ++r) {
+            uint32_t pos;
+            union_row(r, ma.w, rowbits, plane, &pos, &wd[r]);
+            sh[r] = pos & 31u;
+            e0[r] = cmap[pos >> 5];
+            e1[r] = cmap[(pos >> 5) + 1u].x;
+        }
+        uint32_t win[13], id0[13];
+#pragma unroll
+        for (int r = 0; r < 13; ++r) {
+            uint32_t bits = e0[r].x >> sh[r];
+            if (sh[r] + wd[r] > 32u) bits |= (e1[r] << 1) << (31u - sh[r]);
+            win[r] = bits & ((1u << wd[r]) - 1u);
+            id0[r] = e0[r].y + __popc(e0[r].x & ((1u << sh[r]) - 1u));
+        }
+        // round 2: parent words of the occupied neighbours (the ids of a row's occupied cells are consecutive).
+        // Plain loads are enough here: a parent word, however stale, names a member of the neighbour's set, and
+        // sets only ever merge, so equal words prove "same set".  Slots without a neighbour re-read the cell's own.
+        bool differs = false;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t got[7 * 5];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int r = half * 7 + q;
+                if (r < 13) {
+                    const uint32_t cnt = __popc(win[r]);
+#pragma unroll
+                    for (uint32_t k = 0; k < 5; ++k) got[q * 5 + k] = parent[k < cnt ? id0[r] + k : c];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int r = half * 7 + q;
+                if (r < 13) {
+                    const uint32_t cnt = __popc(win[r]);
+#pragma unroll
+                    for (uint32_t k = 0; k < 5; ++k) differs |= (k < cnt) && (got[q * 5 + k] != pa);
+                }
+            }
+        }
+        if (!differs || scan_only) continue;
+        // some neighbour may be in another set: walk the rows again and look properly at those whose parent
+        // word differs from the cell's (roots, pair test, union by CAS)
+        uint32_t pnow = pa;
 #pragma unroll 1
         for (int r = 0; r < 13; ++r) {
-            // rows: own row dx = 1..2; (dy = 1..2, dz = 0) and (dy = -2..2, dz = 1..2) with dx = -2..2
-            uint32_t pos, width;
-            if (r == 0) { pos = ma.w + 1u; width = 2u; }
-            else if (r < 3) { pos = ma.w + (uint32_t)r * rowbits - 2u; width = 5u; }
-            else { const int q = r - 3; pos = ma.w + (uint32_t)(1 + q / 5) * plane + (uint32_t)(q % 5 - 2) * rowbits - 2u; width = 5u; }
-            uint32_t id;
-            uint32_t win = row_window(cmap, pos, width, &id);
-            while (win) {
-                win &= win - 1u;
-                const uint32_t pb = ld_agent(parent + id);
-                if (pb != pa && !scan_only) {
-                    const uint32_t ra = uf_find(parent, c), rb = uf_find(parent, id);
-                    if (ra != rb) {
-                        const uint4 mb = slot_meta[id];
-                        if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) uf_union(parent, prio, c, id);
-                    }
-                    pa = ld_agent(parent + c);
+            uint32_t id = id0[r];
+            for (uint32_t left = __popc(win[r]); left; --left, ++id) {
+                if (ld_agent(parent + id) == pnow) continue;
+                const uint32_t ra = uf_find(parent, c), rb = uf_find(parent, id);
+                if (ra != rb) {
+                    const uint4 mb = slot_meta[id];
+                    if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) uf_union(parent, prio, c, id);
                 }
-                ++id;
+                pnow = ld_agent(parent + c);
             }
         }
     }
