@@ -2138,18 +2138,19 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames) {
         if (!differs || scan_only) continue;
         // some neighbour may be in another set: walk the rows again and look properly at those whose parent
         // word differs from the cell's (roots, pair test, union by CAS)
-        uint32_t pnow = pa;
+        uint32_t ra = uf_find(parent, c);
 #pragma unroll 1
         for (int r = 0; r < 13; ++r) {
             uint32_t id = id0[r];
             for (uint32_t left = __popc(win[r]); left; --left, ++id) {
-                if (ld_agent(parent + id) == pnow) continue;
-                const uint32_t ra = uf_find(parent, c), rb = uf_find(parent, id);
-                if (ra != rb) {
-                    const uint4 mb = slot_meta[id];
-                    if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) uf_union(parent, prio, c, id);
-                }
-                pnow = ld_agent(parent + c);
+                const uint32_t pb = ld_agent(parent + id);
+                if (pb == pa || pb == ra) continue;
+                const uint32_t rb = uf_find(parent, id);
+                if (rb == ra) continue;
+                ra = uf_find(parent, ra);   // the cell's root may have been hung under another one meanwhile
+                if (rb == ra) continue;
+                const uint4 mb = slot_meta[id];
+                if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) { uf_union(parent, prio, ra, rb); ra = uf_find(parent, ra); }
             }
         }
     }
