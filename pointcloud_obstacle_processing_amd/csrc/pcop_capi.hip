@@ -220,7 +220,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
             mark(c, "k_table_scan");
             k_vid_scatter<kNarrowBits><<<pg, kBlock, 0, s>>>(fr);
             mark(c, "k_vid_scatter");
-            k_voxel_stream<<<dim3(kStreamBuckets, nf), kWave, (size_t)c->vcap * 24u, s>>>(fr);
+            k_voxel_stream<<<dim3(kStreamBuckets, nf), kStreamWaves * kWave, (size_t)c->vcap * 24u, s>>>(fr);
             mark(c, "k_voxel_stream");
         } else {
             for (uint32_t p = 0; p < c->npass_voxel; ++p) {

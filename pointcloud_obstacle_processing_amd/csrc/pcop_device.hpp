@@ -1216,9 +1216,13 @@ __global__ __launch_bounds__(kBlock) void k_vid_scatter(const Frame* frames) {
     }
 }
 
-// One wave per bucket.  Dynamic LDS: float4 acc[vcap] {sum x, sum y, sum z, count} and
-// unsigned long long peers[vcap].
-__global__ __launch_bounds__(kWave) void k_voxel_stream(const Frame* frames) {
+// One block per bucket.  With kStreamWaves > 1 the bucket's voxels are dealt out to the block's waves
+// (voxel & (waves-1)) and every wave walks all of the bucket's records, accumulating the ones it owns;
+// measured on C3: 1 wave 66 us, 2 waves 70 us, 4 waves 77 us per batch - the kernel is bound by the chain of
+// LDS round trips of the longest bucket (about 8 per step), not by waves in flight, so one wave it is.
+// Dynamic LDS: float4 acc[vcap] {sum x, sum y, sum z, count} and unsigned long long peers[vcap].
+constexpr int kStreamWaves = 1;
+__global__ __launch_bounds__(kStreamWaves * kWave) void k_voxel_stream(const Frame* frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
@@ -1232,21 +1236,23 @@ __global__ __launch_bounds__(kWave) void k_voxel_stream(const Frame* frames) {
     float4* acc = reinterpret_cast<float4*>(s_dyn);
     unsigned long long* peers_w = reinterpret_cast<unsigned long long*>(s_dyn + (size_t)vcap * sizeof(float4));
     const uint32_t lane = lane_id();
+    const uint32_t wv = threadIdx.x / kWave;
     // records of the bucket: [start, start + count)
     uint32_t before = 0;
     for (uint32_t t = lane; t < b; t += kWave) before += bin_total[t];
     const uint32_t start = wave_sum(before), count = bin_total[b];
     const uint32_t id0 = b << sh;
     const uint32_t nv = min(1u << sh, m - id0);   // voxels of this bucket
-    for (uint32_t v = lane; v < nv; v += kWave) { acc[v] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u)); peers_w[v] = 0ull; }
-    __builtin_amdgcn_wave_barrier();
+    for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) { acc[v] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u)); peers_w[v] = 0ull; }
+    __syncthreads();
     const uint32_t steps = (count + kWave - 1) / kWave;
     // records two steps ahead are in flight while a step runs (clamped, unconditional loads: a load
     // under a branch would be waited for at the branch's join)
     const uint32_t last = start + count - 1u;
     auto step = [&](const float4& r, uint32_t i) {
-        const bool active = i < count;
-        const uint32_t lv = active ? f2u(r.w) - id0 : 0u;
+        const uint32_t lv0 = f2u(r.w) - id0;
+        const bool active = i < count && (lv0 & (uint32_t)(kStreamWaves - 1)) == wv;   // this wave's voxels only
+        const uint32_t lv = active ? lv0 : 0u;
         const uint64_t peers = match_digit_lds(peers_w, lv, active);
         const uint32_t rank = active ? (uint32_t)__popcll(peers & lanemask_lt()) : 0xFFFFFFFFu;
         for (uint32_t q = 0; __any(active && rank >= q); ++q) {   // same voxel: lane order = index order
@@ -1277,7 +1283,8 @@ __global__ __launch_bounds__(kWave) void k_voxel_stream(const Frame* frames) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    for (uint32_t v = lane; v < nv; v += kWave) {
+    __syncthreads();
+    for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) {
         const float4 a = acc[v];
         const float fc = (float)f2u(a.w);
         cx[id0 + v] = a.x / fc; cy[id0 + v] = a.y / fc; cz[id0 + v] = a.z / fc;
@@ -2025,6 +2032,8 @@ __device__ __forceinline__ uint32_t row_window(const uint2* __restrict__ cmap, u
 
 // parent[c] = the adjacent cell of smallest priority among the 13 backward cells of the 3x3x3
 // neighbourhood (5 rows), if it has a smaller priority than c.  No atomics: a forest.
+// Two rounds of independent loads (row windows, then the metadata of the 13 neighbour slots; a slot
+// without a neighbour re-reads the cell's own), then pair tests only against cells of smaller priority.
 __global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
@@ -2038,24 +2047,41 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
         const uint4 ma = slot_meta[c];   // {first record, points, priority, grid position}
-        unsigned long long best = ~0ull;
-#pragma unroll 1
+        // rows: (dy,dz) = (-1,-1) (0,-1) (1,-1) (-1,0) with dx = -1..1, and the cell's own row with dx = -1
+        uint2 e0[5];
+        uint32_t e1[5], sh[5], wd[5];
+#pragma unroll
         for (int r = 0; r < 5; ++r) {
-            // rows: (dy,dz) = (-1,-1) (0,-1) (1,-1) (-1,0) with dx = -1..1, and the cell's own row with dx = -1
-            uint32_t pos, width;
-            if (r < 3) { pos = ma.w - plane + (uint32_t)(r - 1) * rowbits - 1u; width = 3u; }
-            else if (r == 3) { pos = ma.w - rowbits - 1u; width = 3u; }
-            else { pos = ma.w - 1u; width = 1u; }
-            uint32_t id;
-            uint32_t win = row_window(cmap, pos, width, &id);
-            while (win) {
-                win &= win - 1u;   // the ids of a row's occupied cells are consecutive
-                const uint4 mb = slot_meta[id];
-                if (mb.z < ma.z && (((unsigned long long)mb.z << 32) | id) < best &&
-                    lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2))
-                    best = ((unsigned long long)mb.z << 32) | id;
-                ++id;
+            uint32_t pos;
+            if (r < 3) { pos = ma.w - plane + (uint32_t)(r - 1) * rowbits - 1u; wd[r] = 3u; }
+            else if (r == 3) { pos = ma.w - rowbits - 1u; wd[r] = 3u; }
+            else { pos = ma.w - 1u; wd[r] = 1u; }
+            sh[r] = pos & 31u;
+            e0[r] = cmap[pos >> 5];
+            e1[r] = cmap[(pos >> 5) + 1u].x;
+        }
+        uint4 mb[13];
+        uint32_t nid[13];
+        int slot = 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            uint32_t bits = e0[r].x >> sh[r];
+            if (sh[r] + wd[r] > 32u) bits |= (e1[r] << 1) << (31u - sh[r]);
+            const uint32_t cnt = __popc(bits & ((1u << wd[r]) - 1u));
+            const uint32_t id0 = e0[r].y + __popc(e0[r].x & ((1u << sh[r]) - 1u));
+            const int w = r == 4 ? 1 : 3;
+#pragma unroll
+            for (int k = 0; k < w; ++k) {
+                nid[slot] = (uint32_t)k < cnt ? id0 + (uint32_t)k : c;   // the ids of a row's occupied cells are consecutive
+                mb[slot] = slot_meta[nid[slot]];
+                ++slot;
             }
+        }
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int q = 0; q < 13; ++q) {
+            const unsigned long long key = ((unsigned long long)mb[q].z << 32) | nid[q];
+            if (mb[q].z < ma.z && key < best && lane_cells_hit(rec, ma.x, ma.y, mb[q].x, mb[q].y, r2)) best = key;
         }
         if (best != ~0ull) parent[c] = (uint32_t)best;
     }
