@@ -50,7 +50,13 @@ def kernel_alg_bytes(name, occurrence, n, m, n_cells):
         return 12 * m + 8 * m
     if name == "k_cell_place":
         return 12 * m + 8 * m + 16 * m
-    if name in ("k_cell_union", "k_cell_hook", "k_cell_check"):
+    if name == "k_cell_mark":
+        return 12 * m + 4 * m
+    if name == "k_cell_count":
+        return 4 * m + 8 * m
+    if name == "k_cell_starts":
+        return 28 * n_cells
+    if name in ("k_cell_union", "k_cell_hook", "k_cgrid_union", "k_cgrid_hook"):
         return 12 * m + 4 * m          # neighbour + cluster pass reads 12·M, writes 4·M
     if name == "k_cell_flatten":
         return 8 * m

@@ -55,7 +55,7 @@ class DevState(C.Structure):
     _fields_ = [("err", C.c_uint32), ("n_in", C.c_uint32), ("is_dense", C.c_uint32), ("n_valid", C.c_uint32),
                 ("passthrough", C.c_uint32), ("m", C.c_uint32), ("kind", C.c_uint32), ("trivial", C.c_uint32),
                 ("emit_cloud", C.c_uint32), ("out_layout", C.c_uint32), ("out_soa_stride", C.c_uint32),
-                ("ticket", C.c_uint32), ("inv_leaf", C.c_float), ("vmin", C.c_float * 3), ("vmax", C.c_float * 3),
+                ("reserved0", C.c_uint32), ("inv_leaf", C.c_float), ("vmin", C.c_float * 3), ("vmax", C.c_float * 3),
                 ("min_b", C.c_int32 * 3), ("div_b", C.c_int32 * 3), ("mul", C.c_uint32 * 3), ("plan_voxel", RadixPlan),
                 ("src_x", C.c_void_p), ("src_y", C.c_void_p), ("src_z", C.c_void_p), ("inv_cell", C.c_double),
                 ("c_n", C.c_uint32), ("c_from_input", C.c_uint32), ("r2", C.c_float), ("min_cluster", C.c_uint32),

@@ -107,6 +107,10 @@ struct pcop_ctx {
     // dense cell grid: on unless PCOP_CELL_PATH=hash; a frame whose grid exceeds kCmapCells is re-run on the hash
     // table and the context stays there until the tolerance changes
     bool cell_grid = true, cgrid_ok = true;
+    // The grid kernels give a lane to a cell and let it walk its cross pairs alone, which suits the usual few points
+    // per cell; when cells are crowded (large tolerance / tiny leaf) the hash-table kernels, which put a whole wave
+    // on a cell, are faster.  Chosen from the previous batch's points per cell; either choice gives the same result.
+    bool crowded_cells = false;
     uint32_t ctiles = kCmapCells / 32u / kVmapTile;
     std::map<GraphKey, hipGraphExec_t> graphs;
 
@@ -183,7 +187,7 @@ uint32_t hash_cap_for(uint32_t n) {
     return cap;
 }
 
-bool grid_on(const pcop_ctx* c) { return c->cell_grid && c->cgrid_ok && c->kind != kFrameVoxelOnly; }
+bool grid_on(const pcop_ctx* c) { return c->cell_grid && c->cgrid_ok && !c->crowded_cells && c->kind != kFrameVoxelOnly; }
 bool stream_on(const pcop_ctx* c) { return c->voxel_stream && c->stream_ok && c->kind != kFrameClusterOnly; }
 
 // The launch sequence of one batch.  nb = launch-size bucket (>= every frame's point count), nf =
@@ -282,8 +286,6 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
         }
         k_cell_flatten<<<dim3(64, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_flatten");
-        k_kept_count<<<sg, kBlock, 0, s>>>(fr);
-        mark(c, "k_kept_count");
         k_kept_apply<<<sg, kBlock, 0, s>>>(fr, c->npass_csr, (uint32_t)MAXB);
         mark(c, "k_kept_apply");
         for (uint32_t p = 0; p < c->npass_csr; ++p) {
@@ -482,6 +484,17 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
     }
     if (kb_voxel) c->npass_voxel = passes_for(c, kb_voxel);
     if (kb_csr) c->npass_csr = passes_for(c, kb_csr);
+    if (c->kind != kFrameVoxelOnly) {
+        uint64_t pts = 0, cells = 0;
+        for (uint32_t f = 0; f < c->nframes; ++f) {
+            const DevState* hs = c->slots[f].h_state;
+            if (!c->slots[f].result_trivial) { pts += hs->c_n; cells += hs->n_cells; }
+        }
+        if (cells) {
+            if (pts > 24 * cells) c->crowded_cells = true;
+            else if (pts < 16 * cells) c->crowded_cells = false;
+        }
+    }
     if (grid_on(c)) {
         uint32_t tiles = 0;
         for (uint32_t f = 0; f < c->nframes; ++f)
@@ -575,7 +588,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
     TRY(dev_alloc(c, &f.hkey, hcap)); TRY(dev_alloc(c, &f.hcount, hcap)); TRY(dev_alloc(c, &f.hmin, hcap));
     TRY(dev_alloc(c, &f.cell_start, hcap)); TRY(dev_alloc(c, &f.parent, hcap));
     TRY(dev_alloc(c, &f.comp_size, hcap)); TRY(dev_alloc(c, &f.comp_rank, hcap)); TRY(dev_alloc(c, &f.cell_list, n + 1));
-    TRY(dev_alloc(c, &f.slot_meta, hcap)); TRY(dev_alloc(c, &f.cell_info, 2 * (n + 1))); TRY(dev_alloc(c, &f.todo, n + 2));
+    TRY(dev_alloc(c, &f.slot_meta, hcap)); TRY(dev_alloc(c, &f.cell_info, 2 * (n + 1)));
     TRY(dev_alloc(c, &f.pt_slot, n + 1)); TRY(dev_alloc(c, &f.pt_rank, n + 1)); TRY(dev_alloc(c, &f.pt_root, n + 1));
     TRY(dev_alloc(c, &f.idx_a, n + 1)); TRY(dev_alloc(c, &f.idx_b, n + 1)); TRY(dev_alloc(c, &f.d_offsets, n + 2));
     TRY(dev_alloc(c, &f.d_xyzr, n + 1));
@@ -907,7 +920,7 @@ int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* byt
         {"comp_rank", f.comp_rank, h * 4}, {"pt_slot", f.pt_slot, n * 4}, {"pt_rank", f.pt_rank, n * 4},
         {"pt_root", f.pt_root, n * 4}, {"idx_a", f.idx_a, n * 4}, {"idx_b", f.idx_b, n * 4},
         {"d_offsets", f.d_offsets, (n + 1) * 4}, {"bin_total", f.bin_total, (size_t)kMaxBins * 4},
-        {"todo", f.todo, (n + 1) * 4}, {"cell_list", f.cell_list, n * 4},
+        {"cell_list", f.cell_list, n * 4},
         {"vkey", f.vkey, n * 4}, {"vflag", f.vflag, f.vflag.get() ? (size_t)kVmapCells : 0},
         {"cflag", f.cflag, f.cflag.get() ? (size_t)kCmapCells : 0}, {"slot_meta", f.slot_meta, h * 16},
     };

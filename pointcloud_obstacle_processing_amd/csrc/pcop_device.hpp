@@ -13,13 +13,15 @@
 //     k_radix_hist / k_table_scan / k_radix_scatter   (x passes) stable LSD radix partition of
 //                             packed xyz records by PCL's linear voxel index
 //     k_voxel_reduce          run heads -> rank; in-order float32 sums -> centroids
-//   cell grid (replaces the FLANN kd-tree built at od.cpp:791-792)
-//     k_cell_insert           points -> hash table of cells (edge tol/1.99), rank inside the cell
-//     k_slot_count, k_slot_apply, k_cell_place   counting sort of the points by cell
+//   cell grid (replaces the FLANN kd-tree built at od.cpp:791-792): cells of edge tol/1.99
+//    dense grid (default): k_cgrid_setup, k_cell_mark, k_occ_scan<1>, k_cell_count, k_cell_starts,
+//                          k_cell_place   occupancy bits -> cell ids; points sorted by cell
+//    hash table (fallback): k_cell_insert, k_slot_count, k_slot_apply, k_cell_place
 //   clusters (replaces EuclideanClusterExtraction::extract, od.cpp:446-454)
-//     k_cell_hook, k_cell_compress, k_cell_union   connected components of the cell graph
+//     k_cgrid_hook | k_cell_hook, k_cell_compress, k_cgrid_union | k_cell_union
+//                             connected components of the cell graph
 //     k_cell_flatten          root per point, component sizes
-//     k_kept_count, k_kept_apply   size filter, discovery order, CSR offsets
+//     k_kept_apply            size filter, discovery order, CSR offsets
 //     k_csr_hist / k_table_scan / k_csr_scatter   stable partition of point indices by cluster
 //     k_emit                  results -> pinned host memory; hash table reset for the next frame
 //
@@ -50,7 +52,7 @@ constexpr int kTile = kBlock * kItems;           // records per partition block
 constexpr int kMaxPasses = 4;                    // 4 x 8 bits = 3 x 11 bits >= 32-bit keys
 constexpr int kScanItems = 4;                    // elements per thread in flag-scan kernels
 constexpr int kScanTile = kBlock * kScanItems;
-constexpr int kReduceBlocks = 256;               // grid of the min/max kernel: one block per CU, short ticket queue
+constexpr int kReduceBlocks = 256;               // grid of the min/max kernel: one block per CU
 constexpr int kCellBias = 1 << 20;               // cell coordinates are stored biased, 21 bits per axis
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint32_t kVmapCells = 1u << 26;       // streaming voxel path: largest voxel grid (cells) with an occupancy map
@@ -126,7 +128,7 @@ struct DevState {
     uint32_t passthrough;   // VoxelGrid overflow rule fired
     uint32_t m;             // voxels (downsampled points)
     uint32_t kind, trivial, emit_cloud, out_layout, out_soa_stride;
-    uint32_t ticket;        // arrival counter of k_minmax_voxel_setup
+    uint32_t reserved0;
     // voxel grid (pcl::VoxelGrid members)
     float    inv_leaf;
     float    vmin[3], vmax[3];
@@ -182,7 +184,6 @@ struct Frame {
     DevPtr<unsigned long long> hkey;  // cell hash table: key+1 (0 = empty)
     DevPtr<uint32_t> hcount, hmin;    //                  points, smallest point index (= priority)
     DevPtr<uint32_t> cell_start, cell_list, parent, comp_size, comp_rank;
-    DevPtr<uint32_t> todo;            // unused
     DevPtr<uint4> slot_meta;          // per occupied slot: {first record, points, smallest point index, 0}
     DevPtr<uint4> cell_info;          // per cell (dense), 2 x uint4: {key lo, key hi, first record, points}, {min idx, slot, 0, 0}
     DevPtr<uint32_t> pt_slot, pt_rank, pt_root;
@@ -2194,6 +2195,11 @@ __global__ __launch_bounds__(kBlock) void k_cell_flatten(const Frame* frames) {
     uint32_t* __restrict__ comp_size = F.comp_size;
     if (cluster_stage_off(st)) return;
     const uint32_t n = st->c_n;
+    {   // k_kept_apply publishes one 64-bit word per tile of points in `table` (free between the voxel and the CSR passes)
+        unsigned long long* __restrict__ tile_pub = reinterpret_cast<unsigned long long*>(F.table.get());
+        const uint32_t ntiles = (n + kScanTile - 1) / kScanTile;
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) tile_pub[t] = 0ull;
+    }
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
     const uint32_t wave = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
@@ -2236,37 +2242,16 @@ __device__ __forceinline__ uint32_t kept_size(uint32_t i, const uint32_t* __rest
     return (s >= lo && s <= hi) ? s : 0u;
 }
 
-__global__ __launch_bounds__(kBlock) void k_kept_count(const Frame* frames) {
-    __shared__ uint32_t s_w[kWavesPerBlock];
-    const Frame& F = frames[blockIdx.y];
-    const DevState* st = &F.st;
-    const uint32_t* __restrict__ pt_root = F.pt_root; const uint32_t* __restrict__ hmin = F.hmin;
-    const uint32_t* __restrict__ comp_size = F.comp_size;
-    uint32_t* __restrict__ tile_cnt = F.tile_a; uint32_t* __restrict__ tile_pts = F.tile_b;
-    if (cluster_stage_off(st)) return;
-    const uint32_t n = st->c_n;
-    const uint32_t base = blockIdx.x * kScanTile;
-    if (base >= n) return;
-    const uint32_t lo = st->min_cluster, hi = st->max_cluster;
-    uint32_t c = 0, s = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const uint32_t i = base + threadIdx.x * kScanItems + k;
-        if (i < n) { uint32_t r; const uint32_t v = kept_size(i, pt_root, hmin, comp_size, lo, hi, &r); c += v ? 1u : 0u; s += v; }
-    }
-    const uint32_t tc = block_sum(c, s_w);
-    const uint32_t ts = block_sum(s, s_w);
-    if (threadIdx.x == 0) { tile_cnt[blockIdx.x] = tc; tile_pts[blockIdx.x] = ts; }
-}
-
-// comp_rank[root] = discovery rank of the kept cluster; offsets_out[rank] = CSR offset.
+// comp_rank[root] = discovery rank of the kept cluster; offsets_out[rank] = CSR offset.  One kernel: a
+// tile publishes {clusters it opens + 1, their points} as one 64-bit word and adds up the words of the
+// lower tiles (bounded wait, as in k_voxel_reduce; k_cell_flatten zeroes the words).
 __global__ __launch_bounds__(kBlock) void k_kept_apply(Frame* frames, uint32_t npass_csr, uint32_t maxbits) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     const uint32_t* __restrict__ pt_root = F.pt_root; const uint32_t* __restrict__ hmin = F.hmin;
     const uint32_t* __restrict__ comp_size = F.comp_size;
-    const uint32_t* __restrict__ tile_cnt = F.tile_a; const uint32_t* __restrict__ tile_pts = F.tile_b;
+    unsigned long long* __restrict__ tile_pub = reinterpret_cast<unsigned long long*>(F.table.get());
     uint32_t* __restrict__ comp_rank = F.comp_rank; uint32_t* __restrict__ offsets_out = F.d_offsets;
     if (cluster_stage_off(st)) return;
     const uint32_t n = st->c_n;
@@ -2276,8 +2261,6 @@ __global__ __launch_bounds__(kBlock) void k_kept_apply(Frame* frames, uint32_t n
     }
     const uint32_t base = blockIdx.x * kScanTile;
     if (base >= n) return;
-    const uint32_t before_c = tiles_before(tile_cnt, blockIdx.x, s_w);
-    const uint32_t before_s = tiles_before(tile_pts, blockIdx.x, s_w);
     const uint32_t lo = st->min_cluster, hi = st->max_cluster;
     uint32_t v[kScanItems], root[kScanItems];
     uint32_t c = 0, s = 0;
@@ -2290,8 +2273,25 @@ __global__ __launch_bounds__(kBlock) void k_kept_apply(Frame* frames, uint32_t n
         c += v[k] ? 1u : 0u; s += v[k];
     }
     uint32_t totc, tots;
-    uint32_t rc = before_c + block_excl_scan(c, s_w, &totc);
-    uint32_t rs = before_s + block_excl_scan(s, s_w, &tots);
+    uint32_t rc = block_excl_scan(c, s_w, &totc);
+    uint32_t rs = block_excl_scan(s, s_w, &tots);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(tile_pub + blockIdx.x, ((unsigned long long)(totc + 1u) << 32) | tots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t mine_c = 0, mine_s = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
+        unsigned long long q = __hip_atomic_load(tile_pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        while ((q >> 32) == 0ull) {
+            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); q = 1ull << 32; break; }
+            __builtin_amdgcn_s_sleep(2);
+            q = __hip_atomic_load(tile_pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        mine_c += (uint32_t)(q >> 32) - 1u; mine_s += (uint32_t)q;
+    }
+    __syncthreads();
+    const uint32_t before_c = block_sum(mine_c, s_w);
+    const uint32_t before_s = block_sum(mine_s, s_w);
+    rc += before_c; rs += before_s;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         if (v[k]) { comp_rank[root[k]] = rc; offsets_out[rc] = rs; ++rc; rs += v[k]; }

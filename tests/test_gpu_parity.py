@@ -588,3 +588,29 @@ def test_cell_grid_too_large_falls_back_to_hash(capi, oracle, monkeypatch):
     got = c.process_xyz(pts)
     assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
     c.close()
+
+
+def test_crowded_cells_switch_to_the_hash_kernels(capi, oracle, monkeypatch):
+    """Many points per cell (large tolerance): after one batch the context runs the wave-per-cell kernels of the
+    hash path; a sparse cloud brings it back to the grid.  Same answers either way."""
+    monkeypatch.setenv("PCOP_CELL_PATH", "grid")
+    c = capi.Context(200_000)
+    pts = synth.make_cloud("C3", n=150_000, seed=31)
+    p = dict(leaf=0.015, tol=0.4, min_cluster=5, max_cluster=10**9)     # the deployed params.yaml values
+    c.set_params(publish_clouds=1, **p)
+    ref = oracle.process_xyz(pts, **p)
+    paths = []
+    for rep in range(3):
+        got = c.process_xyz(pts)
+        assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+        paths.append(c.debug_state().cpath)
+    assert paths[0] == 1 and paths[-1] == 0
+    q = synth.params_of("C3")
+    c.set_params(publish_clouds=1, **q)
+    ref2 = oracle.process_xyz(pts, **q)
+    for rep in range(2):
+        got = c.process_xyz(pts)
+        assert_same_clusters(got["offsets"], got["indices"], ref2["offsets"], ref2["indices"])
+    assert c.debug_state().cpath == 1
+    c.close()
