@@ -152,6 +152,40 @@ int pcop_wait_batch(pcop_ctx* ctx, pcop_result* out, int nframes);
 int pcop_cluster_summaries(pcop_ctx* ctx, float* xyzr, int32_t cap_clusters);
 int pcop_cluster_summaries_frame(pcop_ctx* ctx, int frame, float* xyzr, int32_t cap_clusters);
 
+/* ---- the step before the hot path: bounds filter + occupancy binning -------------
+ * Replaces build_initial_occupancy_grid_dataset (od.cpp:175-269) with its helpers
+ * get_occupancy_grid_x_y (od.cpp:134-150) and get_occupancy_grid_location (od.cpp:153-157):
+ * drops the points outside the box (and those whose x is NaN), counts the kept points per 2-D grid
+ * cell, takes the integer mean of every grid row and marks the cells below (1 - dev_percent) of
+ * their row's mean as holes (100).  The kept points, in input order, are the cloud the reference
+ * hands to downsample_cloud (od.cpp:740); here they stay resident in HBM for pcop_process_filtered. */
+typedef struct pcop_occ_params {
+    float   x_min, x_max;      /* pt_lower_lim_x, pt_upper_lim_x   (od.cpp:947-948) */
+    float   y_min, y_max;      /* pt_lower_lim_y, pt_upper_lim_y   (od.cpp:949-950) */
+    float   z_min, z_max;      /* pt_lower_lim_z, pt_upper_lim_z   (od.cpp:951-952) */
+    float   block_size;        /* block_size                       (od.cpp:955)     */
+    float   dev_percent;       /* dev_percent                      (od.cpp:956)     */
+    int32_t grid_width;        /* occupancy_grid_width             (od.cpp:958)     */
+    int32_t grid_height;       /* occupancy_grid_height            (od.cpp:959)     */
+} pcop_occ_params;
+
+/* occupancy_grid_width / _height as main() derives them from the limits (od.cpp:958-959). */
+void pcop_occupancy_grid_dims(float x_min, float x_max, float y_min, float y_max, float block_size,
+                              int32_t* grid_width, int32_t* grid_height);
+
+/* xyz/layout/n/mem as in pcop_process_xyz.  Outputs (each may be NULL): out_xyz = the kept points
+ * (AOS12, caller provides room for n points); counts[w*h] = occupancy_grid_pt_counts; row_avg[h] =
+ * row_averages; grid[w*h] = occupancy_grid_data (100 or 0).  *n_out = kept points; *index_errors =
+ * kept points whose cell index was >= w*h (the reference logs them, does not count them and keeps
+ * them, od.cpp:205-213). */
+int pcop_occupancy_filter(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int mem, const pcop_occ_params* p,
+                          float* out_xyz, size_t* n_out, int64_t* counts, int64_t* row_avg, int8_t* grid,
+                          int32_t* index_errors);
+
+/* The chain of pcop_process_xyz on the cloud the last pcop_occupancy_filter kept (it never leaves
+ * HBM): build_initial_occupancy_grid_dataset -> downsample_cloud -> ... of cloud_cb (od.cpp:727-797). */
+int pcop_process_filtered(pcop_ctx* ctx, pcop_result* out);
+
 /* Device-side allocation helpers so a host program without its own HIP code
  * (e.g. a ctypes caller) can keep clouds resident in HBM. */
 int pcop_dev_alloc(pcop_ctx* ctx, size_t bytes, void** dev_ptr);

@@ -19,8 +19,8 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle with g++ (seconds)."""
-    src = os.path.join(_HERE, "pcl_restatement.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("pcl_restatement.cpp", "occupancy_restatement.cpp")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpcop_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -51,8 +51,54 @@ def lib():
         L.pcop_oracle_process_xyz.restype = C.c_int
         L.pcop_oracle_process_xyz.argtypes = [fp, C.c_int, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_int32,
                                               C.c_int32, fp, C.POINTER(C.c_size_t), C.POINTER(C.c_int), ip, ip, ip]
+        L.pcop_oracle_occ_grid_dims.restype = None
+        L.pcop_oracle_occ_grid_dims.argtypes = [C.c_float] * 5 + [ip, ip]
+        L.pcop_oracle_occ_cell.restype = C.c_int32
+        L.pcop_oracle_occ_cell.argtypes = [C.c_float, C.c_float, C.POINTER(OccParams)]
+        L.pcop_oracle_occupancy.restype = C.c_int
+        L.pcop_oracle_occupancy.argtypes = [fp, C.c_size_t, C.POINTER(OccParams), fp, C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_byte), ip]
         _lib = L
     return _lib
+
+
+class OccParams(C.Structure):
+    """pcop_oracle_occ_params: the occupancy step's limits, block size, deviation and grid size (od.cpp:87-102, 958-959)."""
+    _fields_ = [("x_min", C.c_float), ("x_max", C.c_float), ("y_min", C.c_float), ("y_max", C.c_float),
+                ("z_min", C.c_float), ("z_max", C.c_float), ("block_size", C.c_float), ("dev_percent", C.c_float),
+                ("grid_width", C.c_int32), ("grid_height", C.c_int32)]
+
+
+def occ_params(x_min, x_max, y_min, y_max, z_min, z_max, block_size, dev_percent):
+    """Parameters with the grid size derived as the reference's main() does (od.cpp:958-959)."""
+    w, h = C.c_int32(0), C.c_int32(0)
+    lib().pcop_oracle_occ_grid_dims(x_min, x_max, y_min, y_max, block_size, C.byref(w), C.byref(h))
+    return OccParams(x_min, x_max, y_min, y_max, z_min, z_max, block_size, dev_percent, w.value, h.value)
+
+
+def occ_cell(px, py, p):
+    return lib().pcop_oracle_occ_cell(C.c_float(px), C.c_float(py), C.byref(p))
+
+
+def occupancy(xyz, p):
+    """build_initial_occupancy_grid_dataset -> dict(xyz, counts, row_avg, grid, index_errors)."""
+    pts = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    n = len(pts)
+    cells, rows = p.grid_width * p.grid_height, p.grid_height
+    out = np.zeros(max(3 * n, 3), dtype=np.float32)
+    counts = np.zeros(max(cells, 1), dtype=np.int64)
+    row_avg = np.zeros(max(rows, 1), dtype=np.int64)
+    grid = np.zeros(max(cells, 1), dtype=np.int8)
+    n_out, bad = C.c_size_t(0), C.c_int32(0)
+    rc = lib().pcop_oracle_occupancy(_f(pts), n, C.byref(p), _f(out), C.byref(n_out),
+                                     counts.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                     row_avg.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                     grid.ctypes.data_as(C.POINTER(C.c_byte)), C.byref(bad))
+    if rc:
+        raise ValueError("pcop_oracle_occupancy: %d" % rc)
+    k = n_out.value
+    return dict(xyz=out[:3 * k].reshape(k, 3).copy(), n_out=k, counts=counts[:cells], row_avg=row_avg[:rows],
+                grid=grid[:cells], index_errors=bad.value)
 
 
 def _f(a):

@@ -21,8 +21,15 @@ EXPORTS = [
     "pcop_process_pointcloud2", "pcop_process_xyz", "pcop_submit_xyz", "pcop_wait", "pcop_cluster_summaries",
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
     "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
-    "pcop_cluster_summaries_frame",
+    "pcop_cluster_summaries_frame", "pcop_occupancy_grid_dims", "pcop_occupancy_filter", "pcop_process_filtered",
 ]
+
+
+class OccParams(C.Structure):
+    """pcop_occ_params (include/pcop.h): limits, block size, deviation and grid size of the occupancy step."""
+    _fields_ = [("x_min", C.c_float), ("x_max", C.c_float), ("y_min", C.c_float), ("y_max", C.c_float),
+                ("z_min", C.c_float), ("z_max", C.c_float), ("block_size", C.c_float), ("dev_percent", C.c_float),
+                ("grid_width", C.c_int32), ("grid_height", C.c_int32)]
 
 
 class PcopError(RuntimeError):
@@ -95,6 +102,13 @@ def load_library():
     L.pcop_wait_batch.argtypes = [vp, C.POINTER(Result), C.c_int]
     L.pcop_cluster_summaries_frame.restype = C.c_int
     L.pcop_cluster_summaries_frame.argtypes = [vp, C.c_int, fp, C.c_int32]
+    L.pcop_occupancy_grid_dims.restype = None
+    L.pcop_occupancy_grid_dims.argtypes = [C.c_float] * 5 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.pcop_occupancy_filter.restype = C.c_int
+    L.pcop_occupancy_filter.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.POINTER(OccParams), C.c_void_p,
+                                        C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.pcop_process_filtered.restype = C.c_int
+    L.pcop_process_filtered.argtypes = [vp, C.POINTER(Result)]
     L.pcop_destroy.restype = None
     L.pcop_destroy.argtypes = [vp]
     L.pcop_set_params.restype = C.c_int
@@ -237,6 +251,34 @@ class Context:
         flat, n = pack_points(xyz, layout)
         r = Result()
         self._chk(self.lib.pcop_process_xyz(self.h, flat.ctypes.data, layout, n, int(is_dense), MEM_HOST, C.byref(r)))
+        return self._result(r)
+
+    def occupancy_grid_dims(self, x_min, x_max, y_min, y_max, block_size):
+        w, h = C.c_int32(0), C.c_int32(0)
+        self.lib.pcop_occupancy_grid_dims(C.c_float(x_min), C.c_float(x_max), C.c_float(y_min), C.c_float(y_max),
+                                          C.c_float(block_size), C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def occupancy_filter(self, xyz, occ, layout=LAYOUT_AOS12, want_cloud=True):
+        """Bounds filter + occupancy binning -> dict(xyz, counts, row_avg, grid, index_errors); the kept cloud
+        also stays resident for process_filtered()."""
+        flat, n = pack_points(xyz, layout)
+        cells, rows = occ.grid_width * occ.grid_height, occ.grid_height
+        out = np.zeros(max(3 * n, 3), dtype=np.float32)
+        counts = np.zeros(max(cells, 1), dtype=np.int64)
+        row_avg = np.zeros(max(rows, 1), dtype=np.int64)
+        grid = np.zeros(max(cells, 1), dtype=np.int8)
+        n_out, bad = C.c_size_t(0), C.c_int32(0)
+        self._chk(self.lib.pcop_occupancy_filter(self.h, flat.ctypes.data, layout, n, MEM_HOST, C.byref(occ),
+                                                 out.ctypes.data if want_cloud else None, C.byref(n_out),
+                                                 counts.ctypes.data, row_avg.ctypes.data, grid.ctypes.data, C.byref(bad)))
+        k = n_out.value
+        return dict(xyz=out[:3 * k].reshape(k, 3).copy() if want_cloud else None, n_out=k, counts=counts[:cells],
+                    row_avg=row_avg[:rows], grid=grid[:cells], index_errors=bad.value)
+
+    def process_filtered(self):
+        r = Result()
+        self._chk(self.lib.pcop_process_filtered(self.h, C.byref(r)))
         return self._result(r)
 
     def process_device(self, dev_ptr, n, is_dense=True, layout=LAYOUT_SOA):

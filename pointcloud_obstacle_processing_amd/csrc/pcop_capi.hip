@@ -114,6 +114,16 @@ struct pcop_ctx {
     uint32_t ctiles = kCmapCells / 32u / kVmapTile;
     std::map<GraphKey, hipGraphExec_t> graphs;
 
+    // bounds filter + occupancy binning (pcop_occupancy_filter): buffers made on first use
+    float* occ_xyz = nullptr;                 // three planes of `cap` floats: the kept points
+    unsigned long long* occ_counts = nullptr; // grid cells (64-bit counts)
+    long long* occ_rowavg = nullptr;
+    signed char* occ_grid = nullptr;
+    uint32_t* occ_totals = nullptr;           // {kept, index errors, internal error}
+    size_t occ_cells_cap = 0, occ_rows_cap = 0;
+    uint32_t occ_n = 0;
+    bool occ_valid = false;
+
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -863,6 +873,100 @@ int pcop_process_pointcloud2(pcop_ctx* c, const uint8_t* data, uint32_t width, u
     }
     c->nframes = 1;
     if ((rc = submit_common(c, kFrameChain, c->params.publish_clouds != 0, PCOP_LAYOUT_AOS12, is_dense))) return rc;
+    return finish_batch(c, out, out ? 1 : 0);
+}
+
+void pcop_occupancy_grid_dims(float x_min, float x_max, float y_min, float y_max, float block_size,
+                              int32_t* grid_width, int32_t* grid_height) {
+    // od.cpp:958-959, float arithmetic as written there (<math.h> in C++: the float overloads)
+    if (grid_width) *grid_width = (int32_t)std::ceil((std::fabs(y_min) + std::fabs(y_max)) / block_size);
+    if (grid_height) *grid_height = (int32_t)std::ceil((std::fabs(x_min) + std::fabs(x_max)) / block_size);
+}
+
+int pcop_occupancy_filter(pcop_ctx* c, const float* xyz, int layout, size_t n, int mem, const pcop_occ_params* p,
+                          float* out_xyz, size_t* n_out, int64_t* counts, int64_t* row_avg, int8_t* grid,
+                          int32_t* index_errors) {
+    if (!c || !p) return PCOP_ERR_ARG;
+    int rc = busy(c);
+    if (rc) return rc;
+    const float lim[6] = {p->x_min, p->x_max, p->y_min, p->y_max, p->z_min, p->z_max};
+    for (float v : lim) if (!std::isfinite(v)) { c->err = "occupancy limits must be finite"; return PCOP_ERR_PARAM; }
+    if (!(p->block_size > 0.0f) || !std::isfinite(p->block_size) || !std::isfinite(p->dev_percent)) { c->err = "block_size must be finite and > 0"; return PCOP_ERR_PARAM; }
+    if (p->grid_width <= 0 || p->grid_height <= 0 || (int64_t)p->grid_width * p->grid_height > (1 << 26)) { c->err = "occupancy grid must have 1 .. 2^26 cells"; return PCOP_ERR_PARAM; }
+    // the walks of od.cpp:139-147 end only if the limits are reachable in a sane number of steps
+    if ((std::fabs(p->x_min) + std::fabs(p->x_max) + std::fabs(p->y_min) + std::fabs(p->y_max)) / p->block_size > 1.0e8f) { c->err = "limits / block_size too large"; return PCOP_ERR_PARAM; }
+    if ((rc = set_device(c))) return rc;
+    Slot& sl = c->slots[0];
+    if ((rc = stage_input(c, sl, xyz, layout, n, mem))) return rc;
+    const size_t cells = (size_t)p->grid_width * p->grid_height, rows = (size_t)p->grid_height;
+    if (!c->occ_xyz) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->occ_xyz), std::max<size_t>(c->cap, 1) * 3 * sizeof(float)));
+        c->dev_allocs.push_back(c->occ_xyz);
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->occ_totals), 4 * sizeof(uint32_t)));
+        c->dev_allocs.push_back(c->occ_totals);
+    }
+    if (cells > c->occ_cells_cap) {   // the old, smaller buffers stay on the context's free list
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->occ_counts), cells * sizeof(unsigned long long)));
+        c->dev_allocs.push_back(c->occ_counts);
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->occ_grid), cells));
+        c->dev_allocs.push_back(c->occ_grid);
+        c->occ_cells_cap = cells;
+    }
+    if (rows > c->occ_rows_cap) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->occ_rowavg), rows * sizeof(long long)));
+        c->dev_allocs.push_back(c->occ_rowavg);
+        c->occ_rows_cap = rows;
+    }
+    c->occ_valid = false;
+    float* ox = c->occ_xyz; float* oy = ox + c->cap; float* oz = oy + c->cap;
+    const uint32_t ntiles = div_up((uint32_t)n, kScanTile);
+    HIPCHK(c, hipMemsetAsync(c->occ_counts, 0, cells * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->occ_totals, 0, 4 * sizeof(uint32_t), c->stream));
+    const OccParams op{p->x_min, p->x_max, p->y_min, p->y_max, p->z_min, p->z_max, p->block_size, p->dev_percent, p->grid_width, p->grid_height};
+    if (n) {
+        HIPCHK(c, hipMemsetAsync(sl.f.tile_a.get(), 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
+        k_occ_filter<<<ntiles, kBlock, 0, c->stream>>>(op, sl.src_x, sl.src_y, sl.src_z, (uint32_t)n, ox, oy, oz, c->occ_counts,
+                                                        sl.f.tile_a.get(), c->occ_totals);
+    }
+    k_occ_finish<<<(uint32_t)rows, kBlock, 0, c->stream>>>(op, c->occ_counts, c->occ_rowavg, c->occ_grid);
+    HIPCHK(c, hipGetLastError());
+    uint32_t totals[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(totals, c->occ_totals, sizeof(totals), hipMemcpyDeviceToHost, c->stream));
+    if (counts) HIPCHK(c, hipMemcpyAsync(counts, c->occ_counts, cells * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (row_avg) HIPCHK(c, hipMemcpyAsync(row_avg, c->occ_rowavg, rows * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (grid) HIPCHK(c, hipMemcpyAsync(grid, c->occ_grid, cells, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (totals[2]) { c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
+    const uint32_t kept = totals[0];
+    if (out_xyz && kept) {
+        std::vector<float> planes((size_t)kept * 3);
+        HIPCHK(c, hipMemcpy(planes.data(), ox, (size_t)kept * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(planes.data() + kept, oy, (size_t)kept * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(planes.data() + 2 * (size_t)kept, oz, (size_t)kept * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < kept; ++i) {
+            out_xyz[3 * (size_t)i] = planes[i]; out_xyz[3 * (size_t)i + 1] = planes[(size_t)kept + i]; out_xyz[3 * (size_t)i + 2] = planes[2 * (size_t)kept + i];
+        }
+    }
+    if (n_out) *n_out = kept;
+    if (index_errors) *index_errors = (int32_t)totals[1];
+    c->occ_n = kept;
+    c->occ_valid = true;
+    return PCOP_OK;
+}
+
+int pcop_process_filtered(pcop_ctx* c, pcop_result* out) {
+    if (!c) return PCOP_ERR_ARG;
+    int rc = busy(c);
+    if (rc) return rc;
+    if (!c->occ_valid) { c->err = "pcop_occupancy_filter has not produced a cloud on this context"; return PCOP_ERR_STATE; }
+    if ((rc = check_params(c, true, true))) return rc;
+    if ((rc = set_device(c))) return rc;
+    Slot& sl = c->slots[0];
+    sl.n = c->occ_n;
+    sl.src_x = c->occ_xyz; sl.src_y = c->occ_xyz + c->cap; sl.src_z = c->occ_xyz + 2 * c->cap;
+    c->nframes = 1;
+    // the cloud build_initial_occupancy_grid_dataset fills by push_back keeps PointCloud's default is_dense = true (od.cpp:214)
+    if ((rc = submit_common(c, kFrameChain, c->params.publish_clouds != 0, PCOP_LAYOUT_AOS12, 1))) return rc;
     return finish_batch(c, out, out ? 1 : 0);
 }
 

@@ -1,5 +1,6 @@
 #include "obstacle_path.hpp"
 
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 
@@ -82,6 +83,36 @@ void extract_euclidian_clusters(PointCloudXYZ::Ptr& input_cloud, std::vector<Poi
         pi.header = input_cloud->header;
         pi.indices.assign(indices.begin() + offsets[cidx], indices.begin() + offsets[cidx + 1]);
     }
+}
+
+void build_initial_occupancy_grid_dataset(int grid_size, int grid_height, int grid_width, char* grid_data, float x_min,
+                                          float x_max, float y_min, float y_max, float z_min, float z_max,
+                                          long long* point_count_array, long long* row_point_averages,
+                                          const PointCloudXYZ& input_cloud, PointCloudXYZ& output_cloud,
+                                          float block_size, float dev_percent) {
+    if (grid_size != grid_height * grid_width) throw std::runtime_error("build_initial_occupancy_grid_dataset: grid_size != height * width");
+    const size_t n = input_cloud.points.size();
+    pcop_ctx* c = default_context(n);
+    pcop_occ_params p{};
+    p.x_min = x_min; p.x_max = x_max; p.y_min = y_min; p.y_max = y_max; p.z_min = z_min; p.z_max = z_max;
+    p.block_size = block_size; p.dev_percent = dev_percent; p.grid_width = grid_width; p.grid_height = grid_height;
+    std::vector<float> kept(n ? 3 * n : 3);
+    std::vector<int64_t> counts((size_t)grid_size), rows((size_t)grid_height);
+    size_t n_out = 0;
+    int32_t bad = 0;
+    check(c, pcop_occupancy_filter(c, n ? &input_cloud.points[0].x : nullptr, PCOP_LAYOUT_AOS16, n, PCOP_MEM_HOST, &p, kept.data(),
+                                   &n_out, counts.data(), rows.data(), reinterpret_cast<int8_t*>(grid_data), &bad),
+          "pcop_occupancy_filter");
+    for (int i = 0; i < grid_size; ++i) point_count_array[i] = counts[(size_t)i];
+    for (int i = 0; i < grid_height; ++i) row_point_averages[i] = rows[(size_t)i];
+    for (size_t i = 0; i < n_out; ++i) {   // output_cloud.push_back(input_cloud.points[i])   od.cpp:214
+        PointXYZ q{};
+        q.x = kept[3 * i]; q.y = kept[3 * i + 1]; q.z = kept[3 * i + 2];
+        output_cloud.points.push_back(q);
+    }
+    output_cloud.width = (uint32_t)output_cloud.points.size();
+    output_cloud.height = 1;
+    if (bad) fprintf(stderr, "OUT OF BOUNDS INDEX ACCESS (%d points)\n", bad);   // ROS_ERROR at od.cpp:206
 }
 
 ObstacleNode::ObstacleNode(const NodeParams& prm, size_t max_points, int device) : params(prm) {

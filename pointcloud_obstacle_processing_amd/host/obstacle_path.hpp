@@ -5,6 +5,7 @@
 //
 //   downsample_cloud            od.cpp:271-296     VoxelGrid + optional publish on "voxel_grid"
 //   extract_euclidian_clusters  od.cpp:430-455     EuclideanClusterExtraction
+//   build_initial_occupancy_grid_dataset  od.cpp:175-269   bounds filter + occupancy binning (the step before)
 //   ObstacleNode::cloud_cb      od.cpp:674-928     the part of the callback the north star names:
 //                                                  PointCloud2 in -> voxel grid -> clusters ->
 //                                                  "voxel_grid", "centroids", "euc_clusters" out
@@ -33,6 +34,16 @@ void downsample_cloud(const PointCloudXYZ::Ptr& input_cloud, PointCloudXYZ& outp
 void extract_euclidian_clusters(PointCloudXYZ::Ptr& input_cloud, std::vector<PointIndices>& cluster_indices,
                                 float cluster_tolerance, int min_cluster_size, int max_cluster_size,
                                 KdTreeHandle::Ptr& search_method);
+
+// od.cpp:175-269, same argument list (the reference reads block_size and dev_percent from globals, od.cpp:87-88;
+// here they are the two trailing arguments).  grid_data gets 100 for a "hole" and 0 otherwise, point_count_array and
+// row_point_averages the per-cell counts and the integer row means, output_cloud the points inside the box in input
+// order.  The kept cloud also stays resident on the GPU of the default context (pcop_process_filtered).
+void build_initial_occupancy_grid_dataset(int grid_size, int grid_height, int grid_width, char* grid_data, float x_min,
+                                          float x_max, float y_min, float y_max, float z_min, float z_max,
+                                          long long* point_count_array, long long* row_point_averages,
+                                          const PointCloudXYZ& input_cloud, PointCloudXYZ& output_cloud,
+                                          float block_size, float dev_percent);
 
 // The node surface of the path: same topic names, queue sizes and parameter keys as od.cpp:930-1015.
 class ObstacleNode {

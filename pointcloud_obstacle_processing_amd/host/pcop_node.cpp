@@ -2,15 +2,19 @@
 // serialized sensor_msgs/PointCloud2, runs the path on the GPU and writes what the node would
 // publish on "voxel_grid", "centroids" and "euc_clusters", plus the cluster indices.
 //
-//   pcop_node --params params.yaml --cloud in.pc2 --out outdir [--device 0] [--stage-api]
+//   pcop_node --params params.yaml --cloud in.pc2 --out outdir [--device 0] [--stage-api] [--occupancy]
 //
 // --stage-api runs the two free functions (downsample_cloud, extract_euclidian_clusters) the way
 // cloud_cb calls them (od.cpp:740, od.cpp:791-797) instead of the fused frame entry.
+// --occupancy (with --stage-api) runs build_initial_occupancy_grid_dataset first, as cloud_cb does (od.cpp:725-731),
+// with the limits, block_size and dev_percent of the yaml tree, and writes occupancy.txt (grid size, kept points,
+// counts, row means, hole marks).
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "obstacle_path.hpp"
 
@@ -29,7 +33,7 @@ static void write_indices(const std::string& path, const std::vector<PointIndice
 int main(int argc, char** argv) {
     std::string params_path, cloud_path, out_dir = ".";
     int device = 0;
-    bool stage_api = false;
+    bool stage_api = false, occupancy = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--params" && i + 1 < argc) params_path = argv[++i];
@@ -37,6 +41,7 @@ int main(int argc, char** argv) {
         else if (a == "--out" && i + 1 < argc) out_dir = argv[++i];
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (a == "--stage-api") stage_api = true;
+        else if (a == "--occupancy") occupancy = true;
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (params_path.empty() || cloud_path.empty()) {
@@ -52,6 +57,27 @@ int main(int argc, char** argv) {
         if (stage_api) {
             PointCloudXYZ::Ptr in(new PointCloudXYZ);
             if (!from_pointcloud2(msg, in.get(), &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            if (occupancy) {   // od.cpp:725-731 with the grid size of od.cpp:958-960
+                int32_t gw = 0, gh = 0;
+                pcop_occupancy_grid_dims(prm.x_min, prm.x_max, prm.y_min, prm.y_max, prm.block_size, &gw, &gh);
+                const int gsize = gw * gh;
+                std::vector<char> grid((size_t)gsize);
+                std::vector<long long> cnt((size_t)gsize), rows((size_t)gh);
+                PointCloudXYZ::Ptr kept(new PointCloudXYZ);
+                build_initial_occupancy_grid_dataset(gsize, gh, gw, grid.data(), prm.x_min, prm.x_max, prm.y_min, prm.y_max,
+                                                     prm.z_min, prm.z_max, cnt.data(), rows.data(), *in, *kept,
+                                                     prm.block_size, prm.dev_percent);
+                std::ofstream f(out_dir + "/occupancy.txt");
+                f << gw << " " << gh << " " << kept->size() << "\n";
+                for (long long v : cnt) f << v << " ";
+                f << "\n";
+                for (long long v : rows) f << v << " ";
+                f << "\n";
+                for (char v : grid) f << (int)v << " ";
+                f << "\n";
+                kept->header = in->header;
+                in = kept;   // downsample_input_cloud
+            }
             Publisher<PointCloud2> pub;
             pub.topic = "voxel_grid";
             PointCloudXYZ::Ptr vox(new PointCloudXYZ);

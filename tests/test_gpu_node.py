@@ -48,3 +48,47 @@ def test_node_harness_c1(oracle, tmp_path, mode):
         ec = pc2io.read_pointcloud2(str(tmp_path / "euc_clusters.pc2"))
         assert ec["frame_id"] == "/world"                                                      # od.cpp:865
         assert ec["xyz"].tobytes() == ref["voxel_xyz"][ref["indices"]].tobytes()
+
+
+def test_node_harness_occupancy_then_chain(oracle, tmp_path):
+    """--occupancy: build_initial_occupancy_grid_dataset (host mirror, reference argument list) in front of the
+    stage API, as cloud_cb runs it (od.cpp:725-797); limits, block_size and dev_percent come from the yaml tree."""
+    exe = os.path.join(HOST, "pcop_node")
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    pts = synth.make_cloud("C1")
+    pts[::37, 1] = np.nan          # NaN y passes the reference's predicate (only x is tested, od.cpp:196)
+    pts[::91, 0] = np.nan
+    cloud = str(tmp_path / "c1.pc2")
+    pc2io.write_pointcloud2(cloud, pts, point_step=32, offsets=(0, 4, 8), width=100, height=100)
+    yaml_path = str(tmp_path / "params.yaml")
+    with open(yaml_path, "w") as f:
+        f.write("pointcloud_obstacle_processing:\n        x_min: 0.4\n        x_max: 4.0\n        y_min: 0.3\n        y_max: 3.2\n"
+                "        z_min: -0.4\n        z_max: 0.2\n        obstacle_detection:\n                block_size: 0.2\n"
+                "                dev_percent: 0.4\n                downsample_size: 0.05\n                euc_cluster_tolerance: 0.1\n"
+                "                euc_min_cluster_size: 5\n                euc_max_cluster_size: 20000\n")
+    out = subprocess.run([exe, "--params", yaml_path, "--cloud", cloud, "--out", str(tmp_path), "--stage-api", "--occupancy"],
+                         capture_output=True, text=True, timeout=300)
+    # NaN y survives the filter and the voxel grid is then handed a cloud it believes dense: the library refuses it loudly
+    assert out.returncode != 0 and "non-finite" in out.stderr
+    pts = synth.make_cloud("C1")
+    pts[::91, 0] = np.nan
+    pc2io.write_pointcloud2(cloud, pts, point_step=32, offsets=(0, 4, 8), width=100, height=100)
+    out = subprocess.run([exe, "--params", yaml_path, "--cloud", cloud, "--out", str(tmp_path), "--stage-api", "--occupancy"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    p = oracle.occ_params(np.float32(0.4), np.float32(4.0), np.float32(0.3), np.float32(3.2), np.float32(-0.4), np.float32(0.2),
+                          np.float32(0.2), np.float32(0.4))
+    ref = oracle.occupancy(pts, p)
+    lines = open(str(tmp_path / "occupancy.txt")).read().split("\n")
+    gw, gh, kept = (int(v) for v in lines[0].split())
+    assert (gw, gh, kept) == (p.grid_width, p.grid_height, ref["n_out"])
+    assert np.array_equal(np.array(lines[1].split(), dtype=np.int64), ref["counts"])
+    assert np.array_equal(np.array(lines[2].split(), dtype=np.int64), ref["row_avg"])
+    assert np.array_equal(np.array(lines[3].split(), dtype=np.int64), ref["grid"].astype(np.int64))
+    want = oracle.process_xyz(ref["xyz"], leaf=0.05, tol=0.1, min_cluster=5, max_cluster=20000)
+    vox = pc2io.read_pointcloud2(str(tmp_path / "voxel_grid.pc2"))
+    assert vox["xyz"].tobytes() == want["voxel_xyz"].tobytes()
+    clusters = read_indices(str(tmp_path / "cluster_indices.txt"))
+    assert len(clusters) == len(want["offsets"]) - 1
+    for c, idx in enumerate(clusters):
+        assert np.array_equal(idx, want["indices"][want["offsets"][c]:want["offsets"][c + 1]])
