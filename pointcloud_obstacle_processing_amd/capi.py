@@ -276,6 +276,13 @@ class Context:
         return dict(xyz=out[:3 * k].reshape(k, 3).copy() if want_cloud else None, n_out=k, counts=counts[:cells],
                     row_avg=row_avg[:rows], grid=grid[:cells], index_errors=bad.value)
 
+    def occupancy_filter_device(self, dev_ptr, n, occ, layout=LAYOUT_SOA):
+        """The same on a cloud already resident in HBM; returns (kept points, index errors) only."""
+        n_out, bad = C.c_size_t(0), C.c_int32(0)
+        self._chk(self.lib.pcop_occupancy_filter(self.h, C.c_void_p(dev_ptr), layout, int(n), MEM_DEVICE, C.byref(occ),
+                                                 None, C.byref(n_out), None, None, None, C.byref(bad)))
+        return n_out.value, bad.value
+
     def process_filtered(self):
         r = Result()
         self._chk(self.lib.pcop_process_filtered(self.h, C.byref(r)))

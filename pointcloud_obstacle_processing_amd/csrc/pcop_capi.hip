@@ -120,6 +120,7 @@ struct pcop_ctx {
     long long* occ_rowavg = nullptr;
     signed char* occ_grid = nullptr;
     uint32_t* occ_totals = nullptr;           // {kept, index errors, internal error}
+    uint32_t* occ_partials = nullptr;         // kOccPartials partial grids of up to kOccLdsCells cells
     size_t occ_cells_cap = 0, occ_rows_cap = 0;
     uint32_t occ_n = 0;
     bool occ_valid = false;
@@ -904,6 +905,8 @@ int pcop_occupancy_filter(pcop_ctx* c, const float* xyz, int layout, size_t n, i
         c->dev_allocs.push_back(c->occ_xyz);
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->occ_totals), 4 * sizeof(uint32_t)));
         c->dev_allocs.push_back(c->occ_totals);
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->occ_partials), (size_t)kOccPartials * kOccLdsCells * sizeof(uint32_t)));
+        c->dev_allocs.push_back(c->occ_partials);
     }
     if (cells > c->occ_cells_cap) {   // the old, smaller buffers stay on the context's free list
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->occ_counts), cells * sizeof(unsigned long long)));
@@ -922,13 +925,20 @@ int pcop_occupancy_filter(pcop_ctx* c, const float* xyz, int layout, size_t n, i
     const uint32_t ntiles = div_up((uint32_t)n, kScanTile);
     HIPCHK(c, hipMemsetAsync(c->occ_counts, 0, cells * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->occ_totals, 0, 4 * sizeof(uint32_t), c->stream));
+    if (cells <= (size_t)kOccLdsCells) HIPCHK(c, hipMemsetAsync(c->occ_partials, 0, (size_t)kOccPartials * cells * sizeof(uint32_t), c->stream));
     const OccParams op{p->x_min, p->x_max, p->y_min, p->y_max, p->z_min, p->z_max, p->block_size, p->dev_percent, p->grid_width, p->grid_height};
+    c->ev_used = 0;
     if (n) {
         HIPCHK(c, hipMemsetAsync(sl.f.tile_a.get(), 0, (size_t)ntiles * sizeof(uint32_t), c->stream));
+        mark(c, "start");
         k_occ_filter<<<ntiles, kBlock, 0, c->stream>>>(op, sl.src_x, sl.src_y, sl.src_z, (uint32_t)n, ox, oy, oz, c->occ_counts,
-                                                        sl.f.tile_a.get(), c->occ_totals);
+                                                        c->occ_partials, sl.f.tile_a.get(), c->occ_totals);
+        mark(c, "k_occ_filter");
+    } else {
+        mark(c, "start");
     }
-    k_occ_finish<<<(uint32_t)rows, kBlock, 0, c->stream>>>(op, c->occ_counts, c->occ_rowavg, c->occ_grid);
+    k_occ_finish<<<(uint32_t)rows, kBlock, 0, c->stream>>>(op, c->occ_counts, c->occ_partials, c->occ_rowavg, c->occ_grid);
+    mark(c, "k_occ_finish");
     HIPCHK(c, hipGetLastError());
     uint32_t totals[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(totals, c->occ_totals, sizeof(totals), hipMemcpyDeviceToHost, c->stream));
@@ -936,6 +946,7 @@ int pcop_occupancy_filter(pcop_ctx* c, const float* xyz, int layout, size_t n, i
     if (row_avg) HIPCHK(c, hipMemcpyAsync(row_avg, c->occ_rowavg, rows * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     if (grid) HIPCHK(c, hipMemcpyAsync(grid, c->occ_grid, cells, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    collect_times(c);
     if (totals[2]) { c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
     const uint32_t kept = totals[0];
     if (out_xyz && kept) {

@@ -2486,7 +2486,9 @@ struct OccParams {
     float x_min, x_max, y_min, y_max, z_min, z_max, block, dev;
     int32_t w, h;
 };
-constexpr int kOccLdsCells = 4096;   // grids up to this many cells are counted in LDS first
+constexpr int kOccLdsCells = 4096;   // grids up to this many cells are counted in LDS first ...
+constexpr int kOccPartials = 64;     // ... and flushed to one of this many partial grids (977 blocks adding into the same
+                                     // few hundred 64-bit words would serialise in L2); k_occ_finish adds the partials up
 
 // Smallest c >= 0 for which `lo + (c+1)*block < a` is false: the walk of od.cpp:139-142, whose float
 // expression is monotone in c, so an estimate plus a local walk in both directions lands on the same c.
@@ -2513,7 +2515,8 @@ __device__ __forceinline__ int occ_walk_down(float hi, float block, float b) {
 __global__ __launch_bounds__(kBlock) void k_occ_filter(OccParams p, const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ z, uint32_t n, float* __restrict__ ox,
                                                        float* __restrict__ oy, float* __restrict__ oz,
-                                                       unsigned long long* __restrict__ counts, uint32_t* __restrict__ tile_pub,
+                                                       unsigned long long* __restrict__ counts, uint32_t* __restrict__ partials,
+                                                       uint32_t* __restrict__ tile_pub,
                                                        uint32_t* __restrict__ totals) {   // totals: {kept, index errors, internal error}
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     __shared__ uint32_t s_cnt[kOccLdsCells];
@@ -2552,7 +2555,8 @@ __global__ __launch_bounds__(kBlock) void k_occ_filter(OccParams p, const float*
     if (threadIdx.x == 0) st_agent(tile_pub + blockIdx.x, tot + 1u);   // publish
     if (lds) {
         __syncthreads();
-        for (int i = threadIdx.x; i < size; i += kBlock) { const uint32_t v = s_cnt[i]; if (v) atomicAdd(counts + i, (unsigned long long)v); }
+        uint32_t* mine_part = partials + (size_t)(blockIdx.x % kOccPartials) * size;
+        for (int i = threadIdx.x; i < size; i += kBlock) { const uint32_t v = s_cnt[i]; if (v) atomicAdd(mine_part + i, v); }
     }
     const uint32_t nbad = block_sum(bad, s_w);
     if (threadIdx.x == 0 && nbad) atomicAdd(totals + 1, nbad);
@@ -2576,10 +2580,25 @@ __global__ __launch_bounds__(kBlock) void k_occ_filter(OccParams p, const float*
 }
 
 // one block per grid row: integer mean of the row (od.cpp:226-234), then the hole marks (od.cpp:241-266)
-__global__ __launch_bounds__(kBlock) void k_occ_finish(OccParams p, const unsigned long long* __restrict__ counts,
+__global__ __launch_bounds__(kBlock) void k_occ_finish(OccParams p, unsigned long long* __restrict__ counts,
+                                                       const uint32_t* __restrict__ partials,
                                                        long long* __restrict__ row_avg, signed char* __restrict__ grid) {
     __shared__ unsigned long long s_sum[kBlock];
+    __shared__ unsigned int s_cell[kOccLdsCells];
     const int r = blockIdx.x;
+    const int size = p.w * p.h;
+    if (size <= kOccLdsCells) {   // add up the partial grids of k_occ_filter: all threads, (partial, cell) pairs
+        for (int cidx = threadIdx.x; cidx < p.w; cidx += kBlock) s_cell[cidx] = 0u;
+        __syncthreads();
+        for (int e = threadIdx.x; e < p.w * kOccPartials; e += kBlock) {
+            const int q = e / p.w, cidx = e - q * p.w;
+            const uint32_t v = partials[(size_t)q * size + (size_t)r * p.w + cidx];
+            if (v) atomicAdd(&s_cell[cidx], v);
+        }
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < p.w; cidx += kBlock) counts[(size_t)r * p.w + cidx] += s_cell[cidx];
+        __syncthreads();
+    }
     unsigned long long s = 0;
     for (int cidx = threadIdx.x; cidx < p.w; cidx += kBlock) s += counts[(size_t)r * p.w + cidx];
     s_sum[threadIdx.x] = s;
