@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    os.environ.setdefault("LIBC_FATAL_STDERR_", "1")   # glibc's abort messages to stderr, not to /dev/tty
 
 
 @pytest.fixture(scope="session")
