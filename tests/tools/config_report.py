@@ -1,7 +1,7 @@
 """Every BASELINE config through the GPU path and the CPU oracle: parity + timings (for BASELINE.md §5)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa
 from oracle import oracle as O

@@ -1,12 +1,12 @@
 """GPU diagnostic: runs a few clouds through libpcop.so and prints where it diverges from the oracle.
-Usage on the GPU box: python tools/gpu_diag.py [config] [n]"""
+Usage on the GPU box: python tests/tools/gpu_diag.py [config] [n]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
 from pointcloud_obstacle_processing_amd import capi, synth  # noqa: E402

@@ -2,7 +2,7 @@
 HIP events, algorithmic bytes / time against the HBM peak, and the CPU restatement (1 core) beside it."""
 import os, sys, time, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa
 from oracle import oracle as O
