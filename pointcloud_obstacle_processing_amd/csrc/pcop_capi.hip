@@ -718,6 +718,7 @@ void pcop_destroy(pcop_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    hipDeviceSynchronize();   // nothing of this context may still be queued anywhere when its graphs and buffers go
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     for (void* p : c->dev_allocs) if (p) hipFree(p);
     for (Slot& sl : c->slots) if (sl.d_raw) hipFree(sl.d_raw);
