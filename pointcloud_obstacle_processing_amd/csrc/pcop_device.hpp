@@ -6,7 +6,7 @@
 //     k_frame_init            mailbox -> DevState
 //     k_minmax, k_voxel_setup pcl::getMinMax3D; min_b/div_b/divb_mul, the overflow rule, the plan
 //    streaming path (default):
-//     k_vox_mark, k_vmap_scan occupied grid cells -> voxel id = rank of the key, M
+//     k_vox_mark, k_occ_scan<0> occupied grid cells -> voxel id = rank of the key, M
 //     k_vid_hist / k_table_scan / k_vid_scatter   one stable 8-bit partition of {x,y,z,id} by bucket
 //     k_voxel_stream          per bucket: in-order float32 sums in LDS accumulators -> centroids
 //    sort path (fallback for grids or voxel counts the streaming path does not cover):
@@ -56,7 +56,7 @@ constexpr int kReduceBlocks = 256;               // grid of the min/max kernel: 
 constexpr int kCellBias = 1 << 20;               // cell coordinates are stored biased, 21 bits per axis
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint32_t kVmapCells = 1u << 26;       // streaming voxel path: largest voxel grid (cells) with an occupancy map
-constexpr uint32_t kVmapTile = 1024;            // occupancy words per block of k_vmap_scan
+constexpr uint32_t kVmapTile = 1024;            // occupancy words per block of k_occ_scan
 constexpr uint32_t kStreamBuckets = 256;        // buckets of the streaming voxel path (one 8-bit partition pass)
 constexpr uint32_t kVcapMin = 512, kVcapMax = 2048;   // voxels per bucket (LDS accumulators: 24 bytes per voxel)
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t 
         return;
     }
     if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass, maxbits, stream != 0u);
-    if (stream) {   // k_vmap_scan publishes its tile counts in vtile
+    if (stream) {   // k_occ_scan<0> publishes its tile counts in vtile
         uint32_t* __restrict__ vtile = F.vtile;
         for (uint32_t t = threadIdx.x; t < kVmapCells / 32u / kVmapTile; t += kBlock) vtile[t] = 0u;
         return;
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 // PCL sorts the points by voxel key and sums every run in order.  What that needs is (a) the
 // rank of every occupied voxel in key order and (b) for every voxel its points in index order.
 //   k_vox_mark     : key of every point; one byte per grid cell set for the occupied ones
-//   k_vmap_scan    : bytes -> occupancy bits + running popcount  =>  voxel id = rank in key order, M
+//   k_occ_scan<0>  : bytes -> occupancy bits + running popcount  =>  voxel id = rank in key order, M
 //   k_vid_hist / k_table_scan / k_vid_scatter : ONE stable 8-bit partition of {x,y,z,id} records
 //                    by bucket = id >> vshift (up to 256 buckets of up to vcap voxels)
 //   k_voxel_stream : one wave per bucket walks the bucket's records in order (= index order) and
