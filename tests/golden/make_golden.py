@@ -33,5 +33,26 @@ def main():
         print(cfg, "N", len(pts), "M", len(r["voxel_xyz"]), "K", len(r["offsets"]) - 1)
 
 
+def occupancy_case():
+    """The step before the path (od.cpp:175-269): one fixture with NaNs, points outside the box and on cell edges."""
+    rng = np.random.default_rng(7)
+    n = 6000
+    pts = np.stack([rng.uniform(-1.3, 1.3, n), rng.uniform(-0.7, 0.8, n), rng.uniform(-0.6, 0.1, n)], axis=1).astype(np.float32)
+    pts[::41, 1] = np.nan
+    pts[::53, 0] = np.nan
+    pts[::67, 2] = np.nan
+    k = np.arange(1, 8, dtype=np.float32)
+    edge = np.stack([np.float32(1.0) - k * np.float32(0.15), np.float32(-0.5) + k * np.float32(0.15), np.full(7, -0.1, dtype=np.float32)], axis=1)
+    pts = np.concatenate([pts, edge]).astype(np.float32)
+    lim = (-1.0, 1.0, -0.5, 0.6, -0.5, 0.0, 0.15, 0.5)          # the defaults of the reference's main(), z written as a usable range
+    p = O.occ_params(*lim)
+    r = O.occupancy(pts, p)
+    np.savez_compressed(os.path.join(HERE, "occupancy_seed7.npz"), points=pts, limits=np.array(lim, dtype=np.float32),
+                        grid_width=p.grid_width, grid_height=p.grid_height, kept=r["xyz"], counts=r["counts"],
+                        row_avg=r["row_avg"], grid=r["grid"], index_errors=r["index_errors"])
+    print("occupancy N", len(pts), "kept", r["n_out"], "grid", p.grid_width, "x", p.grid_height)
+
+
 if __name__ == "__main__":
     main()
+    occupancy_case()

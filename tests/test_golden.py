@@ -8,7 +8,8 @@ import pytest
 
 from pointcloud_obstacle_processing_amd import synth
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c*_seed*.npz")))
+OCC_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "occupancy_seed7.npz")
 
 
 def load(path):
@@ -45,4 +46,29 @@ def test_gpu_reproduces_golden(path):
     assert np.array_equal(r["offsets"], g["offsets"]) and np.array_equal(r["indices"], g["indices"])
     k = len(r["offsets"]) - 1
     assert np.max(np.abs(ctx.cluster_summaries(k) - g["xyzr"]), initial=0.0) <= 1e-5
+    ctx.close()
+
+
+def occ_same(r, g):
+    assert r["xyz"].tobytes() == g["kept"].tobytes()
+    assert np.array_equal(r["counts"], g["counts"]) and np.array_equal(r["row_avg"], g["row_avg"])
+    assert np.array_equal(r["grid"], g["grid"]) and r["index_errors"] == int(g["index_errors"])
+
+
+def test_oracle_reproduces_occupancy_golden(oracle):
+    g = np.load(OCC_GOLDEN, allow_pickle=False)
+    p = oracle.occ_params(*[float(v) for v in g["limits"]])
+    assert (p.grid_width, p.grid_height) == (int(g["grid_width"]), int(g["grid_height"]))
+    occ_same(oracle.occupancy(g["points"], p), g)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_occupancy_golden():
+    from pointcloud_obstacle_processing_amd import capi
+    g = np.load(OCC_GOLDEN, allow_pickle=False)
+    lim = [float(v) for v in g["limits"]]
+    ctx = capi.Context(len(g["points"]))
+    w, h = ctx.occupancy_grid_dims(lim[0], lim[1], lim[2], lim[3], lim[6])
+    assert (w, h) == (int(g["grid_width"]), int(g["grid_height"]))
+    occ_same(ctx.occupancy_filter(g["points"], capi.OccParams(*lim, w, h)), g)
     ctx.close()
