@@ -614,3 +614,25 @@ def test_crowded_cells_switch_to_the_hash_kernels(capi, oracle, monkeypatch):
         assert_same_clusters(got["offsets"], got["indices"], ref2["offsets"], ref2["indices"])
     assert c.debug_state().cpath == 1
     c.close()
+
+
+@pytest.mark.parametrize("vox,cell", [("stream", "hash"), ("sort", "grid")])
+def test_mixed_path_combinations(capi, oracle, monkeypatch, vox, cell):
+    """The `ctx` fixture covers stream+grid and sort+hash; the two paths are independent, so the other two
+    combinations must give the same answers too (also without the hipGraph, launches issued eagerly)."""
+    monkeypatch.setenv("PCOP_VOXEL_PATH", vox)
+    monkeypatch.setenv("PCOP_CELL_PATH", cell)
+    for no_graph in ("0", "1"):
+        monkeypatch.setenv("PCOP_NO_GRAPH", no_graph)
+        c = capi.Context(200_000, max_frames=2)
+        for cfg, n in (("C1", None), ("C3", 150_000)):
+            p = synth.params_of(cfg)
+            pts = synth.make_cloud(cfg, n=n, seed=17)
+            c.set_params(publish_clouds=1, **p)
+            ref = oracle.process_xyz(pts, **p)
+            got = c.process_xyz(pts)
+            st = c.debug_state()
+            assert st.vpath == (1 if vox == "stream" else 0) and st.cpath == (1 if cell == "grid" else 0)
+            assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+            assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+        c.close()
