@@ -97,6 +97,7 @@ struct pcop_ctx {
     bool use_graph = true;
     uint32_t cell_blocks = 2560;      // total blocks per launch of the wave-per-cell kernels (whole batch)
     uint32_t stride_blocks = 4096;    // total blocks per launch of the grid-strided point kernels
+    uint32_t flatten_blocks = 128;    // blocks per frame of k_cell_flatten (each wave walks one contiguous chunk of points)
     uint32_t debug_skip_union = 0;    // diagnostics: 1 = no union kernel, 2 = union scans but never fixes up
     // streaming voxel path (pcop_device.hpp): on unless PCOP_VOXEL_PATH=sort; a frame it does not fit
     // (grid > kVmapCells cells, or > 256 * kVcapMax voxels) is re-run on the sort path and the context stays there
@@ -295,7 +296,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
             k_cell_union<<<dim3(std::min(cell_blocks, std::max(1u, div_up(nb, 2 * kWavesPerBlock))), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_cell_union");
         }
-        k_cell_flatten<<<dim3(64, nf), kBlock, 0, s>>>(fr);
+        k_cell_flatten<<<dim3(c->flatten_blocks, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_cell_flatten");
         k_kept_apply<<<sg, kBlock, 0, s>>>(fr, c->npass_csr, (uint32_t)MAXB);
         mark(c, "k_kept_apply");
@@ -688,6 +689,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
     if (const char* e = getenv("PCOP_CELL_BLOCKS")) c->cell_blocks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_STRIDE_BLOCKS")) c->stride_blocks = (uint32_t)std::max(64, atoi(e));
+    if (const char* e = getenv("PCOP_FLATTEN_BLOCKS")) c->flatten_blocks = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("PCOP_DEBUG_SKIP_UNION")) c->debug_skip_union = (uint32_t)atoi(e);
     const size_t nbk = bucket_of(c, (uint32_t)max_points);           // launch sizes round up to this
     const size_t n = std::max<size_t>(max_points, nbk);

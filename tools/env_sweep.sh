@@ -7,7 +7,7 @@ for v in "$@"; do
 import json,sys
 d=json.load(open("gpurun_out/sw.json"))
 k=d["kernel_ms"]
-sel=["k_cell_union","k_cell_hook","k_cell_compress","k_cell_insert","k_cell_place","k_emit","k_cell_flatten"]
+sel=["k_voxel_stream","k_vid_scatter","k_vox_mark","k_vid_hist","k_cgrid_union","k_cgrid_hook","k_cell_flatten","k_emit"]
 print(sys.argv[1], round(d["value"],1), "lat", round(d["latency_ms_single_frame"],3), {s[2:]:k.get(s) for s in sel})
 PY
 done
