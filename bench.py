@@ -77,8 +77,8 @@ kernel_alg_bytes.voxel_passes = 3
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per context, processed in the same launches")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) in flight per GPU")
     ap.add_argument("--config", default="C3")
