@@ -186,6 +186,19 @@ int pcop_occupancy_filter(pcop_ctx* ctx, const float* xyz, int layout, size_t n,
  * HBM): build_initial_occupancy_grid_dataset -> downsample_cloud -> ... of cloud_cb (od.cpp:727-797). */
 int pcop_process_filtered(pcop_ctx* ctx, pcop_result* out);
 
+/* ---- between voxel grid and clustering in the real node: statistical outlier removal -------
+ * Replaces remove_statistical_outliers (od.cpp:316-340: pcl::StatisticalOutlierRemoval with setMeanK(mean_k),
+ * setStddevMulThresh(stddev_mul), called at od.cpp:751-754).  The GPU computes, for every point, the mean
+ * distance to its mean_k nearest neighbours (exact k-NN on a dense cell grid, float32 L2_Simple distances,
+ * square roots summed in double in ascending order); the global mean / standard deviation of those values is a
+ * sequential double sum in the reference and is formed on the host in the same order, as is the final
+ * `distance > threshold` selection.  xyz / layout as in pcop_voxel_downsample (host memory); out_xyz receives
+ * the kept points in input order and the same layout (room for n points).  distances (n floats) and threshold
+ * may be NULL.  1 <= mean_k <= 31; a cloud with fewer than mean_k + 1 points, or with a non-finite coordinate,
+ * is refused (PCOP_ERR_PARAM / PCOP_ERR_NONFINITE): the reference reads past its search result on the former. */
+int pcop_statistical_outlier_removal(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int mean_k, float stddev_mul,
+                                     float* out_xyz, size_t* n_out, float* distances, double* threshold);
+
 /* Device-side allocation helpers so a host program without its own HIP code
  * (e.g. a ctypes caller) can keep clouds resident in HBM. */
 int pcop_dev_alloc(pcop_ctx* ctx, size_t bytes, void** dev_ptr);

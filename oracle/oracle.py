@@ -19,7 +19,7 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle with g++ (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pcl_restatement.cpp", "occupancy_restatement.cpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("pcl_restatement.cpp", "occupancy_restatement.cpp", "sor_restatement.cpp")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpcop_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -58,6 +58,9 @@ def lib():
         L.pcop_oracle_occupancy.restype = C.c_int
         L.pcop_oracle_occupancy.argtypes = [fp, C.c_size_t, C.POINTER(OccParams), fp, C.POINTER(C.c_size_t),
                                             C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_byte), ip]
+        L.pcop_oracle_sor.restype = C.c_int
+        L.pcop_oracle_sor.argtypes = [fp, C.c_size_t, C.c_int, C.c_float, fp, C.POINTER(C.c_double), C.POINTER(C.c_uint8),
+                                      C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -208,3 +211,18 @@ def process_xyz(xyz, leaf, tol, min_cluster, max_cluster, is_dense=True, layout=
         raise ValueError("oracle process_xyz rc=%d" % rc)
     return dict(voxel_xyz=vox[: 3 * m.value].reshape(-1, 3).copy(), passthrough=bool(pt.value),
                 offsets=offsets[: k.value + 1].copy(), indices=indices[: offsets[k.value]].copy())
+
+
+def sor(xyz, mean_k, stddev_mul):
+    """StatisticalOutlierRemoval -> dict(distances float32[n], threshold, keep bool[n], xyz kept points)."""
+    pts = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    n = len(pts)
+    dist = np.zeros(max(n, 1), dtype=np.float32)
+    keep = np.zeros(max(n, 1), dtype=np.uint8)
+    thr, nk = C.c_double(0.0), C.c_size_t(0)
+    rc = lib().pcop_oracle_sor(_f(pts), n, int(mean_k), np.float32(stddev_mul), _f(dist), C.byref(thr),
+                               keep.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(nk))
+    if rc:
+        raise ValueError("pcop_oracle_sor: %d" % rc)
+    keep = keep[:n].astype(bool)
+    return dict(distances=dist[:n], threshold=thr.value, keep=keep, xyz=pts[keep])

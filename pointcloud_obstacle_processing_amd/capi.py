@@ -22,6 +22,7 @@ EXPORTS = [
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
     "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
     "pcop_cluster_summaries_frame", "pcop_occupancy_grid_dims", "pcop_occupancy_filter", "pcop_process_filtered",
+    "pcop_statistical_outlier_removal",
 ]
 
 
@@ -107,6 +108,9 @@ def load_library():
     L.pcop_occupancy_filter.restype = C.c_int
     L.pcop_occupancy_filter.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.POINTER(OccParams), C.c_void_p,
                                         C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.pcop_statistical_outlier_removal.restype = C.c_int
+    L.pcop_statistical_outlier_removal.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_float, C.c_void_p,
+                                                   C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_double)]
     L.pcop_process_filtered.restype = C.c_int
     L.pcop_process_filtered.argtypes = [vp, C.POINTER(Result)]
     L.pcop_destroy.restype = None
@@ -282,6 +286,16 @@ class Context:
         self._chk(self.lib.pcop_occupancy_filter(self.h, C.c_void_p(dev_ptr), layout, int(n), MEM_DEVICE, C.byref(occ),
                                                  None, C.byref(n_out), None, None, None, C.byref(bad)))
         return n_out.value, bad.value
+
+    def statistical_outlier_removal(self, xyz, mean_k, stddev_mul, layout=LAYOUT_AOS12):
+        """remove_statistical_outliers -> dict(xyz kept points, distances float32[n], threshold)."""
+        flat, n = pack_points(xyz, layout)
+        out = np.zeros_like(flat) if n else np.zeros(3, dtype=np.float32)
+        dist = np.zeros(max(n, 1), dtype=np.float32)
+        n_out, thr = C.c_size_t(0), C.c_double(0.0)
+        self._chk(self.lib.pcop_statistical_outlier_removal(self.h, flat.ctypes.data, layout, n, int(mean_k), C.c_float(stddev_mul),
+                                                            out.ctypes.data, C.byref(n_out), dist.ctypes.data, C.byref(thr)))
+        return dict(xyz=unpack_points(out, layout, n_out.value, n), distances=dist[:n], threshold=thr.value)
 
     def process_filtered(self):
         r = Result()

@@ -984,6 +984,109 @@ int pcop_process_filtered(pcop_ctx* c, pcop_result* out) {
     return finish_batch(c, out, out ? 1 : 0);
 }
 
+// One eager pass of a cluster-only frame up to the point where the requested stage has run; k_emit at the end puts
+// the DevState into pinned host memory and hands the borrowed per-cell counters back clean.
+static int sor_pass(pcop_ctx* c, Slot& sl, double inv_cell, bool with_knn, uint32_t mean_k, double edge) {
+    FrameArgs& a = *sl.h_args;
+    std::memset(&a, 0, sizeof(a));
+    a.n = sl.n; a.is_dense = 1u; a.kind = kFrameClusterOnly; a.trivial = 0u;
+    a.inv_leaf = 1.0f; a.r2 = 1.0f; a.inv_cell = inv_cell;
+    a.min_cluster = 1u; a.max_cluster = 0xFFFFFFFFu;
+    a.out_layout = (uint32_t)PCOP_LAYOUT_AOS12; a.out_soa_stride = sl.n;
+    a.cell_grid = 1u; a.vcap = c->vcap;
+    a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
+    Frame* fr = c->d_frames;
+    hipStream_t s = c->stream;
+    const uint32_t n = sl.n;
+    const dim3 tg(stride_grid(n), 1), sg(std::max(1u, div_up(n, kScanTile)), 1);
+    c->ev_used = 0;
+    mark(c, "start");
+    k_frame_init<<<dim3(1, 1), 64, 0, s>>>(fr);
+    k_minmax<<<dim3(kReduceBlocks, 1), kBlock, 0, s>>>(fr);
+    k_voxel_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr, kReduceBlocks, 1u, (uint32_t)kNarrowBits, 0u);
+    mark(c, "bounds");
+    if (with_knn) {
+        k_cgrid_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr);
+        k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
+        k_occ_scan<1><<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
+        k_cell_count<<<tg, kBlock, 0, s>>>(fr);
+        k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
+        k_cell_place<<<tg, kBlock, 0, s>>>(fr);
+        mark(c, "cell_grid");
+        k_knn_mean<<<tg, kBlock, 0, s>>>(fr, mean_k, edge);
+        mark(c, "k_knn_mean");
+    }
+    k_emit<<<tg, kBlock, 0, s>>>(fr, 1u);
+    mark(c, "k_emit");
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    collect_times(c);
+    return PCOP_OK;
+}
+
+int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, size_t n, int mean_k, float stddev_mul,
+                                     float* out_xyz, size_t* n_out, float* distances, double* threshold) {
+    if (!c || !n_out || (!out_xyz && n) || (!xyz && n)) return PCOP_ERR_ARG;
+    int rc = busy(c);
+    if (rc) return rc;
+    if (mean_k < 1 || mean_k + 1 > kKnnMax) { c->err = "mean_k must be 1..31"; return PCOP_ERR_PARAM; }
+    if (!std::isfinite(stddev_mul)) { c->err = "stddev multiplier must be finite"; return PCOP_ERR_PARAM; }
+    if (n < (size_t)mean_k + 1) { c->err = "fewer points than mean_k + 1: the reference reads past its k-NN result"; return PCOP_ERR_PARAM; }
+    if (!c->cell_grid) { c->err = "statistical outlier removal needs the dense cell grid (context created with PCOP_CELL_PATH=hash)"; return PCOP_ERR_STATE; }
+    if ((rc = set_device(c))) return rc;
+    Slot& sl = c->slots[0];
+    if ((rc = stage_input(c, sl, xyz, layout, n, PCOP_MEM_HOST))) return rc;
+    // bounds (and the non-finite check) first: the cell edge depends on the density
+    if ((rc = sor_pass(c, sl, 1.0, false, 0u, 1.0))) return rc;
+    if (sl.h_state->err & kErrNonFinite) { c->err = "non-finite coordinates"; return PCOP_ERR_NONFINITE; }
+    double ext[3], longest = 0.0;
+    for (int a = 0; a < 3; ++a) { ext[a] = std::max((double)sl.h_state->vmax[a] - (double)sl.h_state->vmin[a], 1e-6); longest = std::max(longest, ext[a]); }
+    // about four points per cell if the cloud filled its box; surfaces end up sparser, the ring search does not care
+    double edge = std::cbrt(ext[0] * ext[1] * ext[2] * 4.0 / (double)n);
+    edge = std::max(edge, longest / 2000.0);
+    auto cells_of = [&](double e) {
+        double t = 1.0;
+        for (int a = 0; a < 3; ++a) t *= std::floor(ext[a] / e) + 1.0 + 2.0 * kCellMargin + (a == 0 ? 32.0 : 0.0);
+        return t;
+    };
+    while (cells_of(edge) > 0.5 * (double)kCmapCells) edge *= 1.26;
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = sor_pass(c, sl, 1.0 / edge, true, (uint32_t)mean_k, edge))) return rc;
+        const uint32_t e = sl.h_state->err;
+        if (e & kErrReplanCpath) {
+            if (attempt >= 8) { scrub_flags(c); c->err = "no cell grid fits this cloud"; return PCOP_ERR_STATE; }
+            edge *= 2.0;
+            continue;
+        }
+        if (e) { scrub_flags(c); c->err = "internal error in the k-NN pass"; return PCOP_ERR_STATE; }
+        break;
+    }
+    std::vector<float> dist(n);
+    HIPCHK(c, hipMemcpy(dist.data(), sl.f.cen_x.get(), n * sizeof(float), hipMemcpyDeviceToHost));
+    // StatisticalOutlierRemoval::applyFilterIndices, second half: sequential double sums in index order
+    double sum = 0.0, sq_sum = 0.0;
+    for (size_t i = 0; i < n; ++i) { sum += dist[i]; sq_sum += dist[i] * dist[i]; }
+    const double valid = (double)n;
+    const double mean = sum / valid;
+    const double variance = (sq_sum - sum * sum / valid) / (valid - 1.0);
+    const double thr = mean + (double)stddev_mul * std::sqrt(variance);
+    size_t kept = 0;
+    const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
+    for (size_t i = 0; i < n; ++i) {
+        if ((double)dist[i] > thr) continue;   // the outliers
+        if (layout == PCOP_LAYOUT_SOA) {
+            for (int a = 0; a < 3; ++a) out_xyz[(size_t)a * n + kept] = xyz[(size_t)a * n + i];
+        } else {
+            for (size_t a = 0; a < fl; ++a) out_xyz[fl * kept + a] = xyz[fl * i + a];
+        }
+        ++kept;
+    }
+    *n_out = kept;
+    if (distances) std::memcpy(distances, dist.data(), n * sizeof(float));
+    if (threshold) *threshold = thr;
+    return PCOP_OK;
+}
+
 int pcop_cluster_summaries_frame(pcop_ctx* c, int frame, float* xyzr, int32_t cap_clusters) {
     if (!c || (!xyzr && cap_clusters) || frame < 0 || (uint32_t)frame >= c->max_frames) return PCOP_ERR_ARG;
     Slot& sl = c->slots[frame];

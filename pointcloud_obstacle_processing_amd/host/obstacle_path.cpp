@@ -115,6 +115,29 @@ void build_initial_occupancy_grid_dataset(int grid_size, int grid_height, int gr
     if (bad) fprintf(stderr, "OUT OF BOUNDS INDEX ACCESS (%d points)\n", bad);   // ROS_ERROR at od.cpp:206
 }
 
+void remove_statistical_outliers(PointCloudXYZ::Ptr& input_cloud, PointCloudXYZ& output_cloud, float meanK, float stdDevThres,
+                                 Publisher<PointCloud2>& pub, bool publish) {
+    const size_t n = input_cloud->points.size();
+    pcop_ctx* c = default_context(n);
+    std::vector<PointXYZ> kept(n ? n : 1);
+    size_t n_out = 0;
+    check(c, pcop_statistical_outlier_removal(c, n ? &input_cloud->points[0].x : nullptr, PCOP_LAYOUT_AOS16, n, (int)meanK,   // sor2.setMeanK(meanK)
+                                              stdDevThres, &kept[0].x, &n_out, nullptr, nullptr),                              // sor2.filter(output_cloud)
+          "pcop_statistical_outlier_removal");
+    kept.resize(n_out);
+    output_cloud.points.swap(kept);
+    output_cloud.header = input_cloud->header;
+    output_cloud.width = (uint32_t)n_out;
+    output_cloud.height = 1;
+    output_cloud.is_dense = true;
+    if (publish) {                                       // od.cpp:331-338
+        PointCloud2 msg;
+        to_pointcloud2(output_cloud, &msg);
+        msg.header.frame_id = "world";
+        pub.publish(msg);
+    }
+}
+
 ObstacleNode::ObstacleNode(const NodeParams& prm, size_t max_points, int device) : params(prm) {
     downsample_publisher.topic = "voxel_grid"; downsample_publisher.queue_size = 1;
     centroid_publisher.topic = "centroids"; centroid_publisher.queue_size = 1;

@@ -6,6 +6,7 @@
 //   downsample_cloud            od.cpp:271-296     VoxelGrid + optional publish on "voxel_grid"
 //   extract_euclidian_clusters  od.cpp:430-455     EuclideanClusterExtraction
 //   build_initial_occupancy_grid_dataset  od.cpp:175-269   bounds filter + occupancy binning (the step before)
+//   remove_statistical_outliers  od.cpp:316-340    StatisticalOutlierRemoval + optional publish (between the two)
 //   ObstacleNode::cloud_cb      od.cpp:674-928     the part of the callback the north star names:
 //                                                  PointCloud2 in -> voxel grid -> clusters ->
 //                                                  "voxel_grid", "centroids", "euc_clusters" out
@@ -44,6 +45,11 @@ void build_initial_occupancy_grid_dataset(int grid_size, int grid_height, int gr
                                           long long* point_count_array, long long* row_point_averages,
                                           const PointCloudXYZ& input_cloud, PointCloudXYZ& output_cloud,
                                           float block_size, float dev_percent);
+
+// od.cpp:316-340.  Same signature with the stand-in types (meanK arrives as a float there too and is narrowed
+// by setMeanK(int)); publishes on `pub` with frame_id "world" when asked (od.cpp:331-338).
+void remove_statistical_outliers(PointCloudXYZ::Ptr& input_cloud, PointCloudXYZ& output_cloud, float meanK, float stdDevThres,
+                                 Publisher<PointCloud2>& pub, bool publish);
 
 // The node surface of the path: same topic names, queue sizes and parameter keys as od.cpp:930-1015.
 class ObstacleNode {

@@ -2,13 +2,15 @@
 // serialized sensor_msgs/PointCloud2, runs the path on the GPU and writes what the node would
 // publish on "voxel_grid", "centroids" and "euc_clusters", plus the cluster indices.
 //
-//   pcop_node --params params.yaml --cloud in.pc2 --out outdir [--device 0] [--stage-api] [--occupancy]
+//   pcop_node --params params.yaml --cloud in.pc2 --out outdir [--device 0] [--stage-api] [--occupancy] [--sor]
 //
 // --stage-api runs the two free functions (downsample_cloud, extract_euclidian_clusters) the way
 // cloud_cb calls them (od.cpp:740, od.cpp:791-797) instead of the fused frame entry.
 // --occupancy (with --stage-api) runs build_initial_occupancy_grid_dataset first, as cloud_cb does (od.cpp:725-731),
 // with the limits, block_size and dev_percent of the yaml tree, and writes occupancy.txt (grid size, kept points,
 // counts, row means, hole marks).
+// --sor (with --stage-api) runs remove_statistical_outliers between the voxel grid and the clustering, as cloud_cb
+// does (od.cpp:751-754), with statistical_outlier_meanK / _stdDevThres of the yaml tree, and writes sor.pc2.
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -33,7 +35,7 @@ static void write_indices(const std::string& path, const std::vector<PointIndice
 int main(int argc, char** argv) {
     std::string params_path, cloud_path, out_dir = ".";
     int device = 0;
-    bool stage_api = false, occupancy = false;
+    bool stage_api = false, occupancy = false, sor = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--params" && i + 1 < argc) params_path = argv[++i];
@@ -42,6 +44,7 @@ int main(int argc, char** argv) {
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (a == "--stage-api") stage_api = true;
         else if (a == "--occupancy") occupancy = true;
+        else if (a == "--sor") sor = true;
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (params_path.empty() || cloud_path.empty()) {
@@ -82,6 +85,15 @@ int main(int argc, char** argv) {
             pub.topic = "voxel_grid";
             PointCloudXYZ::Ptr vox(new PointCloudXYZ);
             downsample_cloud(in, *vox, prm.downsample_size, pub, prm.publish_point_clouds);          // od.cpp:740
+            if (sor) {                                                                                // od.cpp:751-754
+                PointCloudXYZ::Ptr filtered(new PointCloudXYZ);
+                Publisher<PointCloud2> sor_pub;
+                sor_pub.topic = "statistical_outliers";
+                remove_statistical_outliers(vox, *filtered, (float)prm.statistical_outlier_meanK, prm.statistical_outlier_stdDevThres,
+                                            sor_pub, true);
+                if (!write_pointcloud2_file(out_dir + "/sor.pc2", sor_pub.last, &err)) throw std::runtime_error(err);
+                vox = filtered;
+            }
             KdTreeHandle::Ptr tree(new KdTreeHandle);
             tree->setInputCloud(vox);                                                                 // od.cpp:791-792
             std::vector<PointIndices> clusters;

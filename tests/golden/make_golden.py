@@ -53,6 +53,17 @@ def occupancy_case():
     print("occupancy N", len(pts), "kept", r["n_out"], "grid", p.grid_width, "x", p.grid_height)
 
 
+def sor_case():
+    """Statistical outlier removal (od.cpp:316-340) on a small voxel cloud, the node's meanK 15."""
+    pts = synth.make_cloud("C3", n=40000, seed=9)
+    vox, _ = O.voxel_downsample(pts, 0.05)
+    r = O.sor(vox, 15, 1.0)
+    np.savez_compressed(os.path.join(HERE, "sor_seed9.npz"), points=vox, mean_k=15, stddev_mul=np.float32(1.0),
+                        distances=r["distances"], threshold=r["threshold"], kept=r["xyz"])
+    print("sor N", len(vox), "kept", len(r["xyz"]))
+
+
 if __name__ == "__main__":
     main()
     occupancy_case()
+    sor_case()

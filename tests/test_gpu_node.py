@@ -92,3 +92,31 @@ def test_node_harness_occupancy_then_chain(oracle, tmp_path):
     assert len(clusters) == len(want["offsets"]) - 1
     for c, idx in enumerate(clusters):
         assert np.array_equal(idx, want["indices"][want["offsets"][c]:want["offsets"][c + 1]])
+
+
+def test_node_harness_sor_between_voxel_grid_and_clusters(oracle, tmp_path):
+    """--sor: remove_statistical_outliers (host mirror) between downsample_cloud and extract_euclidian_clusters, as
+    cloud_cb runs them (od.cpp:740-797); meanK and the stddev multiplier come from the yaml tree."""
+    exe = os.path.join(HOST, "pcop_node")
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    pts = synth.make_cloud("C1")
+    cloud = str(tmp_path / "c1.pc2")
+    pc2io.write_pointcloud2(cloud, pts, point_step=32, offsets=(0, 4, 8), width=100, height=100)
+    yaml_path = str(tmp_path / "params.yaml")
+    with open(yaml_path, "w") as f:
+        f.write("pointcloud_obstacle_processing:\n        obstacle_detection:\n                downsample_size: 0.05\n"
+                "                statistical_outlier_meanK: 15\n                statistical_outlier_stdDevThres: 0.8\n"
+                "                euc_cluster_tolerance: 0.1\n                euc_min_cluster_size: 5\n                euc_max_cluster_size: 20000\n")
+    out = subprocess.run([exe, "--params", yaml_path, "--cloud", cloud, "--out", str(tmp_path), "--stage-api", "--sor"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    vox, _ = oracle.voxel_downsample(pts, 0.05)
+    ref = oracle.sor(vox, 15, np.float32(0.8))
+    got = pc2io.read_pointcloud2(str(tmp_path / "sor.pc2"))
+    assert got["frame_id"] == "world" and got["xyz"].tobytes() == ref["xyz"].tobytes()
+    assert 0 < len(ref["xyz"]) < len(vox)
+    want_off, want_idx = oracle.euclidean_clusters(ref["xyz"], 0.1, 5, 20000)
+    clusters = read_indices(str(tmp_path / "cluster_indices.txt"))
+    assert len(clusters) == len(want_off) - 1
+    for c, idx in enumerate(clusters):
+        assert np.array_equal(idx, want_idx[want_off[c]:want_off[c + 1]])
