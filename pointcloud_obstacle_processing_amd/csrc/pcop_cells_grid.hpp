@@ -1,0 +1,360 @@
+// pcop_cells_grid.hpp - cells on a dense grid (default): occupancy bits -> cell ids, hook / union with lane = cell.
+// Part of pcop_device.hpp (included from there, in this order; not a stand-alone header).
+#pragma once
+
+namespace pcop {
+
+// ------------------------------------------------------------------------------------------
+// Dense cell grid (default; the hash table of pcop_cells_hash.hpp is the fallback for grids beyond kCmapCells).
+// Same cells (edge tol/1.99), same predicate, same union-find; only the way a neighbour cell is
+// found differs.  The bounding box of the cloud is known, so the cells form a dense 3-D array
+// with an occupancy bit each (x fastest, rows padded to 32 bits, kCellMargin empty cells all
+// round) and cell id = rank of the bit = occupied cells before it:
+//   * the neighbour at (dx,dy,dz) is the bit at a constant offset: no probing, no bounds checks;
+//   * the 5 (or 3) x-neighbours of a row sit in one or two 32-bit words, and their ids are
+//     consecutive, so one 8-byte load resolves a whole row of the stencil;
+//   * ids follow the grid, so cells that are neighbours in space are neighbours in every
+//     per-cell array and the lanes of a wave (64 consecutive cells) touch the same cache lines.
+//   k_cgrid_setup   grid origin / size from the bounding box (margins added), or "replan"
+//   k_cell_mark     grid position of every point; one byte per occupied cell
+//   k_occ_scan<1>   bytes -> occupancy bits + running popcount => cell ids, n_cells
+//   k_cell_count    points per cell, rank inside the cell, smallest point index (= priority)
+//   k_cell_starts   exclusive scan of the counts; per-cell metadata; union-find init
+//   k_cell_place    (shared with the hash path) records sorted by cell
+//   k_cgrid_hook / k_cell_compress / k_cgrid_union   components, lane = cell
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cgrid_off(const DevState* st) { return cluster_stage_off(st) || !st->cpath; }
+
+__global__ __launch_bounds__(kBlock) void k_cgrid_setup(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    if (cluster_stage_off(st) || !st->cgrid_req) return;
+    uint32_t* __restrict__ ctile = F.ctile; uint32_t* __restrict__ tile_pub = F.tile_a;
+    for (uint32_t t = threadIdx.x; t < kCmapCells / 32u / kVmapTile; t += kBlock) ctile[t] = 0u;
+    const uint32_t ntiles = (st->c_n + kScanTile - 1) / kScanTile;   // k_cell_starts publishes here
+    for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock) tile_pub[t] = 0u;
+    if (threadIdx.x != 0) return;
+    st->n_cells = 0;
+    if (st->c_n == 0) { st->cpath = 1u; st->cmap_words = 0u; return; }
+    const double ig = st->inv_cell;
+    long long dim[3];
+    for (int a = 0; a < 3; ++a) {
+        const double lo = floor((double)st->vmin[a] * ig), hi = floor((double)st->vmax[a] * ig);
+        if (!(fabs(lo) < 1e9 && fabs(hi) < 1e9)) { atomicOr(&st->err, (uint32_t)kErrReplanCpath); return; }
+        st->c0[a] = (int32_t)lo - kCellMargin;
+        dim[a] = (long long)hi - (long long)lo + 1 + 2 * kCellMargin;
+    }
+    const long long rowbits = (dim[0] + 31) / 32 * 32;
+    const long long plane = rowbits * dim[1], total = plane * dim[2];
+    if (dim[0] > (1 << 24) || dim[1] > (1 << 24) || dim[2] > (1 << 24) || plane > (long long)kCmapCells || total > (long long)kCmapCells) {
+        atomicOr(&st->err, (uint32_t)kErrReplanCpath);
+        return;
+    }
+    for (int a = 0; a < 3; ++a) st->c_dim[a] = (uint32_t)dim[a];
+    st->c_rowbits = (uint32_t)rowbits; st->c_plane = (uint32_t)plane;
+    st->cmap_words = (uint32_t)(total / 32);
+    st->cpath = 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const float* __restrict__ cen_x = F.cen_x; const float* __restrict__ cen_y = F.cen_y; const float* __restrict__ cen_z = F.cen_z;
+    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;   // pt_root is free until k_cell_flatten
+    if (cgrid_off(st)) return;
+    const bool from_in = st->c_from_input != 0;
+    const float* __restrict__ x = from_in ? st->src_x.get() : cen_x;
+    const float* __restrict__ y = from_in ? st->src_y.get() : cen_y;
+    const float* __restrict__ z = from_in ? st->src_z.get() : cen_z;
+    const uint32_t n = st->c_n;
+    const double ig = st->inv_cell;
+    const long long c0x = st->c0[0], c0y = st->c0[1], c0z = st->c0[2];
+    const long long d0 = st->c_dim[0], d1 = st->c_dim[1], d2 = st->c_dim[2];
+    const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float px = x[i], py = y[i], pz = z[i];
+        uint32_t pos = 0;
+        if (!finite3(px, py, pz)) {   // radiusSearch on a non-finite point is undefined in PCL
+            atomicOr(&st->err, (uint32_t)kErrNonFinite);
+        } else {
+            const long long gx = (long long)floor((double)px * ig) - c0x, gy = (long long)floor((double)py * ig) - c0y,
+                            gz = (long long)floor((double)pz * ig) - c0z;
+            // two free cells on every side keep the whole 5x5x5 stencil inside the array
+            if (gx < 2 || gy < 2 || gz < 2 || gx > d0 - 3 || gy > d1 - 3 || gz > d2 - 3) {
+                atomicOr(&st->err, (uint32_t)kErrReplanCpath);
+            } else {
+                pos = (uint32_t)gz * plane + (uint32_t)gy * rowbits + (uint32_t)gx;
+                cflag[pos] = 1;
+            }
+        }
+        pt_pos[i] = pos;
+    }
+}
+
+// id of the occupied cell at grid position pos
+__device__ __forceinline__ uint32_t cell_id_at(const uint2* __restrict__ cmap, uint32_t pos) {
+    const uint2 e = cmap[pos >> 5];
+    return e.y + __popc(e.x & ((1u << (pos & 31u)) - 1u));
+}
+
+__global__ __launch_bounds__(kBlock) void k_cell_count(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint2* __restrict__ cmap = F.cmap; const uint32_t* __restrict__ pt_pos = F.pt_root;
+    uint32_t* __restrict__ ccount = F.hcount; uint32_t* __restrict__ cmin = F.hmin;
+    uint32_t* __restrict__ pt_slot = F.pt_slot; uint32_t* __restrict__ pt_rank = F.pt_rank;
+    uint32_t* __restrict__ cell_pos = F.cell_list;
+    if (cgrid_off(st)) return;
+    const uint32_t n = st->c_n;
+    const uint32_t lane = lane_id();
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    // ccount is all zero and cmin all ones on entry: k_emit leaves the borrowed arrays that way
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += nthreads) {
+        const uint32_t i = base + lane;
+        const bool valid = i < n;
+        uint32_t cid = 0xFFFFFFFFu, pos = 0;
+        if (valid) { pos = pt_pos[i]; cid = cell_id_at(cmap, pos); }
+        // runs of consecutive points in one cell (frequent: the points arrive in voxel order) share one set of atomics
+        const uint32_t cprev = __shfl_up(cid, 1, kWave);
+        const bool leader = valid && (lane == 0 || cid != cprev);
+        const uint64_t leaders = __ballot(leader);
+        const uint64_t breaks = __ballot(leader || !valid);
+        uint32_t rank0 = 0;
+        if (leader) {
+            const uint64_t later = lane == 63 ? 0ull : (breaks >> (lane + 1));
+            const uint32_t runlen = later ? (uint32_t)__ffsll((unsigned long long)later) : (uint32_t)(kWave - lane);
+            rank0 = atomicAdd(ccount + cid, runlen);
+            atomicMin(cmin + cid, i);
+            cell_pos[cid] = pos;   // every writer of a cell stores the same value
+        }
+        const uint64_t le = leaders & (lanemask_lt() | (1ull << lane));
+        const int ll = le ? 63 - __clzll((unsigned long long)le) : 0;
+        const uint32_t r = __shfl(rank0, ll, kWave);
+        if (valid) { pt_slot[i] = cid; pt_rank[i] = r + (lane - (uint32_t)ll); }
+    }
+}
+
+// cell_start = exclusive scan of the counts (tiles publish / add up the lower tiles); per-cell
+// metadata {first record, points, smallest point index, grid position}; union-find init
+__global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames) {
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const uint32_t* __restrict__ ccount = F.hcount; const uint32_t* __restrict__ cmin = F.hmin;
+    const uint32_t* __restrict__ cell_pos = F.cell_list;
+    uint32_t* __restrict__ tile_pub = F.tile_a;
+    uint32_t* __restrict__ cell_start = F.cell_start; uint32_t* __restrict__ parent = F.parent;
+    uint32_t* __restrict__ comp_size = F.comp_size; uint32_t* __restrict__ comp_rank = F.comp_rank;
+    uint4* __restrict__ slot_meta = F.slot_meta;
+    if (cgrid_off(st)) return;
+    const uint32_t nc = st->n_cells;
+    const uint32_t base = blockIdx.x * kScanTile;
+    if (base >= nc) return;
+    uint32_t v[kScanItems];
+    uint32_t c = 0;
+    const uint32_t s0 = base + threadIdx.x * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { v[k] = s0 + k < nc ? ccount[s0 + k] : 0u; c += v[k]; }
+    uint32_t tot;
+    uint32_t run = block_excl_scan(c, s_w, &tot);
+    if (threadIdx.x == 0) st_agent(tile_pub + blockIdx.x, tot + 1u);
+    uint32_t mine = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
+        uint32_t q = ld_agent(tile_pub + t), spins = 0;
+        while (q == 0u) {
+            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); q = 1u; break; }
+            __builtin_amdgcn_s_sleep(2);
+            q = ld_agent(tile_pub + t);
+        }
+        mine += q - 1u;
+    }
+    __syncthreads();
+    run += block_sum(mine, s_w);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t id = s0 + k;
+        if (id < nc) {
+            cell_start[id] = run;
+            parent[id] = id; comp_size[id] = 0u; comp_rank[id] = 0xFFFFFFFFu;
+            slot_meta[id] = make_uint4(run, v[k], cmin[id], cell_pos[id]);
+        }
+        run += v[k];
+    }
+}
+
+// One lane walks the cross pairs of two cells: is some pair within the radius?
+__device__ __forceinline__ bool lane_cells_hit(const float4* __restrict__ rec, uint32_t a0, uint32_t an, uint32_t b0,
+                                               uint32_t bn, float r2) {
+    for (uint32_t ia = 0; ia < an; ++ia) {
+        const float4 pa = rec[a0 + ia];
+        for (uint32_t ib = 0; ib < bn; ++ib)
+            if (l2_simple(pa, rec[b0 + ib]) < r2) return true;
+    }
+    return false;
+}
+
+// Occupied cells among `width` (<= 5) consecutive grid positions starting at `pos`: bit k of the result
+// is position pos + k; *id0 = id of the first occupied one, the others follow consecutively.
+__device__ __forceinline__ uint32_t row_window(const uint2* __restrict__ cmap, uint32_t pos, uint32_t width, uint32_t* id0) {
+    const uint32_t w = pos >> 5, sh = pos & 31u;
+    const uint2 e0 = cmap[w];
+    uint32_t bits = e0.x >> sh;
+    uint32_t before = e0.y + __popc(e0.x & ((1u << sh) - 1u));   // occupied cells before pos
+    if (sh + width > 32u) bits |= cmap[w + 1].x << (32u - sh);   // sh > 0 here
+    *id0 = before;
+    return bits & ((1u << width) - 1u);
+}
+
+// parent[c] = the adjacent cell of smallest priority among the 13 backward cells of the 3x3x3
+// neighbourhood (5 rows), if it has a smaller priority than c.  No atomics: a forest.
+// Two rounds of independent loads (row windows, then the metadata of the 13 neighbour slots; a slot
+// without a neighbour re-reads the cell's own), then pair tests only against cells of smaller priority.
+__global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = F.rec_a;
+    const uint2* __restrict__ cmap = F.cmap;
+    const uint4* __restrict__ slot_meta = F.slot_meta;
+    uint32_t* __restrict__ parent = F.parent;
+    if (cgrid_off(st)) return;
+    const uint32_t nc = st->n_cells;
+    const float r2 = st->r2;
+    const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+        const uint4 ma = slot_meta[c];   // {first record, points, priority, grid position}
+        // rows: (dy,dz) = (-1,-1) (0,-1) (1,-1) (-1,0) with dx = -1..1, and the cell's own row with dx = -1
+        uint2 e0[5];
+        uint32_t e1[5], sh[5], wd[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            uint32_t pos;
+            if (r < 3) { pos = ma.w - plane + (uint32_t)(r - 1) * rowbits - 1u; wd[r] = 3u; }
+            else if (r == 3) { pos = ma.w - rowbits - 1u; wd[r] = 3u; }
+            else { pos = ma.w - 1u; wd[r] = 1u; }
+            sh[r] = pos & 31u;
+            e0[r] = cmap[pos >> 5];
+            e1[r] = cmap[(pos >> 5) + 1u].x;
+        }
+        uint4 mb[13];
+        uint32_t nid[13];
+        int slot = 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            uint32_t bits = e0[r].x >> sh[r];
+            if (sh[r] + wd[r] > 32u) bits |= (e1[r] << 1) << (31u - sh[r]);
+            const uint32_t cnt = __popc(bits & ((1u << wd[r]) - 1u));
+            const uint32_t id0 = e0[r].y + __popc(e0[r].x & ((1u << sh[r]) - 1u));
+            const int w = r == 4 ? 1 : 3;
+#pragma unroll
+            for (int k = 0; k < w; ++k) {
+                nid[slot] = (uint32_t)k < cnt ? id0 + (uint32_t)k : c;   // the ids of a row's occupied cells are consecutive
+                mb[slot] = slot_meta[nid[slot]];
+                ++slot;
+            }
+        }
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int q = 0; q < 13; ++q) {
+            const unsigned long long key = ((unsigned long long)mb[q].z << 32) | nid[q];
+            if (mb[q].z < ma.z && key < best && lane_cells_hit(rec, ma.x, ma.y, mb[q].x, mb[q].y, r2)) best = key;
+        }
+        if (best != ~0ull) parent[c] = (uint32_t)best;
+    }
+}
+
+// Forward half of the 5x5x5 stencil (13 rows, 62 cells).  Neighbours whose parent word equals the
+// cell's are in its set already, and after hook + compress that is nearly all of them, so the common
+// case is made of two rounds of independent loads: the 13 row windows, then the parent words of
+// every occupied neighbour.  Only a cell that sees a different parent word walks its rows again and
+// looks properly (roots, pair test, union by CAS).
+__device__ __forceinline__ void union_row(int r, uint32_t at, uint32_t rowbits, uint32_t plane, uint32_t* pos, uint32_t* width) {
+    // rows: own row dx = 1..2; (dy = 1..2, dz = 0) and (dy = -2..2, dz = 1..2) with dx = -2..2
+    if (r == 0) { *pos = at + 1u; *width = 2u; }
+    else if (r < 3) { *pos = at + (uint32_t)r * rowbits - 2u; *width = 5u; }
+    else { const int q = r - 3; *pos = at + (uint32_t)(1 + q / 5) * plane + (uint32_t)(q % 5 - 2) * rowbits - 2u; *width = 5u; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = F.rec_a;
+    const uint2* __restrict__ cmap = F.cmap;
+    const uint4* __restrict__ slot_meta = F.slot_meta;
+    const uint32_t* __restrict__ prio = F.hmin;
+    uint32_t* __restrict__ parent = F.parent;
+    if (cgrid_off(st) || st->debug_skip_union == 1u) return;
+    const bool scan_only = st->debug_skip_union == 2u;
+    const uint32_t nc = st->n_cells;
+    const float r2 = st->r2;
+    const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+        const uint4 ma = slot_meta[c];
+        const uint32_t pa = ld_agent(parent + c);
+        // round 1: the windows of all rows.  Every load is issued before any is used and none sits under a
+        // branch (the second word of a window is fetched whether it is needed or not).
+        uint2 e0[13];
+        uint32_t e1[13], sh[13], wd[13];
+#pragma unroll
+        for (int r = 0; r < 13; ++r) {
+            uint32_t pos;
+            union_row(r, ma.w, rowbits, plane, &pos, &wd[r]);
+            sh[r] = pos & 31u;
+            e0[r] = cmap[pos >> 5];
+            e1[r] = cmap[(pos >> 5) + 1u].x;
+        }
+        uint32_t win[13], id0[13];
+#pragma unroll
+        for (int r = 0; r < 13; ++r) {
+            uint32_t bits = e0[r].x >> sh[r];
+            if (sh[r] + wd[r] > 32u) bits |= (e1[r] << 1) << (31u - sh[r]);
+            win[r] = bits & ((1u << wd[r]) - 1u);
+            id0[r] = e0[r].y + __popc(e0[r].x & ((1u << sh[r]) - 1u));
+        }
+        // round 2: parent words of the occupied neighbours (the ids of a row's occupied cells are consecutive).
+        // Plain loads are enough here: a parent word, however stale, names a member of the neighbour's set, and
+        // sets only ever merge, so equal words prove "same set".  Slots without a neighbour re-read the cell's own.
+        bool differs = false;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t got[7 * 5];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int r = half * 7 + q;
+                if (r < 13) {
+                    const uint32_t cnt = __popc(win[r]);
+#pragma unroll
+                    for (uint32_t k = 0; k < 5; ++k) got[q * 5 + k] = parent[k < cnt ? id0[r] + k : c];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int r = half * 7 + q;
+                if (r < 13) {
+                    const uint32_t cnt = __popc(win[r]);
+#pragma unroll
+                    for (uint32_t k = 0; k < 5; ++k) differs |= (k < cnt) && (got[q * 5 + k] != pa);
+                }
+            }
+        }
+        if (!differs || scan_only) continue;
+        // some neighbour may be in another set: walk the rows again and look properly at those whose parent
+        // word differs from the cell's (roots, pair test, union by CAS)
+        uint32_t ra = uf_find(parent, c);
+#pragma unroll 1
+        for (int r = 0; r < 13; ++r) {
+            uint32_t id = id0[r];
+            for (uint32_t left = __popc(win[r]); left; --left, ++id) {
+                const uint32_t pb = ld_agent(parent + id);
+                if (pb == pa || pb == ra) continue;
+                const uint32_t rb = uf_find(parent, id);
+                if (rb == ra) continue;
+                ra = uf_find(parent, ra);   // the cell's root may have been hung under another one meanwhile
+                if (rb == ra) continue;
+                const uint4 mb = slot_meta[id];
+                if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) { uf_union(parent, prio, ra, rb); ra = uf_find(parent, ra); }
+            }
+        }
+    }
+}
+
+}  // namespace pcop
