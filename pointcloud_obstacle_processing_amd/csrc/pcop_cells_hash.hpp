@@ -38,26 +38,40 @@ __device__ __forceinline__ unsigned long long pack_cell(long long cx, long long 
            ((unsigned long long)(cz + kCellBias) << 42);
 }
 
+// Probe number p of the cell whose home slot is `home`: the first table-size / 64 probes step from bucket to
+// bucket inside the cell's own sub-table (low 6 slot bits = its index in the 4x4x4 block); should that sub-table be
+// full - a cloud whose cells all share a few in-block indices, e.g. a sparse axis-aligned plane - the walk goes on
+// through the next sub-table, and so on, so that it visits every slot of the table exactly once.  The table has
+// at least twice as many slots as cells, so an insertion always finds a free slot and a lookup always ends.
+__device__ __forceinline__ uint32_t probe_slot(uint32_t home, uint32_t p, uint32_t mask) {
+    const uint32_t nb = (mask + 1u) >> 6;                 // buckets (a power of two, >= 16)
+    const uint32_t b = ((home >> 6) + p) & (nb - 1u);     // bucket: p mod nb steps from the home bucket
+    const uint32_t j = p >> (31 - __clz((int)nb));        // p / nb: sub-tables gone through so far
+    return (b << 6) | (((home & 63u) + j) & 63u);
+}
+
 __device__ __forceinline__ uint32_t hash_find_or_insert(unsigned long long* hkey, uint32_t mask, unsigned long long key) {
     const unsigned long long want = key + 1ull;
-    uint32_t slot = cell_home(key, mask);
+    const uint32_t home = cell_home(key, mask);
+    uint32_t slot = home, p = 0;
     while (true) {
         unsigned long long k = hkey[slot];
         if (k == 0ull) k = atomicCAS(hkey + slot, 0ull, want);
         if (k == 0ull || k == want) return slot;
-        slot = (slot + 64u) & mask;
+        slot = probe_slot(home, ++p, mask);
     }
 }
 
 __device__ __forceinline__ uint32_t hash_lookup(const unsigned long long* __restrict__ hkey, uint32_t mask,
                                                 unsigned long long key) {
     const unsigned long long want = key + 1ull;
-    uint32_t slot = cell_home(key, mask);
+    const uint32_t home = cell_home(key, mask);
+    uint32_t slot = home, p = 0;
     while (true) {
         const unsigned long long k = hkey[slot];
         if (k == want) return slot;
         if (k == 0ull) return kNoSlot;
-        slot = (slot + 64u) & mask;
+        slot = probe_slot(home, ++p, mask);
     }
 }
 
@@ -508,8 +522,8 @@ __global__ __launch_bounds__(kBlock) void k_cell_union(const Frame* frames) {
         const bool two = ai + 1 < ncell;
         const uint32_t a = cur.i1.y, c = cur.j1.y;
         // finish the probes of this step, then ask for the neighbours' parent words
-        while (va != wa && va != 0ull) { sa = (sa + 64u) & mask; va = hkey[sa]; }
-        while (vc != wc && vc != 0ull) { sc = (sc + 64u) & mask; vc = hkey[sc]; }
+        { const uint32_t home = sa; uint32_t p = 0; while (va != wa && va != 0ull) { sa = probe_slot(home, ++p, mask); va = hkey[sa]; } }
+        { const uint32_t home = sc; uint32_t p = 0; while (vc != wc && vc != 0ull) { sc = probe_slot(home, ++p, mask); vc = hkey[sc]; } }
         const uint32_t ba = va == wa ? sa : kNoSlot, bc = (two && vc == wc) ? sc : kNoSlot;
         uint32_t pba = pa, pbc = pc;
         if (ba != kNoSlot) pba = ld_agent(parent + ba);

@@ -636,3 +636,22 @@ def test_mixed_path_combinations(capi, oracle, monkeypatch, vox, cell):
             assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
             assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
         c.close()
+
+
+def test_hash_table_sub_table_overflow(capi, oracle, monkeypatch):
+    """Hash fallback, a sparse axis-aligned plane: every cell has the same z index inside its 4x4x4 block, so only 16 of
+    the table's 64 sub-tables are addressed and they overflow; probing must spill into the next sub-table (it used to
+    walk its own one forever).  Also a line (4 sub-tables) and a single column of cells."""
+    monkeypatch.setenv("PCOP_CELL_PATH", "hash")
+    c = capi.Context(20_000)
+    rng = np.random.default_rng(13)
+    plane = np.zeros((4000, 3), dtype=f32)
+    plane[:, :2] = rng.uniform(-20, 20, (4000, 2))
+    line = np.zeros((3000, 3), dtype=f32)
+    line[:, 0] = rng.uniform(-30, 30, 3000)
+    for pts, tol in ((plane, 0.02), (line, 0.004), (plane * f32(0.01), 0.0002)):
+        c.set_params(leaf=0.001, tol=tol, min_cluster=1, max_cluster=10**9)
+        got = c.euclidean_clusters(pts)
+        assert c.debug_state().cpath == 0
+        assert_same_clusters(*got, *oracle.euclidean_clusters(pts, tol, 1, 10**9))
+    c.close()

@@ -1,0 +1,91 @@
+"""Randomised parity campaign: many small and mid-sized clouds of awkward shapes through the GPU chain, the occupancy
+step and the outlier removal, each compared with the CPU oracle.  usage: python tests/tools/fuzz.py [cases] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+from oracle import oracle as O
+from pointcloud_obstacle_processing_amd import capi
+
+f32 = np.float32
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def cloud(kind, n, scale):
+    if kind == "cube":
+        p = rng.uniform(-scale, scale, (n, 3))
+    elif kind == "plane":
+        p = np.concatenate([rng.uniform(-scale, scale, (n, 2)), rng.normal(0, 0.002, (n, 1))], axis=1)
+    elif kind == "line":
+        p = np.zeros((n, 3)); p[:, 0] = rng.uniform(-scale, scale, n)
+    elif kind == "blobs":
+        c = rng.uniform(-scale, scale, (max(1, n // 200), 3))
+        p = c[rng.integers(0, len(c), n)] + rng.normal(0, 0.03, (n, 3))
+    elif kind == "dups":
+        b = rng.uniform(-scale, scale, (max(1, n // 5), 3))
+        p = b[rng.integers(0, len(b), n)]
+    else:   # lattice: coordinates on multiples of a step, so that keys and distances sit on boundaries
+        step = rng.choice([0.01, 0.02, 0.025, 0.05])
+        p = rng.integers(-int(scale / step), int(scale / step) + 1, (n, 3)) * step
+    return p.astype(f32)
+
+
+ctx = capi.Context(60_000, max_frames=2)
+t0 = time.time()
+fails = 0
+kinds = ["cube", "plane", "line", "blobs", "dups", "lattice"]
+for it in range(cases):
+    kind = kinds[it % len(kinds)]
+    n = int(rng.choice([1, 2, 3, 7, 33, 64, 65, 200, 1000, 5000, 20000, 50000]))
+    scale = float(rng.choice([0.05, 0.5, 2.0, 20.0]))
+    leaf = float(rng.choice([0.01, 0.02, 0.05, 0.2]))
+    tol = float(rng.choice([0.02, 0.05, 0.1, 0.4, -0.1]))
+    mn = int(rng.choice([1, 2, 5])); mx = int(rng.choice([20, 20000, 10**9]))
+    if abs(tol) / scale > 0.2 or kind in ("dups", "lattice", "line"):
+        n = min(n, 2000)        # the CPU oracle's radius search is quadratic when everything is within the radius
+    pts = cloud(kind, n, scale)
+    p = dict(leaf=leaf, tol=tol, min_cluster=mn, max_cluster=mx)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("case", it, kind, n, scale, p, flush=True)
+    ctx.set_params(publish_clouds=1, **p)
+    try:
+        got = ctx.process_xyz(pts)
+        ref = O.process_xyz(pts, **p)
+        ok = (got["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes() and np.array_equal(got["offsets"], ref["offsets"])
+              and np.array_equal(got["indices"], ref["indices"]) and got["passthrough"] == ref["passthrough"])
+    except capi.PcopError as e:
+        ok = e.status == -7 and scale / abs(tol) > 1e5     # PCOP_ERR_RANGE is the only legitimate refusal here
+    if not ok:
+        fails += 1
+        print("CHAIN MISMATCH", it, kind, n, scale, p, flush=True)
+    if it % 3 == 0 and n >= 33:      # outlier removal on the same cloud
+        k = int(rng.choice([1, 4, 15, 31]))
+        if n >= k + 1:
+            if os.environ.get("FUZZ_VERBOSE"):
+                print("  sor k", k, flush=True)
+            g = ctx.statistical_outlier_removal(pts, k, 1.0)
+            r = O.sor(pts, k, 1.0)
+            if not (g["distances"].tobytes() == r["distances"].tobytes() and g["threshold"] == r["threshold"] and g["xyz"].tobytes() == r["xyz"].tobytes()):
+                fails += 1
+                print("SOR MISMATCH", it, kind, n, scale, k, flush=True)
+    if it % 4 == 0:                  # occupancy step with limits cutting through the cloud
+        po = O.occ_params(-0.6 * scale, 0.7 * scale, -0.5 * scale, 0.8 * scale, -scale, scale, float(rng.choice([0.013, 0.05, 0.15])) * max(scale, 0.1), 0.5)
+        if po.grid_width * po.grid_height <= (1 << 22):
+            if os.environ.get("FUZZ_VERBOSE"):
+                print("  occ", po.grid_width, po.grid_height, po.block_size, flush=True)
+            q = pts.copy()
+            if n > 10:
+                q[::7, 1] = np.nan; q[::11, 0] = np.nan
+            g = ctx.occupancy_filter(q, capi.OccParams(po.x_min, po.x_max, po.y_min, po.y_max, po.z_min, po.z_max, po.block_size, po.dev_percent, po.grid_width, po.grid_height))
+            r = O.occupancy(q, po)
+            if not (g["xyz"].tobytes() == r["xyz"].tobytes() and np.array_equal(g["counts"], r["counts"]) and np.array_equal(g["grid"], r["grid"])
+                    and np.array_equal(g["row_avg"], r["row_avg"]) and g["index_errors"] == r["index_errors"]):
+                fails += 1
+                print("OCC MISMATCH", it, kind, n, scale, flush=True)
+    if it % 20 == 19:
+        print("  ... %d cases, %d mismatches, %.0f s" % (it + 1, fails, time.time() - t0), flush=True)
+print("cases %d, mismatches %d, %.1f s" % (cases, fails, time.time() - t0))
+ctx.close()
+sys.exit(1 if fails else 0)
