@@ -60,6 +60,52 @@ for it in range(cases):
     if not ok:
         fails += 1
         print("CHAIN MISMATCH", it, kind, n, scale, p, flush=True)
+    if it % 5 == 1 and n >= 3:       # a cloud declared not dense, with NaN / Inf rows: the voxel grid drops them
+        q = pts.copy()
+        q[::3, rng.integers(0, 3)] = np.nan
+        if n > 5:
+            q[1::5, 0] = np.inf
+        fin = np.isfinite(q).all(axis=1)
+        gerr, rerr = None, False
+        try:
+            got = ctx.process_xyz(q, is_dense=False)
+        except capi.PcopError as e:
+            gerr = e.status
+        try:
+            ref = O.process_xyz(q, is_dense=False, **p)
+        except ValueError:
+            rerr = True       # a passthrough frame (grid overflow) clusters the input itself, NaNs included: refused by both
+        if gerr is not None or rerr:
+            ok = gerr is not None and (rerr or gerr == -7)
+        else:
+            ok = (got["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes() and np.array_equal(got["offsets"], ref["offsets"])
+                  and np.array_equal(got["indices"], ref["indices"]))
+        if not ok:
+            fails += 1
+            print("NONDENSE MISMATCH", it, kind, n, scale, p, flush=True)
+    if it % 7 == 2:                  # the two stage calls, and two frames of different sizes in one batch
+        vg, ptg = ctx.voxel_downsample(pts)
+        vr, ptr_ = O.voxel_downsample(pts, leaf)
+        okv = vg.tobytes() == vr.tobytes() and ptg == ptr_
+        try:
+            cg = ctx.euclidean_clusters(pts)
+            cr = O.euclidean_clusters(pts, tol, mn, mx)
+            okc = np.array_equal(cg[0], cr[0]) and np.array_equal(cg[1], cr[1])
+        except capi.PcopError as e:
+            okc = e.status == -7
+        other = cloud(kinds[(it + 1) % len(kinds)], max(1, n // 3), scale)
+        try:
+            ctx.submit_batch_host([pts, other])
+            rb = ctx.wait_batch()
+            okb = True
+            for fr, src in zip(rb, (pts, other)):
+                rr = O.process_xyz(src, **p)
+                okb = okb and fr["voxel_xyz"].tobytes() == rr["voxel_xyz"].tobytes() and np.array_equal(fr["offsets"], rr["offsets"]) and np.array_equal(fr["indices"], rr["indices"])
+        except capi.PcopError as e:
+            okb = e.status == -7
+        if not (okv and okc and okb):
+            fails += 1
+            print("STAGE/BATCH MISMATCH", it, kind, n, scale, p, okv, okc, okb, flush=True)
     if it % 3 == 0 and n >= 33 and os.environ.get("PCOP_CELL_PATH") != "hash":      # outlier removal on the same cloud (needs the dense grid's buffers)
         k = int(rng.choice([1, 4, 15, 31]))
         if n >= k + 1:
