@@ -12,7 +12,8 @@ from pointcloud_obstacle_processing_amd import capi, synth
 f32 = np.float32
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-ctx = capi.Context(400_000, max_frames=2)
+big = os.environ.get("FUZZ_BIG") == "1"     # FUZZ_BIG=1: clouds up to 1 M points (slower oracle)
+ctx = capi.Context(1_000_000 if big else 400_000, max_frames=2)
 menu = [
     ("C3", dict(leaf=0.02, tol=0.1), 1.0),            # the benchmark shape
     ("C3", dict(leaf=0.004, tol=0.02), 1.0),           # many voxels: more LDS per bucket; many cells
@@ -27,7 +28,7 @@ t0 = time.time()
 paths = set()
 for it in range(steps):
     cfg, prm, stretch = menu[int(rng.integers(0, len(menu)))]
-    n = int(rng.choice([5_000, 40_000, 150_000, 400_000]))
+    n = int(rng.choice([5_000, 150_000, 600_000, 1_000_000] if big else [5_000, 40_000, 150_000, 400_000]))
     pts = (synth.make_cloud(cfg, n=n, seed=int(rng.integers(0, 1 << 30))) * f32(stretch)).astype(f32)
     p = dict(prm, min_cluster=int(rng.choice([1, 5])), max_cluster=int(rng.choice([20000, 10**9])))
     ctx.set_params(publish_clouds=1, **p)
