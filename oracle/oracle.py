@@ -1,4 +1,5 @@
-"""ctypes front-end of the CPU oracle (oracle/pcl_restatement.cpp).
+"""ctypes front-end of the CPU oracle (oracle/pcl_restatement.cpp: voxel grid, radius graph, clusters;
+oracle/occupancy_restatement.cpp: bounds filter + occupancy binning; oracle/sor_restatement.cpp: statistical outlier removal).
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg.  The product package never imports this module.

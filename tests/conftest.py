@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def oracle():
-    """The CPU oracle (oracle/pcl_restatement.cpp), built on demand.  Test-only."""
+    """The CPU oracle (oracle/*.cpp), built on demand.  Test-only."""
     from oracle import oracle as O
     O.build()
     return O
