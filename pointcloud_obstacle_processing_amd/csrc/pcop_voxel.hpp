@@ -797,13 +797,18 @@ __global__ __launch_bounds__(kBlock) void k_vid_hist(const Frame* frames) {
     uint32_t k[kItems];
 #pragma unroll
     for (int j = 0; j < kItems; ++j) { const uint32_t i = wbase + j * kWave; k[j] = i < n ? vkey[i] : kNoKey; }
+    // all occupancy words of the thread's records are requested before any is used (a dropped point reads word 0;
+    // a load under a branch would be waited for at the branch's join, one L2 round trip per record)
+    uint2 e[kItems];
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) e[j] = vmap[k[j] != kNoKey ? k[j] >> 5 : 0u];
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
         const uint32_t i = wbase + j * kWave;
         if (i < n) {
             uint32_t d = nb - 1u;
             if (k[j] != kNoKey) {
-                const uint32_t id = voxel_id(vmap, k[j]);
+                const uint32_t id = e[j].y + __popc(e[j].x & ((1u << (k[j] & 31u)) - 1u));
                 vkey[i] = id;   // key -> id, in place
                 d = id >> sh;
             }
