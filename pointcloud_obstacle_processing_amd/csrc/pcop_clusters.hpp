@@ -86,11 +86,17 @@ __global__ __launch_bounds__(kBlock) void k_kept_apply(Frame* frames, uint32_t n
     uint32_t v[kScanItems], root[kScanItems];
     uint32_t c = 0, s = 0;
     const uint32_t i0 = base + threadIdx.x * kScanItems;
+    // root, first point and size of the component of each of the thread's points: three rounds of independent loads
+    uint32_t first[kScanItems], size[kScanItems];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) root[k] = pt_root[min(i0 + k, n - 1u)];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { first[k] = hmin[root[k]]; size[k] = comp_size[root[k]]; }
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t i = i0 + k;
-        v[k] = 0; root[k] = 0;
-        if (i < n) v[k] = kept_size(i, pt_root, hmin, comp_size, lo, hi, &root[k]);
+        // point i opens a kept cluster iff it is the first point of its component and min <= size <= max
+        v[k] = (i < n && first[k] == i && size[k] >= lo && size[k] <= hi) ? size[k] : 0u;
         c += v[k] ? 1u : 0u; s += v[k];
     }
     uint32_t totc, tots;
@@ -142,6 +148,22 @@ __device__ __forceinline__ uint32_t point_label(uint32_t p, const uint32_t* __re
     return min(comp_rank[pt_root[p]], trash);
 }
 
+// Cluster rank of each of a thread's kItems records (count = "not there").  Three rounds of independent loads
+// (point index, root, rank): a load under a per-record branch would be waited for at the branch's join, which
+// would put the records' dependent chains one after the other.
+__device__ __forceinline__ void point_labels(uint32_t wbase, uint32_t count, int pass, const uint32_t* __restrict__ idx_in,
+                                             const uint32_t* __restrict__ pt_root, const uint32_t* __restrict__ comp_rank,
+                                             uint32_t trash, uint32_t* pt, uint32_t* label) {
+    const uint32_t last = count - 1u;   // count >= 1 here
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) { const uint32_t i = min(wbase + j * kWave, last); pt[j] = pass == 0 ? i : idx_in[i]; }
+    uint32_t root[kItems];
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) root[j] = pt_root[pt[j]];
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) label[j] = min(comp_rank[root[j]], trash);
+}
+
 template <int MAXB>
 __global__ __launch_bounds__(kBlock) void k_csr_hist(const Frame* frames, int pass) {
     __shared__ uint32_t s_h[(1 << MAXB) + 1];
@@ -159,14 +181,11 @@ __global__ __launch_bounds__(kBlock) void k_csr_hist(const Frame* frames, int pa
     __syncthreads();
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t wbase = tile_base + (threadIdx.x / kWave) * (kItems * kWave) + lane_id();
+    uint32_t pt[kItems], label[kItems];
+    point_labels(wbase, count, pass, idx_in, pt_root, comp_rank, trash, pt, label);
 #pragma unroll
-    for (int j = 0; j < kItems; ++j) {
-        const uint32_t i = wbase + j * kWave;
-        if (i < count) {
-            const uint32_t p = pass == 0 ? i : idx_in[i];
-            atomicAdd(&s_h[(point_label(p, pt_root, comp_rank, trash) >> shift) & mask], 1u);
-        }
-    }
+    for (int j = 0; j < kItems; ++j)
+        if (wbase + j * kWave < count) atomicAdd(&s_h[(label[j] >> shift) & mask], 1u);
     __syncthreads();
     const uint32_t ntiles = (count + kTile - 1) / kTile;
     for (uint32_t b = threadIdx.x; b < nb; b += kBlock) table[(size_t)b * ntiles + blockIdx.x] = s_h[b];
@@ -194,17 +213,13 @@ __global__ __launch_bounds__(kBlock) void k_csr_scatter(const Frame* frames, int
     uint32_t* hist_w = s_hist + w * nb;
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t wbase = tile_base + w * (kItems * kWave) + lane_id();
-    uint32_t pt[kItems], dig[kItems], lrank[kItems];
+    uint32_t pt[kItems], label[kItems], dig[kItems], lrank[kItems];
+    point_labels(wbase, count, pass, idx_in, pt_root, comp_rank, trash, pt, label);
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
         const uint32_t i = wbase + j * kWave;
         const bool active = i < count;
-        uint32_t d = 0;
-        pt[j] = 0;
-        if (active) {
-            pt[j] = pass == 0 ? i : idx_in[i];
-            d = (point_label(pt[j], pt_root, comp_rank, trash) >> shift) & mask;
-        }
+        const uint32_t d = active ? (label[j] >> shift) & mask : 0u;
         // few tiles, latency-bound: the ballots (pure ALU) beat the LDS round trips of match_digit_lds here
         const uint64_t peers = match_digit(d, bits, active);
         const uint32_t rank = __popcll(peers & lanemask_lt());
