@@ -23,6 +23,23 @@ struct RecSrc {
     }
 };
 
+// The kItems records of a thread (record j at wbase + j * 64), all requested before any is used: the indices are
+// clamped instead of tested, and the choice of source is made once, outside the loop (a load under a per-record
+// branch is waited for at the branch's join, which would cost one HBM round trip per record).
+__device__ __forceinline__ void load_records(const RecSrc& src, uint32_t wbase, uint32_t count, Rec3* rec) {
+    const uint32_t last = count - 1u;   // count >= 1: the caller's tile starts below count
+    if (src.r) {
+#pragma unroll
+        for (int j = 0; j < kItems; ++j) rec[j] = src.r[min(wbase + j * kWave, last)];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kItems; ++j) {
+            const uint32_t i = min(wbase + j * kWave, last);
+            rec[j].x = src.x[i]; rec[j].y = src.y[i]; rec[j].z = src.z[i];
+        }
+    }
+}
+
 // PCL's linear voxel index (voxel_grid.hpp, "First pass"): ijk = (int)(floor(p*inv) - (float)min_b).
 struct VoxelKey {
     float inv, fb0, fb1, fb2;
@@ -291,11 +308,13 @@ __global__ __launch_bounds__(kBlock) void k_radix_hist(const Frame* frames, int 
     __syncthreads();
     const uint32_t mask = (1u << pi.bits) - 1u;
     const uint32_t wbase = tile_base + (threadIdx.x / kWave) * (kItems * kWave) + lane_id();
+    Rec3 rec[kItems];
+    load_records(src, wbase, pi.count, rec);
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
         const uint32_t i = wbase + j * kWave;
         if (i < pi.count) {
-            const Rec3 r = src.load(i);
+            const Rec3 r = rec[j];
             uint32_t d;
             if (pi.drop_nonfinite && !finite3(r.x, r.y, r.z)) d = pi.nb - 1;
             else d = (key(r) >> pi.shift) & mask;
@@ -444,13 +463,13 @@ __global__ __launch_bounds__(kBlock) void k_radix_scatter(const Frame* frames, i
     const uint32_t wbase = tile_base + w * (kItems * kWave) + lane_id();
     Rec3 rec[kItems];
     uint32_t dig[kItems], lrank[kItems];
+    load_records(src, wbase, pi.count, rec);
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
         const uint32_t i = wbase + j * kWave;
         const bool active = i < pi.count;
         uint32_t d = 0;
         if (active) {
-            rec[j] = src.load(i);
             if (pi.drop_nonfinite && !finite3(rec[j].x, rec[j].y, rec[j].z)) d = nb - 1;
             else d = (key(rec[j]) >> pi.shift) & mask;
         }
