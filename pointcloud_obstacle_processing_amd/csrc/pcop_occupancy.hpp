@@ -59,11 +59,15 @@ __global__ __launch_bounds__(kBlock) void k_occ_filter(OccParams p, const float*
     uint32_t c = 0, bad = 0;
     const uint32_t i0 = base + threadIdx.x * kScanItems;
 #pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {   // loads first (clamped, not tested)
+        const uint32_t i = min(i0 + k, n - 1u);
+        px[k] = x[i]; py[k] = y[i]; pz[k] = z[i];
+    }
+#pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t i = i0 + k;
         keep[k] = false;
         if (i < n) {
-            px[k] = x[i]; py[k] = y[i]; pz[k] = z[i];
             // od.cpp:196-199: only x is tested for NaN; a NaN y or z fails every comparison and passes
             keep[k] = !(isnan(px[k]) || px[k] < p.x_min || px[k] > p.x_max || pz[k] < p.z_min || pz[k] > p.z_max ||
                         py[k] < p.y_min || py[k] > p.y_max);

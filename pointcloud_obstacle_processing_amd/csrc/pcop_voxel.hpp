@@ -580,10 +580,13 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
     // stage the tile's records and keys in LDS (coalesced), so that the in-order run sums below
     // chase LDS, not L2
     const uint32_t cnt = min((uint32_t)kScanTile, n - base);
+    Rec3 staged[kScanItems];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) staged[k] = rec[base + min((uint32_t)(k * kBlock) + threadIdx.x, cnt - 1u)];   // loads first
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t j = k * kBlock + threadIdx.x;
-        if (j < cnt) { const Rec3 r = rec[base + j]; s_rec[j] = r; s_key[j + 1] = key(r); }
+        if (j < cnt) { s_rec[j] = staged[k]; s_key[j + 1] = key(staged[k]); }
     }
     if (threadIdx.x == 0) s_key[0] = base > 0 ? key(rec[base - 1]) : 0u;
     __syncthreads();
@@ -733,14 +736,18 @@ __global__ __launch_bounds__(kBlock) void k_occ_scan(Frame* frames) {
     if (base >= words) return;
     const uint32_t cnt = min(kVmapTile, words - base);
     // a word = 32 cells = two 16-byte loads; the flag array is padded to whole tiles
+    constexpr uint32_t kHalves = 2 * kVmapTile / kBlock;
+    uint4 fl[kHalves];
 #pragma unroll
-    for (uint32_t k = 0; k < 2 * kVmapTile / kBlock; ++k) {
+    for (uint32_t k = 0; k < kHalves; ++k)   // all loads first (clamped, not tested: no load sits under a branch)
+        fl[k] = flags[(size_t)base * 2 + min(k * kBlock + threadIdx.x, 2 * cnt - 1u)];
+#pragma unroll
+    for (uint32_t k = 0; k < kHalves; ++k) {
         const uint32_t h = k * kBlock + threadIdx.x;   // half-word of the tile
         uint32_t bits = 0;
         if (h < 2 * cnt) {
-            const size_t at = (size_t)base * 2 + h;
-            bits = flags_to_bits(flags[at]);
-            if (bits) flags[at] = make_uint4(0u, 0u, 0u, 0u);
+            bits = flags_to_bits(fl[k]);
+            if (bits) flags[(size_t)base * 2 + h] = make_uint4(0u, 0u, 0u, 0u);
         }
         s_half[h] = (uint16_t)bits;
     }
