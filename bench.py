@@ -32,14 +32,12 @@ def kernel_alg_bytes(name, occurrence, n, m, n_cells):
     n = input points, m = voxels.  `occurrence` = index of this launch among launches of the same name."""
     if name == "k_minmax":
         return 12 * n
-    if name == "k_vox_mark":
-        return 12 * n + 4 * n           # read xyz planes, write the voxel key
-    if name == "k_vid_hist":
-        return 4 * n + 4 * n            # key -> id in place
-    if name == "k_vid_scatter":
-        return (12 + 4) * n + 16 * n    # xyz planes + id in, {x,y,z,id} records out
-    if name == "k_voxel_stream":
-        return 16 * n + 12 * m
+    if name == "k_bin_hist":
+        return 12 * n                   # read the xyz planes
+    if name == "k_bin_scatter":
+        return 12 * n + 12 * n          # xyz planes in, packed xyz records out
+    if name == "k_bucket_reduce":
+        return 12 * n + 12 * m          # records in, centroids out
     if name == "k_radix_hist":
         return 12 * n                   # xyz planes (pass 0) or packed 12-byte records
     if name == "k_radix_scatter":

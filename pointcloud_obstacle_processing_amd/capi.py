@@ -69,9 +69,9 @@ class DevState(C.Structure):
                 ("c_n", C.c_uint32), ("c_from_input", C.c_uint32), ("r2", C.c_float), ("min_cluster", C.c_uint32),
                 ("max_cluster", C.c_uint32), ("hash_mask", C.c_uint32), ("n_cells", C.c_uint32),
                 ("n_kept", C.c_uint32), ("n_kept_pts", C.c_uint32), ("plan_csr", RadixPlan), ("debug_skip_union", C.c_uint32),
-                ("vpath", C.c_uint32), ("vmap_words", C.c_uint32), ("vshift", C.c_uint32), ("nbuckets", C.c_uint32), ("vcap", C.c_uint32),
+                ("vpath", C.c_uint32), ("gbits", C.c_uint32), ("cshift", C.c_uint32), ("nbuckets", C.c_uint32), ("nb_cap", C.c_uint32),
                 ("cgrid_req", C.c_uint32), ("cpath", C.c_uint32), ("cmap_words", C.c_uint32), ("c_rowbits", C.c_uint32),
-                ("c_plane", C.c_uint32), ("c0", C.c_int32 * 3), ("c_dim", C.c_uint32 * 3), ("pad1", C.c_uint32)]
+                ("c_plane", C.c_uint32), ("c0", C.c_int32 * 3), ("c_dim", C.c_uint32 * 3), ("maxbin", C.c_uint32)]
 
 
 _lib = None

@@ -32,14 +32,14 @@ inline bool compare_clusters(const ClusterRef& a, const ClusterRef& b) { return 
 
 struct GraphKey {
     uint32_t kind, bucket, npass_voxel, npass_csr, nframes;
-    uint32_t stream, vcap, vtiles;   // streaming voxel path: on?, voxels per bucket (LDS), occupancy tiles (grid)
+    uint32_t stream, nb_cap, gbits;  // streaming voxel path: on?, buckets provided for (LDS, grids), log2 of the coarse bins (LDS)
     uint32_t cgrid, ctiles;          // dense cell grid: on?, occupancy tiles (grid)
     bool operator<(const GraphKey& o) const {
         if (cgrid != o.cgrid) return cgrid < o.cgrid;
         if (ctiles != o.ctiles) return ctiles < o.ctiles;
         if (stream != o.stream) return stream < o.stream;
-        if (vcap != o.vcap) return vcap < o.vcap;
-        if (vtiles != o.vtiles) return vtiles < o.vtiles;
+        if (nb_cap != o.nb_cap) return nb_cap < o.nb_cap;
+        if (gbits != o.gbits) return gbits < o.gbits;
         if (kind != o.kind) return kind < o.kind;
         if (bucket != o.bucket) return bucket < o.bucket;
         if (npass_voxel != o.npass_voxel) return npass_voxel < o.npass_voxel;
@@ -99,12 +99,13 @@ struct pcop_ctx {
     uint32_t stride_blocks = 4096;    // total blocks per launch of the grid-strided point kernels
     uint32_t flatten_blocks = 128;    // blocks per frame of k_cell_flatten (each wave walks one contiguous chunk of points)
     uint32_t debug_skip_union = 0;    // diagnostics: 1 = no union kernel, 2 = union scans but never fixes up
-    // streaming voxel path (pcop_device.hpp): on unless PCOP_VOXEL_PATH=sort; a frame it does not fit
-    // (grid > kVmapCells cells, or > 256 * kVcapMax voxels) is re-run on the sort path and the context stays there
-    // until the parameters change
+    // streaming voxel path (pcop_voxel.hpp): on unless PCOP_VOXEL_PATH=sort; a frame it does not fit (more than
+    // kNbMax buckets, or a coarse bin above a bucket's capacity even with the finest bins) is re-run on the sort
+    // path and the context stays there until the leaf size changes
     bool voxel_stream = true, stream_ok = true;
-    uint32_t vcap = kVcapMin;                               // voxels per bucket the launch provides LDS for (grows on demand)
-    uint32_t vtiles = kVmapCells / 32u / kVmapTile;         // occupancy tiles launched (adapts to the grid seen)
+    uint32_t nb_cap = kNbMin;                               // buckets the launch provides LDS and blocks for (grows on demand)
+    uint32_t gbits = 13;                                    // log2 of the coarse key bins (tuned from the fullest bin seen; any value gives the same result)
+    bool gbits_fixed = false;                               // PCOP_BIN_BITS given: no tuning
     // dense cell grid: on unless PCOP_CELL_PATH=hash; a frame whose grid exceeds kCmapCells is re-run on the hash
     // table and the context stays there until the tolerance changes
     bool cell_grid = true, cgrid_ok = true;
@@ -226,18 +227,18 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
         k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, stream ? 1u : 0u);
         mark(c, "k_voxel_setup");
         if (stream) {
-            k_vox_mark<<<dim3(stride_grid(nb), nf), kBlock, 0, s>>>(fr);
-            mark(c, "k_vox_mark");
-            k_occ_scan<0><<<dim3(c->vtiles, nf), kBlock, 0, s>>>(fr);
-            mark(c, "k_vmap_scan");
-            k_vid_hist<kNarrowBits><<<pg, kBlock, 0, s>>>(fr);
-            mark(c, "k_vid_hist");
-            k_table_scan<<<dim3(kStreamBuckets + 1u, nf), kBlock, 0, s>>>(fr, 1, 0);
-            mark(c, "k_table_scan");
-            k_vid_scatter<kNarrowBits><<<pg, kBlock, 0, s>>>(fr);
-            mark(c, "k_vid_scatter");
-            k_voxel_stream<<<dim3(kStreamBuckets, nf), kStreamWaves * kWave, (size_t)c->vcap * 24u, s>>>(fr);
-            mark(c, "k_voxel_stream");
+            const dim3 bt(std::max(1u, div_up(nb, kBinTile)), nf);   // tiles of the coarse histogram and of the partition
+            const size_t bins = (size_t)1 << c->gbits;
+            k_bin_hist<<<bt, kBinThreads, bins * 4u, s>>>(fr);
+            mark(c, "k_bin_hist");
+            k_bin_plan<<<dim3(1, nf), kBinThreads, bins * 8u + 16u, s>>>(fr);
+            mark(c, "k_bin_plan");
+            k_bin_offsets<<<dim3(c->nb_cap, nf), kWave, 0, s>>>(fr);
+            mark(c, "k_bin_offsets");
+            k_bin_scatter<<<bt, kScatThreads, scatter_lds_bytes(c->nb_cap), s>>>(fr);
+            mark(c, "k_bin_scatter");
+            k_bucket_reduce<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_bucket_reduce");
         } else {
             for (uint32_t p = 0; p < c->npass_voxel; ++p) {
                 k_radix_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
@@ -264,7 +265,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
             mark(c, "k_cgrid_setup");
             k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "k_cell_mark");
-            k_occ_scan<1><<<dim3(c->ctiles, nf), kBlock, 0, s>>>(fr);
+            k_occ_scan<<<dim3(c->ctiles, nf), kBlock, 0, s>>>(fr);
             mark(c, "k_cmap_scan");
             k_cell_count<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "k_cell_count");
@@ -335,7 +336,7 @@ int enqueue_batch(pcop_ctx* c) {
         a.inv_cell = trivial ? 1.0 : 1.99 / std::fabs((double)p.tol);
         a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
         a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.debug_skip_union = c->debug_skip_union;
-        a.voxel_stream = stream_on(c) ? 1u : 0u; a.vcap = c->vcap; a.cell_grid = grid_on(c) ? 1u : 0u; a.pad0 = 0;
+        a.voxel_stream = stream_on(c) ? 1u : 0u; a.nb_cap = c->nb_cap; a.cell_grid = grid_on(c) ? 1u : 0u; a.gbits = c->gbits;
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         nmax = std::max(nmax, sl.n);
     }
@@ -348,7 +349,7 @@ int enqueue_batch(pcop_ctx* c) {
         HIPCHK(c, hipGetLastError());
     } else {
         const bool st_on = stream_on(c);
-        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? 1u : 0u, st_on ? c->vcap : 0u, st_on ? c->vtiles : 0u,
+        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? 1u : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
                            grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
@@ -433,7 +434,6 @@ void order_frame(pcop_ctx* c, Slot& sl, pcop_result* out) {
 // A batch given up half-way may leave occupancy flags set: the streaming voxel path needs them all zero.
 void scrub_flags(pcop_ctx* c) {
     for (Slot& sl : c->slots) {
-        if (sl.f.vflag.get()) hipMemsetAsync(sl.f.vflag.get(), 0, (size_t)kVmapCells, c->stream);
         if (sl.f.cflag.get()) hipMemsetAsync(sl.f.cflag.get(), 0, (size_t)kCmapCells, c->stream);
     }
     hipStreamSynchronize(c->stream);
@@ -455,7 +455,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (e & kErrNonFinite) { c->in_flight = false; c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
         if (e & kErrRange) { c->in_flight = false; c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
         if (e & kErrInternal) { c->in_flight = false; scrub_flags(c); c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
-        if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanCpath | kErrReplanCtiles)) {
+        if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanBins | kErrReplanCpath | kErrReplanCtiles)) {
             if (attempt >= 6) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
             if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));
             if (kb_csr) c->npass_csr = std::max(c->npass_csr, passes_for(c, kb_csr));
@@ -467,16 +467,16 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
                     if (hs->err & kErrReplanCtiles) c->ctiles = std::max(c->ctiles, std::min(kCmapCells / 32u / kVmapTile, pow2_at_least(div_up(hs->cmap_words, kVmapTile)) * 2u));
                 }
             }
+            if ((e & kErrReplanBins) && (c->gbits >= kBinBitsMax || c->gbits_fixed)) e |= kErrReplanPath;   // the finest bins are still too coarse
             if (e & kErrReplanPath) {
                 c->stream_ok = false;            // this cloud does not fit the streaming voxel path: sort path from here on
                 c->npass_voxel = kMaxPasses;     // (its own plan check then trims the pass count)
+            } else if (e & kErrReplanBins) {
+                ++c->gbits;                      // finer coarse bins
             } else if (e & kErrReplanVcap) {
                 for (uint32_t f = 0; f < c->nframes; ++f) {
                     const DevState* hs = c->slots[f].h_state;
-                    if (!(hs->err & kErrReplanVcap)) continue;
-                    const uint32_t tiles = div_up(hs->vmap_words, kVmapTile);
-                    if (tiles > c->vtiles) c->vtiles = std::min(kVmapCells / 32u / kVmapTile, pow2_at_least(tiles) * 2u);
-                    else c->vcap = std::max(c->vcap, 1u << hs->vshift);
+                    if (hs->err & kErrReplanVcap) c->nb_cap = std::max(c->nb_cap, std::min(kNbMax, pow2_at_least(hs->nbuckets)));
                 }
             }
             int rc = enqueue_batch(c);
@@ -516,13 +516,13 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             if (c->ctiles > 2u * want) c->ctiles = want;
         }
     }
-    if (stream_on(c)) {   // occupancy-scan grid of the next batch: 2x what this one needed, shrunk only when 4x too large
-        uint32_t tiles = 0;
+    if (stream_on(c) && !c->gbits_fixed) {   // coarse bins of the next batch: the fullest bin between 1/8 and 1/2 of a bucket
+        uint32_t maxbin = 0, seen = 0;
         for (uint32_t f = 0; f < c->nframes; ++f)
-            if (c->slots[f].h_state->vpath) tiles = std::max(tiles, div_up(c->slots[f].h_state->vmap_words, kVmapTile));
-        if (tiles) {
-            const uint32_t want = std::min(kVmapCells / 32u / kVmapTile, pow2_at_least(tiles) * 2u);
-            if (c->vtiles > 2u * want) c->vtiles = want;
+            if (c->slots[f].h_state->vpath) { maxbin = std::max(maxbin, c->slots[f].h_state->maxbin); ++seen; }
+        if (seen) {
+            if (maxbin > kBucketCap / 2u && c->gbits < kBinBitsMax) ++c->gbits;
+            else if (maxbin < kBucketCap / 8u && c->gbits > kBinBitsMin) --c->gbits;
         }
     }
     for (uint32_t f = 0; f < c->nframes; ++f) order_frame(c, c->slots[f], (out && f < nout) ? out + f : nullptr);
@@ -611,11 +611,12 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         TRY(dev_alloc(c, &f.ctile, (size_t)kCmapCells / 32u / kVmapTile));
     }
     if (c->voxel_stream) {
-        TRY(dev_alloc(c, &f.vflag, (size_t)kVmapCells));
-        HIPCHK(c, hipMemset(f.vflag.get(), 0, (size_t)kVmapCells));   // the kernels keep it all zero between frames
-        TRY(dev_alloc(c, &f.vmap, (size_t)kVmapCells / 32u));
-        TRY(dev_alloc(c, &f.vkey, n + 1));
-        TRY(dev_alloc(c, &f.vtile, (size_t)kVmapCells / 32u / kVmapTile));
+        const size_t tiles = (n + kBinTile - 1) / kBinTile + 1;
+        TRY(dev_alloc(c, &f.ctab, tiles << kBinBitsMax));
+        TRY(dev_alloc(c, &f.bin2bucket, ((size_t)1 << kBinBitsMax) + 8));
+        TRY(dev_alloc(c, &f.binfo, (size_t)kNbMax + 1));
+        TRY(dev_alloc(c, &f.tbase, tiles * kNbMax));
+        TRY(dev_alloc(c, &f.bucket_pub, (size_t)kNbMax));
     }
     TRY(host_alloc(c, &sl.h_args, 1));
     TRY(host_alloc(c, &sl.h_state, 1));
@@ -687,6 +688,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char* e = getenv("PCOP_VOXEL_PATH")) c->voxel_stream = std::string(e) != "sort";
     if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
+    if (const char* e = getenv("PCOP_BIN_BITS")) { c->gbits = (uint32_t)std::min<int>(kBinBitsMax, std::max<int>(kBinBitsMin, atoi(e))); c->gbits_fixed = true; }
     if (const char* e = getenv("PCOP_CELL_BLOCKS")) c->cell_blocks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_STRIDE_BLOCKS")) c->stride_blocks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_FLATTEN_BLOCKS")) c->flatten_blocks = (uint32_t)std::max(1, atoi(e));
@@ -993,7 +995,7 @@ static int sor_pass(pcop_ctx* c, Slot& sl, double inv_cell, bool with_knn, uint3
     a.inv_leaf = 1.0f; a.r2 = 1.0f; a.inv_cell = inv_cell;
     a.min_cluster = 1u; a.max_cluster = 0xFFFFFFFFu;
     a.out_layout = (uint32_t)PCOP_LAYOUT_AOS12; a.out_soa_stride = sl.n;
-    a.cell_grid = 1u; a.vcap = c->vcap;
+    a.cell_grid = 1u; a.nb_cap = c->nb_cap; a.gbits = c->gbits;
     a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
     Frame* fr = c->d_frames;
     hipStream_t s = c->stream;
@@ -1008,7 +1010,7 @@ static int sor_pass(pcop_ctx* c, Slot& sl, double inv_cell, bool with_knn, uint3
     if (with_knn) {
         k_cgrid_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr);
         k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
-        k_occ_scan<1><<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
+        k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
         k_cell_count<<<tg, kBlock, 0, s>>>(fr);
         k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
         k_cell_place<<<tg, kBlock, 0, s>>>(fr);
@@ -1142,7 +1144,7 @@ int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* byt
         {"pt_root", f.pt_root, n * 4}, {"idx_a", f.idx_a, n * 4}, {"idx_b", f.idx_b, n * 4},
         {"d_offsets", f.d_offsets, (n + 1) * 4}, {"bin_total", f.bin_total, (size_t)kMaxBins * 4},
         {"cell_list", f.cell_list, n * 4},
-        {"vkey", f.vkey, n * 4}, {"vflag", f.vflag, f.vflag.get() ? (size_t)kVmapCells : 0},
+        {"binfo", f.binfo, f.binfo.get() ? (size_t)(kNbMax + 1) * 16 : 0}, {"bin2bucket", f.bin2bucket, f.bin2bucket.get() ? (size_t)2 << kBinBitsMax : 0},
         {"cflag", f.cflag, f.cflag.get() ? (size_t)kCmapCells : 0}, {"slot_meta", f.slot_meta, h * 16},
     };
     for (const Ent& e : tab) {

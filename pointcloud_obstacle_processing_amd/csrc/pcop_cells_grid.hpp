@@ -17,7 +17,7 @@ namespace pcop {
 //     per-cell array and the lanes of a wave (64 consecutive cells) touch the same cache lines.
 //   k_cgrid_setup   grid origin / size from the bounding box (margins added), or "replan"
 //   k_cell_mark     grid position of every point; one byte per occupied cell
-//   k_occ_scan<1>   bytes -> occupancy bits + running popcount => cell ids, n_cells
+//   k_occ_scan      bytes -> occupancy bits + running popcount => cell ids, n_cells
 //   k_cell_count    points per cell, rank inside the cell, smallest point index (= priority)
 //   k_cell_starts   exclusive scan of the counts; per-cell metadata; union-find init
 //   k_cell_place    (shared with the hash path) records sorted by cell

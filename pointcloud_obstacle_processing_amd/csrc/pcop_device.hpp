@@ -5,16 +5,19 @@
 //   voxel grid (replaces pcl::VoxelGrid::applyFilter, called at od.cpp:282-285)
 //     k_frame_init            mailbox -> DevState
 //     k_minmax, k_voxel_setup pcl::getMinMax3D; min_b/div_b/divb_mul, the overflow rule, the plan
-//    streaming path (default):
-//     k_vox_mark, k_occ_scan<0> occupied grid cells -> voxel id = rank of the key, M
-//     k_vid_hist / k_table_scan / k_vid_scatter   one stable 8-bit partition of {x,y,z,id} by bucket
-//     k_voxel_stream          per bucket: in-order float32 sums in LDS accumulators -> centroids
+//    streaming path (default; no scattered global access anywhere):
+//     k_bin_hist              per 16384-point tile: counts of the coarse key bins (key >> cshift)
+//     k_bin_plan              bins -> buckets of consecutive bins, at most kBucketCap points each
+//     k_bin_offsets           per (tile, bucket): where the tile's points start inside the bucket
+//     k_bin_scatter           ONE stable partition of packed 12-byte xyz records by bucket
+//     k_bucket_reduce         per bucket: occupancy bits in LDS -> local voxel ids, stable LDS counting
+//                             sort, one lane per voxel sums its run in order -> centroids, M
 //    sort path (fallback for grids or voxel counts the streaming path does not cover):
 //     k_radix_hist / k_table_scan / k_radix_scatter   (x passes) stable LSD radix partition of
 //                             packed xyz records by PCL's linear voxel index
 //     k_voxel_reduce          run heads -> rank; in-order float32 sums -> centroids
 //   cell grid (replaces the FLANN kd-tree built at od.cpp:791-792): cells of edge tol/1.99
-//    dense grid (default): k_cgrid_setup, k_cell_mark, k_occ_scan<1>, k_cell_count, k_cell_starts,
+//    dense grid (default): k_cgrid_setup, k_cell_mark, k_occ_scan, k_cell_count, k_cell_starts,
 //                          k_cell_place   occupancy bits -> cell ids; points sorted by cell
 //    hash table (fallback): k_cell_insert, k_slot_count, k_slot_apply, k_cell_place
 //   clusters (replaces EuclideanClusterExtraction::extract, od.cpp:446-454)
@@ -55,11 +58,15 @@ constexpr int kScanTile = kBlock * kScanItems;
 constexpr int kReduceBlocks = 256;               // grid of the min/max kernel: one block per CU
 constexpr int kCellBias = 1 << 20;               // cell coordinates are stored biased, 21 bits per axis
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
-constexpr uint32_t kVmapCells = 1u << 26;       // streaming voxel path: largest voxel grid (cells) with an occupancy map
 constexpr uint32_t kVmapTile = 1024;            // occupancy words per block of k_occ_scan
-constexpr uint32_t kStreamBuckets = 256;        // buckets of the streaming voxel path (one 8-bit partition pass)
-constexpr uint32_t kVcapMin = 512, kVcapMax = 2048;   // voxels per bucket (LDS accumulators: 24 bytes per voxel)
-constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+// streaming voxel path
+constexpr uint32_t kBinTile = 16384;            // points per block of k_bin_hist / k_bin_scatter
+constexpr uint32_t kBinThreads = 1024;          // threads of k_bin_hist / k_bin_plan
+constexpr uint32_t kBinBitsMin = 11, kBinBitsMax = 14;   // coarse key bins per frame: 2^11 .. 2^14 (a host hint; any value gives the same result)
+constexpr uint32_t kBucketCap = 2048;           // points per bucket (k_bucket_reduce: 256 threads x 8 records, all in LDS)
+constexpr uint32_t kBucketCells = 1u << 17;     // grid cells a bucket may span (bits of its LDS occupancy map)
+constexpr uint32_t kNbMin = 1024, kNbMax = 4096;   // buckets per frame a launch provides LDS for (grows on demand)
+constexpr uint32_t kScatThreads = 512, kScatItems = 8, kScatChunk = kScatThreads * kScatItems;   // k_bin_scatter: a tile in chunks of 4096
 constexpr uint32_t kCmapCells = 1u << 24;       // dense cell grid: largest grid (cells, margins included) with an occupancy map
 constexpr int kCellMargin = 3;                  // empty cells around the grid: 2 for the 5x5x5 stencil + 1 of slack (a centroid
                                                 // may round a hair outside the bounding box of its points)        // voxel key / id of a dropped (non-finite) point
@@ -92,8 +99,9 @@ enum ErrBits : uint32_t {
     kErrReplanCsr = 8u,    // cluster-rank key needs more radix passes than were launched
     kErrRange = 16u,       // a cell coordinate leaves +-2^20 cells (|p| / tol too large)
     kErrInternal = 32u,    // a bounded wait inside a kernel ran out (never expected)
-    kErrReplanPath = 64u,  // the streaming voxel path does not apply to this frame (grid or voxel count too large)
-    kErrReplanVcap = 128u, // the streaming voxel path needs more voxels per bucket than the launch provided LDS for
+    kErrReplanPath = 64u,  // the streaming voxel path does not apply to this frame (too many buckets)
+    kErrReplanVcap = 128u, // the streaming voxel path needs more buckets than the launch provided LDS for
+    kErrReplanBins = 1024u,  // a coarse key bin holds more points than a bucket (or spans more cells): finer bins needed
     kErrReplanCpath = 256u,  // the dense cell grid does not apply to this frame (grid too large)
     kErrReplanCtiles = 512u, // the occupancy scan of the dense cell grid was launched with too few tiles
 };
@@ -114,8 +122,8 @@ struct FrameArgs {
     double inv_cell;                          // 1.99 / |tol|
     uint32_t min_cluster, max_cluster;
     uint32_t emit_cloud, out_layout, out_soa_stride, debug_skip_union;
-    uint32_t voxel_stream, vcap;              // streaming voxel path requested; voxels per bucket the launch has LDS for
-    uint32_t cell_grid, pad0;                 // dense cell grid requested (else: the hash table of cells)
+    uint32_t voxel_stream, nb_cap;            // streaming voxel path requested; buckets the launch has LDS for
+    uint32_t cell_grid, gbits;                // dense cell grid requested (else: the hash table of cells); log2 of the coarse bins wanted
     DevPtr<const float> src_x, src_y, src_z;
 };
 
@@ -150,10 +158,10 @@ struct DevState {
     uint32_t debug_skip_union;   // diagnostics: leave the hook forest untouched
     // streaming voxel path
     uint32_t vpath;         // 1: this frame's voxel stage runs the streaming path
-    uint32_t vmap_words;    // occupancy words in use = ceil(cells / 32)
-    uint32_t vshift;        // bucket of a voxel = id >> vshift
+    uint32_t gbits;         // coarse bins = 2^gbits (<= the host's hint, <= the key bits)
+    uint32_t cshift;        // coarse bin of a voxel key = key >> cshift
     uint32_t nbuckets;
-    uint32_t vcap;          // voxels per bucket the launch has LDS for
+    uint32_t nb_cap;        // buckets the launch has LDS for
     // dense cell grid
     uint32_t cgrid_req;     // requested by the host
     uint32_t cpath;         // 1: this frame's cell stage runs on the dense grid
@@ -162,7 +170,7 @@ struct DevState {
     uint32_t c_plane;       // bits per z-plane
     int32_t  c0[3];         // cell coordinate of grid position 0 (margin included)
     uint32_t c_dim[3];      // grid size per axis, margins included
-    uint32_t pad1;
+    uint32_t maxbin;        // streaming voxel path: points in the fullest coarse bin (the host tunes gbits with it)
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState layout");
 
@@ -190,10 +198,11 @@ struct Frame {
     DevPtr<uint32_t> idx_a, idx_b, d_offsets;
     DevPtr<float4> d_xyzr;
     // streaming voxel path (null when the context was created without it)
-    DevPtr<uint8_t> vflag;            // one byte per voxel-grid cell: occupied?  all zero between frames
-    DevPtr<uint2> vmap;               // per 32 cells: {occupancy bits, occupied cells before this word}
-    DevPtr<uint32_t> vkey;            // per input point: voxel key, then voxel id (rank among occupied cells)
-    DevPtr<uint32_t> vtile;           // per occupancy tile: its popcount + 1 once known (0 = not yet)
+    DevPtr<uint16_t> ctab;            // [tile][coarse bin]: points of the tile in the bin
+    DevPtr<uint16_t> bin2bucket;      // [coarse bin]: bucket of the bin
+    DevPtr<uint4> binfo;              // [bucket]: {first record, records, first voxel key, voxel keys spanned}
+    DevPtr<uint32_t> tbase;           // [tile][kNbMax]: records of the lower tiles in the bucket
+    DevPtr<uint32_t> bucket_pub;      // [bucket]: its voxel count + 1 once known (0 = not yet)
     // dense cell grid (null when the context was created without it)
     DevPtr<uint8_t> cflag;            // one byte per grid cell: occupied?  all zero between frames
     DevPtr<uint2> cmap;               // per 32 cells: {occupancy bits, occupied cells before this word}
@@ -262,6 +271,25 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int i = 0; i < kWavesPerBlock; ++i) {
+        const uint32_t t = s_w[i];
+        if ((uint32_t)i < w) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// The same for a block of NW waves (s_w: NW words of LDS).
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan_n(uint32_t v, uint32_t* s_w, uint32_t* total) {
+    const uint32_t incl = wave_incl_scan(v);
+    const uint32_t w = threadIdx.x / kWave;
+    __syncthreads();
+    if (lane_id() == kWave - 1) s_w[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
         const uint32_t t = s_w[i];
         if ((uint32_t)i < w) base += t;
         tot += t;

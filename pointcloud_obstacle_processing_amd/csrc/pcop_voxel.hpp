@@ -74,7 +74,7 @@ __global__ void k_frame_init(Frame* frames) {
         s.min_cluster = a.min_cluster; s.max_cluster = a.max_cluster;
         s.src_x = a.src_x; s.src_y = a.src_y; s.src_z = a.src_z;
         s.debug_skip_union = a.debug_skip_union;
-        s.vcap = a.vcap; s.cgrid_req = a.cell_grid;
+        s.nb_cap = a.nb_cap; s.gbits = a.gbits; s.cgrid_req = a.cell_grid;
         if (a.kind == kFrameClusterOnly) {   // no voxel stage: cluster the input cloud as it is
             s.c_from_input = 1; s.c_n = a.n; s.n_valid = a.n;
             uint32_t cap = 1024;
@@ -152,10 +152,11 @@ __device__ __forceinline__ void voxel_setup(DevState* st, const MinMaxPartial& p
     const uint64_t cells = (uint64_t)(uint32_t)div[0] * (uint32_t)div[1] * (uint32_t)div[2];
     const uint32_t kb = cells > 0xFFFFFFFFull ? 32u : bits_for(cells);
     const bool fits = make_plan(&st->plan_voxel, kb, npass, maxbits);
-    if (stream) {
-        if (cells > (uint64_t)kVmapCells) { atomicOr(&st->err, (uint32_t)kErrReplanPath); return; }
+    if (stream) {   // coarse bins of the streaming path: the top gbits bits of the key
         st->vpath = 1u;
-        st->vmap_words = (uint32_t)((cells + 31u) / 32u);
+        st->gbits = min(kb, st->gbits);   // on entry: the host's hint
+        st->cshift = kb - st->gbits;
+        if ((kBucketCells >> st->cshift) == 0u) atomicOr(&st->err, (uint32_t)kErrReplanBins);   // one bin spans more cells than a bucket may
     } else if (!fits) {
         atomicOr(&st->err, (uint32_t)kErrReplanVoxel);
     }
@@ -246,11 +247,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t 
         return;
     }
     if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass, maxbits, stream != 0u);
-    if (stream) {   // k_occ_scan<0> publishes its tile counts in vtile
-        uint32_t* __restrict__ vtile = F.vtile;
-        for (uint32_t t = threadIdx.x; t < kVmapCells / 32u / kVmapTile; t += kBlock) vtile[t] = 0u;
-        return;
-    }
+    if (stream) return;
     // k_voxel_reduce publishes "heads of tile t, plus one" here; zero = not yet published
     uint32_t* __restrict__ tile_heads = F.tile_a;
     const uint32_t ntiles = (st->n_in + kScanTile - 1) / kScanTile;
@@ -327,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_hist(const Frame* frames, int 
     for (uint32_t b = threadIdx.x; b < pi.nb; b += kBlock) table[(size_t)b * ntiles + blockIdx.x] = s_h[b];
 }
 
-// which = 0: voxel partition pass, 1: bucket partition of the streaming voxel path, 2: CSR partition pass
+// which = 0: voxel partition pass, 2: CSR partition pass
 __device__ __forceinline__ bool table_dims(const DevState* st, int which, int pass, uint32_t* ntiles, uint32_t* nb) {
     if (st->err) return false;
     if (which == 2) {
@@ -337,12 +334,6 @@ __device__ __forceinline__ bool table_dims(const DevState* st, int which, int pa
         return st->n_kept != 0;
     }
     if (voxel_stage_off(st)) return false;
-    if (which == 1) {   // the bucket partition of the streaming voxel path
-        if (!st->vpath || st->n_valid == 0) return false;
-        *nb = st->nbuckets + 1u;
-        *ntiles = (st->n_in + kTile - 1) / kTile;
-        return true;
-    }
     const PassInfo pi = pass_info(st, pass);
     *nb = pi.nb;
     *ntiles = (pi.count + kTile - 1) / kTile;
@@ -657,44 +648,568 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------
-// Streaming voxel path (default when the voxel grid has at most kVmapCells cells and the frame at
-// most kStreamBuckets * kVcapMax voxels; otherwise the host re-runs the frame on the sort path).
+// Streaming voxel path (default; a frame it does not fit is re-run on the sort path).
 //
-// PCL sorts the points by voxel key and sums every run in order.  What that needs is (a) the
-// rank of every occupied voxel in key order and (b) for every voxel its points in index order.
-//   k_vox_mark     : key of every point; one byte per grid cell set for the occupied ones
-//   k_occ_scan<0>  : bytes -> occupancy bits + running popcount  =>  voxel id = rank in key order, M
-//   k_vid_hist / k_table_scan / k_vid_scatter : ONE stable 8-bit partition of {x,y,z,id} records
-//                    by bucket = id >> vshift (up to 256 buckets of up to vcap voxels)
-//   k_voxel_stream : one wave per bucket walks the bucket's records in order (= index order) and
-//                    adds each to its voxel's accumulator in LDS, starting from 0.0f; lanes that
-//                    hit the same voxel in one step go in lane order.  cen[id] = sum / float(count).
-// Same float operations in the same order as the sort path, at about half of its HBM traffic.
+// PCL sorts the points by voxel key and sums every run in order.  What that needs is every voxel's points
+// together, in index order, and the voxels in key order - not a full sort of the cloud in HBM:
+//   k_bin_hist      : per tile of kBinTile points, the counts of the coarse key bins (key >> cshift, at most
+//                     2^kBinBitsMax of them) in an LDS histogram -> ctab[tile][bin]
+//   k_bin_plan      : one block per frame: bin totals, then buckets = runs of consecutive bins with at most
+//                     kBucketCap points and kBucketCells cells each (a bin above half the capacity stands alone,
+//                     the others are grouped by windows of their running sum) -> bin2bucket, binfo
+//   k_bin_offsets   : per (tile, bucket) the points of the lower tiles -> tbase
+//   k_bin_scatter   : ONE stable partition of packed 12-byte xyz records by bucket (peer masks through LDS,
+//                     per-wave counts, chunks of kScatChunk points staged in LDS so that stores are contiguous)
+//   k_bucket_reduce : a bucket lives in LDS: occupancy bits of its key range -> local voxel ids (rank of the key),
+//                     stable counting sort by id, one lane per voxel sums its run in order from 0.0f and divides
+//                     by float(count); buckets publish their voxel counts and add up the lower ones -> output rank.
+// Same float operations in the same order as the sort path.  No global atomics, no scattered global access: the
+// cloud is read three times (bounds, histogram, partition), written once and read once as 12-byte records.
+// Any bucket plan that respects the two limits gives the same result, so the host may tune gbits freely.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool stream_off(const DevState* st) {
     return voxel_stage_off(st) || !st->vpath || st->n_valid == 0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_vox_mark(const Frame* frames) {
-    const Frame& F = frames[blockIdx.y];
-    const DevState* st = &F.st;
-    uint8_t* __restrict__ vflag = F.vflag; uint32_t* __restrict__ vkey = F.vkey;
+__global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_dyn);
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    uint16_t* __restrict__ ctab = F.ctab;
     if (stream_off(st)) return;
-    const float* __restrict__ x = st->src_x; const float* __restrict__ y = st->src_y; const float* __restrict__ z = st->src_z;
     const uint32_t n = st->n_in;
+    const uint32_t tile_base = blockIdx.x * kBinTile;
+    if (tile_base >= n) return;
+    const uint32_t G = 1u << st->gbits, cs = st->cshift;
+    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) s_hist[b] = 0u;
+    __syncthreads();
+    const float* __restrict__ x = st->src_x; const float* __restrict__ y = st->src_y; const float* __restrict__ z = st->src_z;
     const bool drop = st->is_dense == 0;
     VoxelKey key; key.init(st);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        Rec3 r; r.x = x[i]; r.y = y[i]; r.z = z[i];
-        uint32_t k = kNoKey;
-        if (!drop || finite3(r.x, r.y, r.z)) {
-            k = key(r);
-            vflag[k] = 1;   // every writer stores the same value: no atomic needed
+    bool bad = false;
+    constexpr int kRound = 8;   // records in flight per thread
+#pragma unroll
+    for (uint32_t r0 = 0; r0 < kBinTile / kBinThreads; r0 += kRound) {
+        Rec3 r[kRound];
+#pragma unroll
+        for (int k = 0; k < kRound; ++k) {   // clamped, unconditional loads
+            const uint32_t i = min(tile_base + (r0 + k) * kBinThreads + threadIdx.x, n - 1u);
+            r[k].x = x[i]; r[k].y = y[i]; r[k].z = z[i];
         }
-        vkey[i] = k;
+#pragma unroll
+        for (int k = 0; k < kRound; ++k) {
+            const uint32_t i = tile_base + (r0 + k) * kBinThreads + threadIdx.x;
+            if (i < n && (!drop || finite3(r[k].x, r[k].y, r[k].z))) {
+                const uint32_t bin = key(r[k]) >> cs;
+                if (bin < G) atomicAdd(&s_hist[bin], 1u); else bad = true;
+            }
+        }
+    }
+    if (bad) atomicOr(&st->err, (uint32_t)kErrInternal);   // a key beyond the grid: never (the keys are those PCL computes)
+    __syncthreads();
+    uint16_t* __restrict__ row = ctab + (size_t)blockIdx.x * G;
+    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has 16384 points: fits
+}
+
+// One block per frame.  Thread t owns the `per` consecutive bins starting at t * per.
+__global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    constexpr int NW = kBinThreads / kWave;
+    constexpr uint32_t kHalf = kBucketCap / 2u;
+    constexpr int kPerMax = (1 << kBinBitsMax) / kBinThreads;   // 16
+    __shared__ uint32_t s_w[NW];
+    __shared__ uint32_t s_max[NW];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const uint16_t* __restrict__ ctab = F.ctab;
+    uint16_t* __restrict__ bin2bucket = F.bin2bucket;
+    uint4* __restrict__ binfo = F.binfo;
+    uint32_t* __restrict__ bucket_pub = F.bucket_pub;
+    if (stream_off(st)) return;
+    const uint32_t G = 1u << st->gbits, cs = st->cshift;
+    const uint32_t ntiles = (st->n_in + kBinTile - 1u) / kBinTile;
+    const uint32_t per = G >= kBinThreads ? G / kBinThreads : 1u;
+    // LDS: exclusive prefix of the bin totals (G + 1 words), first bin of every segment (G + 1 halves), bucket of every segment (G halves)
+    uint32_t* s_P = reinterpret_cast<uint32_t*>(s_dyn);
+    uint16_t* s_first = reinterpret_cast<uint16_t*>(s_dyn + ((size_t)G + 1u) * 4u);
+    uint16_t* s_segb = s_first + G + 2u;
+    const uint32_t b0 = threadIdx.x * per;
+    const bool mine = b0 < G;
+    for (uint32_t q = threadIdx.x; q < kNbMax; q += kBinThreads) bucket_pub[q] = 0u;   // k_bucket_reduce publishes here
+    // bin totals over the tiles
+    uint32_t c[kPerMax];
+#pragma unroll
+    for (int k = 0; k < kPerMax; ++k) c[k] = 0u;
+    if (mine) {
+        if (per == 16u) {
+#pragma unroll 4
+            for (uint32_t t = 0; t < ntiles; ++t) {
+                const uint4* q = reinterpret_cast<const uint4*>(ctab + (size_t)t * G + b0);
+                const uint4 a = q[0], b = q[1];
+                const uint32_t wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { c[2 * k] += wv[k] & 0xFFFFu; c[2 * k + 1] += wv[k] >> 16; }
+            }
+        } else if (per == 8u) {
+#pragma unroll 4
+            for (uint32_t t = 0; t < ntiles; ++t) {
+                const uint4 a = *reinterpret_cast<const uint4*>(ctab + (size_t)t * G + b0);
+                const uint32_t wv[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { c[2 * k] += wv[k] & 0xFFFFu; c[2 * k + 1] += wv[k] >> 16; }
+            }
+        } else {
+            for (uint32_t t = 0; t < ntiles; ++t) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((uint32_t)k < per) c[k] += ctab[(size_t)t * G + b0 + k];
+            }
+        }
+    }
+    uint32_t csum = 0u, cmax = 0u;
+#pragma unroll
+    for (int k = 0; k < kPerMax; ++k) { csum += c[k]; cmax = max(cmax, c[k]); }
+    uint32_t total;
+    uint32_t run = block_excl_scan_n<NW>(csum, s_w, &total);
+    cmax = wave_max(cmax);
+    if (lane_id() == 0) s_max[threadIdx.x / kWave] = cmax;
+    if (mine) {
+        uint32_t r = run;
+#pragma unroll
+        for (int k = 0; k < kPerMax; ++k)
+            if ((uint32_t)k < per) { s_P[b0 + k] = r; r += c[k]; }
+    }
+    if (threadIdx.x == 0) s_P[G] = total;
+    __syncthreads();
+    uint32_t maxbin = 0u;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) maxbin = max(maxbin, s_max[i]);
+    if (threadIdx.x == 0) st->maxbin = maxbin;
+    const uint32_t bmax = min(G, kBucketCells >> cs);   // bins a bucket may span (>= 1: k_voxel_setup checked)
+    if (maxbin > kBucketCap || bmax == 0u) {            // bins too coarse for this cloud: the host asks for finer ones
+        if (threadIdx.x == 0) atomicOr(&st->err, (uint32_t)kErrReplanBins);
+        return;
+    }
+    // running sum of the light bins (at most half a bucket each)
+    uint32_t lsum = 0u;
+#pragma unroll
+    for (int k = 0; k < kPerMax; ++k) lsum += c[k] <= kHalf ? c[k] : 0u;
+    uint32_t ltot;
+    uint32_t lrun = block_excl_scan_n<NW>(lsum, s_w, &ltot);
+    // segment starts: a multiple of bmax; a heavy bin; the bin after a heavy bin; a new window of the light sum
+    uint32_t startbits = 0u, nstart = 0u;
+    if (mine) {
+        uint32_t cprev = b0 ? s_P[b0] - s_P[b0 - 1u] : 0u;
+        uint32_t lx = lrun;                                              // light sum before bin b0 + k
+        uint32_t lprev = lx - (cprev <= kHalf ? cprev : 0u);            // ... before bin b0 + k - 1
+#pragma unroll
+        for (int k = 0; k < kPerMax; ++k) {
+            if ((uint32_t)k < per) {
+                const uint32_t b = b0 + k;
+                const bool s = b == 0u || (b % bmax) == 0u || c[k] > kHalf || cprev > kHalf || (lx / kHalf) != (lprev / kHalf);
+                if (s) { startbits |= 1u << k; ++nstart; }
+                cprev = c[k]; lprev = lx; lx += c[k] <= kHalf ? c[k] : 0u;
+            }
+        }
+    }
+    uint32_t nseg;
+    uint32_t seg0 = block_excl_scan_n<NW>(nstart, s_w, &nseg);   // segments that start before bin b0
+    if (mine) {
+        uint32_t sidx = seg0;
+#pragma unroll
+        for (int k = 0; k < kPerMax; ++k)
+            if ((uint32_t)k < per && ((startbits >> k) & 1u)) s_first[sidx++] = (uint16_t)(b0 + k);
+    }
+    if (threadIdx.x == 0) s_first[nseg] = (uint16_t)G;   // G <= 2^14 fits
+    __syncthreads();
+    // buckets = the segments that hold points, numbered in order
+    uint32_t nfull = 0u, fullbits = 0u;
+    if (mine) {
+        uint32_t sidx = seg0;
+#pragma unroll
+        for (int k = 0; k < kPerMax; ++k) {
+            if ((uint32_t)k < per && ((startbits >> k) & 1u)) {
+                const uint32_t nxt = s_first[sidx + 1u];
+                if (s_P[nxt] - s_P[b0 + k] > 0u) { fullbits |= 1u << k; ++nfull; }
+                ++sidx;
+            }
+        }
+    }
+    uint32_t nb;
+    uint32_t bk0 = block_excl_scan_n<NW>(nfull, s_w, &nb);
+    if (threadIdx.x == 0) {
+        st->nbuckets = nb;
+        if (nb > kNbMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
+        else if (nb > st->nb_cap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
+    }
+    if (nb > kNbMax) return;
+    if (mine) {
+        uint32_t sidx = seg0, bk = bk0;
+#pragma unroll
+        for (int k = 0; k < kPerMax; ++k) {
+            if ((uint32_t)k < per && ((startbits >> k) & 1u)) {
+                if ((fullbits >> k) & 1u) {
+                    const uint32_t b = b0 + k, nxt = s_first[sidx + 1u];
+                    binfo[bk] = make_uint4(s_P[b], s_P[nxt] - s_P[b], b << cs, (nxt - b) << cs);
+                    s_segb[sidx] = (uint16_t)bk;
+                    ++bk;
+                } else {
+                    s_segb[sidx] = 0u;
+                }
+                ++sidx;
+            }
+        }
+    }
+    __syncthreads();
+    if (mine) {   // bucket of every bin: that of its segment (bins of empty segments hold no points)
+        uint32_t sidx = seg0;   // segments started before b0; the segment of bin b0 + k is (starts up to and including it) - 1
+#pragma unroll
+        for (int k = 0; k < kPerMax; ++k) {
+            if ((uint32_t)k < per) {
+                if ((startbits >> k) & 1u) ++sidx;
+                bin2bucket[b0 + k] = s_segb[sidx - 1u];
+            }
+        }
     }
 }
 
+// One wave per bucket: tbase[tile][bucket] = points of the lower tiles in the bucket.
+__global__ __launch_bounds__(kWave) void k_bin_offsets(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint16_t* __restrict__ ctab = F.ctab;
+    const uint4* __restrict__ binfo = F.binfo;
+    uint32_t* __restrict__ tbase = F.tbase;
+    if (stream_off(st)) return;
+    const uint32_t b = blockIdx.x;
+    if (b >= st->nbuckets) return;
+    const uint32_t G = 1u << st->gbits, cs = st->cshift;
+    const uint32_t ntiles = (st->n_in + kBinTile - 1u) / kBinTile;
+    const uint4 info = binfo[b];
+    const uint32_t first = info.z >> cs, nbins = info.w >> cs;
+    uint32_t carry = 0u;
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += kWave) {
+        const uint32_t t = t0 + lane_id();
+        uint32_t cnt = 0u;
+        if (t < ntiles) {
+            const uint16_t* __restrict__ row = ctab + (size_t)t * G + first;
+            for (uint32_t k = 0; k < nbins; ++k) cnt += row[k];
+        }
+        const uint32_t incl = wave_incl_scan(cnt);
+        if (t < ntiles) tbase[(size_t)t * kNbMax + b] = carry + incl - cnt;
+        carry += __shfl(incl, kWave - 1, kWave);
+    }
+}
+
+// Peers of this lane's value among the active lanes of the wave, through two peer-mask words in LDS: one indexed
+// by the low 6 bits of the value, one by the bits above (fewer than 64 values).  Lanes that share both words hold
+// the same value.  All words are zero on entry and are left zero (every lane clears its own two, unconditionally, so
+// nothing waits for the reads).  A wave's LDS operations execute in program order.
+__device__ __forceinline__ uint64_t match_split_lds(unsigned long long* m_lo, unsigned long long* m_hi, uint32_t d, bool active) {
+    unsigned long long plo = 0ull, phi = 0ull;
+    const unsigned long long bit = 1ull << lane_id();
+    if (active) { atomicOr(m_lo + (d & 63u), bit); atomicOr(m_hi + (d >> 6), bit); }
+    __builtin_amdgcn_wave_barrier();
+    if (active) { plo = m_lo[d & 63u]; phi = m_hi[d >> 6]; }
+    __builtin_amdgcn_wave_barrier();
+    if (active) { m_lo[d & 63u] = 0ull; m_hi[d >> 6] = 0ull; }
+    __builtin_amdgcn_wave_barrier();
+    return plo & phi;
+}
+
+// Dynamic LDS of k_bin_scatter for nbc buckets.
+__host__ __device__ constexpr size_t scatter_lds_bytes(uint32_t nbc) {
+    return (size_t)kScatChunk * 12u + (size_t)kScatChunk * 2u + (size_t)nbc * (4u + 12u + 2u) + 8u + 4u * (kScatThreads / kWave + 1u);
+}
+
+__global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    constexpr uint32_t NW = kScatThreads / kWave;   // 8 waves; a wave ranks 512 consecutive points of a chunk
+    constexpr uint32_t NWW = (NW + 2u) / 3u;        // per bucket: the waves' counts, three 10-bit fields per word
+    constexpr uint32_t kMatchWords = 128u;          // per wave: 64 words for the low 6 bits of the bucket, 64 for the high 6
+    static_assert(kScatItems * kWave <= 1023u, "a wave's count of one bucket fits 10 bits");
+    static_assert(NW * kMatchWords * 8u <= kScatChunk * 12u, "the peer masks fit the staging area");
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const uint16_t* __restrict__ bin2bucket = F.bin2bucket;
+    const uint4* __restrict__ binfo = F.binfo;
+    const uint32_t* __restrict__ tbase = F.tbase;
+    Rec3* __restrict__ out = reinterpret_cast<Rec3*>(F.rec_a.get());
+    if (stream_off(st)) return;
+    const uint32_t n = st->n_in;
+    const uint32_t tile_base = blockIdx.x * kBinTile;
+    if (tile_base >= n) return;
+    const uint32_t nbc = st->nb_cap, nb = st->nbuckets, G = 1u << st->gbits, cs = st->cshift;
+    Rec3* stage = reinterpret_cast<Rec3*>(s_dyn);
+    unsigned long long* s_match = reinterpret_cast<unsigned long long*>(s_dyn);   // shares the staging area (used in turns)
+    uint16_t* sbkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kScatChunk * 12u);
+    uint32_t* cur = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kScatChunk * 14u);
+    uint32_t* wcnt = cur + nbc;
+    uint16_t* lbase = reinterpret_cast<uint16_t*>(wcnt + (size_t)NWW * nbc);
+    uint32_t* s_w = reinterpret_cast<uint32_t*>(lbase + nbc + 4u);
+    const float* __restrict__ x = st->src_x; const float* __restrict__ y = st->src_y; const float* __restrict__ z = st->src_z;
+    const bool drop = st->is_dense == 0;
+    VoxelKey key; key.init(st);
+    const uint32_t w = threadIdx.x / kWave, lane = lane_id();
+    const uint32_t wword = w / 3u, wshift = 10u * (w % 3u);
+    // where this tile's points start in every bucket
+    for (uint32_t b = threadIdx.x; b < nb; b += kScatThreads) cur[b] = binfo[b].x + tbase[(size_t)blockIdx.x * kNbMax + b];
+    const uint32_t pb = nbc / kScatThreads;   // buckets per thread in the per-bucket steps: 2, 4 or 8 consecutive ones
+    unsigned long long* m_lo = s_match + w * kMatchWords;
+    unsigned long long* m_hi = m_lo + 64u;
+    for (uint32_t ch = 0; ch < kBinTile / kScatChunk; ++ch) {
+        const uint32_t cbase = tile_base + ch * kScatChunk;
+        if (cbase >= n) break;
+        for (uint32_t i = threadIdx.x; i < NW * kMatchWords; i += kScatThreads) s_match[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < NWW * nbc; i += kScatThreads) wcnt[i] = 0u;
+        const uint32_t wbase = cbase + w * (kScatItems * kWave) + lane;
+        Rec3 rec[kScatItems];
+        uint32_t bin[kScatItems], bkt[kScatItems], rank[kScatItems];
+        bool act[kScatItems];
+#pragma unroll
+        for (uint32_t j = 0; j < kScatItems; ++j) {
+            const uint32_t i = min(wbase + j * kWave, n - 1u);
+            rec[j].x = x[i]; rec[j].y = y[i]; rec[j].z = z[i];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kScatItems; ++j) {
+            act[j] = wbase + j * kWave < n && (!drop || finite3(rec[j].x, rec[j].y, rec[j].z));
+            const uint32_t bn = act[j] ? key(rec[j]) >> cs : 0u;
+            bin[j] = min(bn, G - 1u);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kScatItems; ++j) bkt[j] = bin2bucket[bin[j]];   // all requested before any is used
+        __syncthreads();
+        // ranks inside (wave, bucket): stable by construction (steps in order, lanes in order)
+#pragma unroll
+        for (uint32_t j = 0; j < kScatItems; ++j) {
+            const uint32_t d = bkt[j];
+            const uint64_t peers = match_split_lds(m_lo, m_hi, d, act[j]);
+            const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
+            uint32_t old = 0u;
+            if (act[j] && lr == 0u) old = atomicAdd(&wcnt[wword * nbc + d], (uint32_t)__popcll(peers) << wshift);
+            const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
+            old = __shfl(old, leader, kWave);
+            rank[j] = ((old >> wshift) & 1023u) + lr;
+        }
+        __syncthreads();
+        // per bucket: points of the chunk, start inside the staged chunk
+        uint32_t tot[8];
+        uint32_t tsum = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            tot[k] = 0u;
+            if (k < pb) {
+                const uint32_t b = threadIdx.x * pb + k;
+#pragma unroll
+                for (uint32_t q = 0; q < NWW; ++q) {
+                    const uint32_t v = wcnt[q * nbc + b];
+                    tot[k] += (v & 1023u) + ((v >> 10) & 1023u) + ((v >> 20) & 1023u);
+                }
+            }
+            tsum += tot[k];
+        }
+        uint32_t ctot;
+        uint32_t lrun = block_excl_scan_n<NW>(tsum, s_w, &ctot);
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+            if (k < pb) { lbase[threadIdx.x * pb + k] = (uint16_t)lrun; lrun += tot[k]; }
+        __syncthreads();
+        // stage the chunk in output order (bucket-major, stable inside a bucket)
+#pragma unroll
+        for (uint32_t j = 0; j < kScatItems; ++j) {
+            if (act[j]) {
+                const uint32_t d = bkt[j];
+                uint32_t woff = 0u;   // points of the lower waves in this bucket
+#pragma unroll
+                for (uint32_t q = 0; q < NWW; ++q) {
+                    const uint32_t v = wcnt[q * nbc + d];
+                    const uint32_t f0 = v & 1023u, f1 = (v >> 10) & 1023u, f2 = (v >> 20) & 1023u;
+                    if (q < wword) woff += f0 + f1 + f2;
+                    else if (q == wword) woff += (wshift >= 10u ? f0 : 0u) + (wshift >= 20u ? f1 : 0u);
+                }
+                const uint32_t slot = (uint32_t)lbase[d] + woff + rank[j];
+                stage[slot] = rec[j];
+                sbkt[slot] = (uint16_t)d;
+            }
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < ctot; e += kScatThreads) {
+            const Rec3 r = stage[e];
+            const uint32_t d = sbkt[e];
+            out[cur[d] + (e - (uint32_t)lbase[d])] = r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+            if (k < pb) cur[threadIdx.x * pb + k] += tot[k];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
+    constexpr uint32_t NW = kBlock / kWave;                    // 4 waves; a wave ranks 512 consecutive points of the bucket
+    constexpr uint32_t kItemsB = kBucketCap / kBlock;          // 8
+    constexpr uint32_t kMapWords = kBucketCells / 32u;         // 4096
+    constexpr uint32_t kPerW = kMapWords / kBlock;             // at most 16 occupancy words per thread
+    static_assert(kBucketCap * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kBucketCap * 12u];   // occupancy bits + running counts, then the staged records
+    __shared__ uint32_t s_wc[2u * kBucketCap];                 // per voxel: counts of waves 0,1 (low / high half) and of waves 2,3
+    __shared__ uint16_t s_run[kBucketCap + 2u];                // per voxel: start of its run in the staged bucket
+    __shared__ unsigned long long s_match[NW * 96u];           // per wave: 64 + 32 peer-mask words (voxel ids below 2048)
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const uint4* __restrict__ binfo = F.binfo;
+    const Rec3* __restrict__ recs = reinterpret_cast<const Rec3*>(F.rec_a.get());
+    uint32_t* __restrict__ bucket_pub = F.bucket_pub;
+    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
+    if (stream_off(st)) return;
+    const uint32_t b = blockIdx.x, nb = st->nbuckets;
+    if (b >= nb) return;
+    const uint4 info = binfo[b];   // {first record, records, first key, keys spanned}
+    const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(s_mem);
+    uint16_t* wpre = reinterpret_cast<uint16_t*>(s_mem + kMapWords * 4u);
+    Rec3* stage = reinterpret_cast<Rec3*>(s_mem);
+    const uint32_t words = (span + 31u) / 32u;
+    bool bad = cnt == 0u || cnt > kBucketCap || span > kBucketCells;   // never: k_bin_plan keeps both limits
+    const uint32_t w = threadIdx.x / kWave, lane = lane_id();
+    for (uint32_t i = threadIdx.x; i < min(words, kMapWords); i += kBlock) bitmap[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < 2u * kBucketCap; i += kBlock) s_wc[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < NW * 96u; i += kBlock) s_match[i] = 0ull;
+    VoxelKey key; key.init(st);
+    Rec3 rec[kItemsB];
+    uint32_t lk[kItemsB], id[kItemsB], rank[kItemsB];
+    bool act[kItemsB];
+    const uint32_t pbase = w * (kItemsB * kWave) + lane;   // position in the bucket = index order
+    const uint32_t last = bad ? 0u : cnt - 1u;
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) rec[j] = recs[info.x + min(pbase + j * kWave, last)];
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) {
+        lk[j] = key(rec[j]) - key_lo;
+        act[j] = !bad && pbase + j * kWave < cnt;
+        if (act[j] && lk[j] >= span) { bad = true; act[j] = false; }
+    }
+    bad = __syncthreads_or(bad ? 1 : 0) != 0;
+    if (bad) {   // publish nothing-but-present, so that the higher buckets do not wait
+        if (threadIdx.x == 0) { atomicOr(&st->err, (uint32_t)kErrInternal); st_agent(bucket_pub + b, 1u); }
+        return;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j)
+        if (act[j]) atomicOr(&bitmap[lk[j] >> 5], 1u << (lk[j] & 31u));
+    __syncthreads();
+    // running count of the occupied cells: thread t owns the perw consecutive words from t * perw
+    const uint32_t perw = (words + kBlock - 1u) / kBlock;   // 1 .. 16
+    uint32_t wv[kPerW];
+    uint32_t c = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kPerW; ++k) {
+        const uint32_t wi = threadIdx.x * perw + k;
+        wv[k] = (k < perw && wi < words) ? bitmap[wi] : 0u;
+        c += __popc(wv[k]);
+    }
+    uint32_t nvox;
+    uint32_t run = block_excl_scan(c, s_w, &nvox);
+    if (threadIdx.x == 0) st_agent(bucket_pub + b, nvox + 1u);   // publish: the higher buckets add this up
+#pragma unroll
+    for (uint32_t k = 0; k < kPerW; ++k) {
+        const uint32_t wi = threadIdx.x * perw + k;
+        if (k < perw && wi < words) wpre[wi] = (uint16_t)run;
+        run += __popc(wv[k]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) {   // local voxel id = occupied cells of the bucket before this one
+        const uint32_t wi = act[j] ? lk[j] >> 5 : 0u;
+        id[j] = (uint32_t)wpre[wi] + __popc(bitmap[wi] & ((1u << (lk[j] & 31u)) - 1u));
+    }
+    __syncthreads();   // the occupancy words are done with: the staging area may be written from here on
+    // ranks inside (wave, voxel)
+    unsigned long long* m_lo = s_match + w * 96u;
+    unsigned long long* m_hi = m_lo + 64u;
+    const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) {
+        const uint32_t d = act[j] ? id[j] : 0u;
+        const uint64_t peers = match_split_lds(m_lo, m_hi, d, act[j]);
+        const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
+        uint32_t old = 0u;
+        if (act[j] && lr == 0u) old = atomicAdd(&s_wc[wword * kBucketCap + d], (uint32_t)__popcll(peers) << wshift);
+        const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
+        old = __shfl(old, leader, kWave);
+        rank[j] = ((old >> wshift) & 0xFFFFu) + lr;
+    }
+    __syncthreads();
+    // run starts: thread t owns voxels t * 8 .. t * 8 + 7
+    uint32_t tot[kItemsB];
+    uint32_t tsum = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kItemsB; ++k) {
+        const uint32_t v = threadIdx.x * kItemsB + k;
+        const uint32_t a = s_wc[v], q = s_wc[kBucketCap + v];
+        tot[k] = (a & 0xFFFFu) + (a >> 16) + (q & 0xFFFFu) + (q >> 16);
+        tsum += tot[k];
+    }
+    uint32_t ttot;
+    uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
+#pragma unroll
+    for (uint32_t k = 0; k < kItemsB; ++k) { s_run[threadIdx.x * kItemsB + k] = (uint16_t)srun; srun += tot[k]; }
+    if (threadIdx.x == 0) s_run[kBucketCap] = (uint16_t)ttot;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) {
+        if (act[j]) {
+            const uint32_t d = id[j];
+            const uint32_t a = s_wc[d], q = s_wc[kBucketCap + d];
+            uint32_t woff = 0u;   // points of the lower waves in this voxel
+            if (w >= 1u) woff += a & 0xFFFFu;
+            if (w >= 2u) woff += a >> 16;
+            if (w >= 3u) woff += q & 0xFFFFu;
+            stage[(uint32_t)s_run[d] + woff + rank[j]] = rec[j];
+        }
+    }
+    __syncthreads();
+    // one lane per voxel: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count)
+    float ox[kItemsB], oy[kItemsB], oz[kItemsB];
+#pragma unroll
+    for (uint32_t k = 0; k < kItemsB; ++k) {
+        const uint32_t v = k * kBlock + threadIdx.x;
+        ox[k] = oy[k] = oz[k] = 0.0f;
+        if (v < nvox) {
+            const uint32_t s = s_run[v], e = s_run[v + 1u];
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            for (uint32_t q = s; q < e; ++q) { const Rec3 r = stage[q]; sx += r.x; sy += r.y; sz += r.z; }
+            const float fc = (float)(e - s);
+            ox[k] = sx / fc; oy[k] = sy / fc; oz[k] = sz / fc;
+        }
+    }
+    // voxels of the lower buckets (published early, so they are usually there by now; the wait is bounded)
+    uint32_t lower = 0u;
+    for (uint32_t t = threadIdx.x; t < b; t += kBlock) {
+        uint32_t v = ld_agent(bucket_pub + t), spins = 0u;
+        while (v == 0u) {
+            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
+            __builtin_amdgcn_s_sleep(2);
+            v = ld_agent(bucket_pub + t);
+        }
+        lower += v - 1u;
+    }
+    __syncthreads();   // s_w is reused
+    const uint32_t before = block_sum(lower, s_w);
+    if (threadIdx.x == 0 && b + 1u == nb) finish_voxel(st, before + nvox);   // the last bucket knows M
+#pragma unroll
+    for (uint32_t k = 0; k < kItemsB; ++k) {
+        const uint32_t v = k * kBlock + threadIdx.x;
+        if (v < nvox) { cx[before + v] = ox[k]; cy[before + v] = oy[k]; cz[before + v] = oz[k]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Occupancy scan of the dense cell grid (pcop_cells_grid.hpp): one byte per cell -> bits + running popcount.
+// ------------------------------------------------------------------------------------------
 // 16 flag bytes (each 0 or 1) -> 16 bits
 __device__ __forceinline__ uint32_t flags_to_bits(const uint4& v) {
     const uint32_t a = ((v.x & 0x01010101u) * 0x01020408u) >> 24, b = ((v.y & 0x01010101u) * 0x01020408u) >> 24;
@@ -704,34 +1219,24 @@ __device__ __forceinline__ uint32_t flags_to_bits(const uint4& v) {
 
 // One block per kVmapTile occupancy words: bytes -> bits (and the bytes are zeroed again for the
 // next frame), popcount scan; the tile publishes its count and adds up the counts of the lower
-// tiles (same publish / bounded-wait scheme as k_voxel_reduce).  The last tile knows the total.
-//   WHICH = 0: the voxel grid (k_vox_mark)   -> voxel ids, M, the bucket plan
-//   WHICH = 1: the dense cell grid (k_cell_mark) -> cell ids, n_cells
+// tiles (same publish / bounded-wait scheme as k_voxel_reduce).  The last tile knows the total: n_cells.
 __device__ __forceinline__ bool cluster_stage_off(const DevState* st);
 
-template <int WHICH>
 __global__ __launch_bounds__(kBlock) void k_occ_scan(Frame* frames) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     __shared__ uint16_t s_half[2 * kVmapTile];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
-    uint4* __restrict__ flags = reinterpret_cast<uint4*>(WHICH == 0 ? F.vflag.get() : F.cflag.get());
-    uint2* __restrict__ omap = WHICH == 0 ? F.vmap.get() : F.cmap.get();
-    uint32_t* __restrict__ otile = WHICH == 0 ? F.vtile.get() : F.ctile.get();
+    uint4* __restrict__ flags = reinterpret_cast<uint4*>(F.cflag.get());
+    uint2* __restrict__ omap = F.cmap.get();
+    uint32_t* __restrict__ otile = F.ctile.get();
     // Runs whenever the marking kernel ran (the replan bits this kernel raises itself must not stop its
     // other tiles: every tile has flag bytes to turn back to zero).
-    uint32_t words;
-    if (WHICH == 0) {
-        const uint32_t own = (uint32_t)(kErrReplanPath | kErrReplanVcap | kErrInternal);
-        if ((st->err & ~own) || st->passthrough || st->kind == kFrameClusterOnly || !st->vpath || st->n_valid == 0) return;
-        words = st->vmap_words;
-    } else {
-        const uint32_t own = (uint32_t)(kErrReplanCpath | kErrReplanCtiles | kErrInternal | kErrNonFinite);
-        if ((st->err & ~own) || st->trivial || st->kind == kFrameVoxelOnly || !st->cpath) return;
-        words = st->cmap_words;
-    }
+    const uint32_t own = (uint32_t)(kErrReplanCpath | kErrReplanCtiles | kErrInternal | kErrNonFinite);
+    if ((st->err & ~own) || st->trivial || st->kind == kFrameVoxelOnly || !st->cpath) return;
+    const uint32_t words = st->cmap_words;
     if (blockIdx.x == 0 && threadIdx.x == 0 && words > gridDim.x * kVmapTile)   // the host sized this grid from the previous frame
-        atomicOr(&st->err, (uint32_t)(WHICH == 0 ? kErrReplanVcap : kErrReplanCtiles));
+        atomicOr(&st->err, (uint32_t)kErrReplanCtiles);
     const uint32_t base = blockIdx.x * kVmapTile;
     if (base >= words) return;
     const uint32_t cnt = min(kVmapTile, words - base);
@@ -783,236 +1288,7 @@ __global__ __launch_bounds__(kBlock) void k_occ_scan(Frame* frames) {
         if (j < cnt) omap[base + j] = make_uint2(w[k], run);
         run += __popc(w[k]);
     }
-    if (threadIdx.x == 0 && base + kVmapTile >= words) {   // the last tile
-        const uint32_t m = before + tot;
-        if (WHICH == 0) {   // M and the bucket plan
-            finish_voxel(st, m);
-            uint32_t sh = 0;
-            while (((uint64_t)kStreamBuckets << sh) < (uint64_t)m) ++sh;   // 256 buckets of 2^sh voxels cover M
-            st->vshift = sh;
-            st->nbuckets = m ? ((m - 1u) >> sh) + 1u : 0u;
-            if ((1u << sh) > kVcapMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
-            else if ((1u << sh) > st->vcap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
-        } else {
-            st->n_cells = m;
-        }
-    }
-}
-
-// voxel id of a key: occupied cells before it in key order
-__device__ __forceinline__ uint32_t voxel_id(const uint2* __restrict__ vmap, uint32_t key) {
-    const uint2 e = vmap[key >> 5];
-    return e.y + __popc(e.x & ((1u << (key & 31u)) - 1u));
-}
-
-template <int MAXB>
-__global__ __launch_bounds__(kBlock) void k_vid_hist(const Frame* frames) {
-    __shared__ uint32_t s_h[(1 << MAXB) + 1];
-    const Frame& F = frames[blockIdx.y];
-    const DevState* st = &F.st;
-    uint32_t* __restrict__ table = F.table; uint32_t* __restrict__ vkey = F.vkey;
-    const uint2* __restrict__ vmap = F.vmap;
-    if (stream_off(st)) return;
-    const uint32_t n = st->n_in;
-    const uint32_t tile_base = blockIdx.x * kTile;
-    if (tile_base >= n) return;
-    const uint32_t nb = st->nbuckets + 1u, sh = st->vshift;
-    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) s_h[b] = 0;
-    __syncthreads();
-    const uint32_t wbase = tile_base + (threadIdx.x / kWave) * (kItems * kWave) + lane_id();
-    uint32_t k[kItems];
-#pragma unroll
-    for (int j = 0; j < kItems; ++j) { const uint32_t i = wbase + j * kWave; k[j] = i < n ? vkey[i] : kNoKey; }
-    // all occupancy words of the thread's records are requested before any is used (a dropped point reads word 0;
-    // a load under a branch would be waited for at the branch's join, one L2 round trip per record)
-    uint2 e[kItems];
-#pragma unroll
-    for (int j = 0; j < kItems; ++j) e[j] = vmap[k[j] != kNoKey ? k[j] >> 5 : 0u];
-#pragma unroll
-    for (int j = 0; j < kItems; ++j) {
-        const uint32_t i = wbase + j * kWave;
-        if (i < n) {
-            uint32_t d = nb - 1u;
-            if (k[j] != kNoKey) {
-                const uint32_t id = e[j].y + __popc(e[j].x & ((1u << (k[j] & 31u)) - 1u));
-                vkey[i] = id;   // key -> id, in place
-                d = id >> sh;
-            }
-            atomicAdd(&s_h[d], 1u);
-        }
-    }
-    __syncthreads();
-    const uint32_t ntiles = (n + kTile - 1) / kTile;
-    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) table[(size_t)b * ntiles + blockIdx.x] = s_h[b];
-}
-
-// The partition of the streaming path: records {x, y, z, id} go to rec_b, stable, bucket-major.
-template <int MAXB>
-__global__ __launch_bounds__(kBlock) void k_vid_scatter(const Frame* frames) {
-    constexpr int kBins = (1 << MAXB) + 1;
-    __shared__ uint32_t s_hist[kWavesPerBlock * kBins];
-    __shared__ uint32_t s_base[kBins];
-    __shared__ uint32_t s_lbase[kBins];
-    __shared__ uint32_t s_delta[kBins];
-    __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    __shared__ float4 s_stage[kTile];
-    unsigned long long* s_match = reinterpret_cast<unsigned long long*>(s_stage);
-    static_assert(MAXB <= kNarrowBits, "the streaming path partitions on an 8-bit digit");
-    const Frame& F = frames[blockIdx.y];
-    const DevState* st = &F.st;
-    const uint32_t* __restrict__ table_x = F.table_x; const uint32_t* __restrict__ bin_total = F.bin_total;
-    const uint32_t* __restrict__ vkey = F.vkey;
-    float4* __restrict__ out = F.rec_b;
-    if (stream_off(st)) return;
-    const uint32_t n = st->n_in;
-    const uint32_t tile_base = blockIdx.x * kTile;
-    if (tile_base >= n) return;
-    const float* __restrict__ x = st->src_x; const float* __restrict__ y = st->src_y; const float* __restrict__ z = st->src_z;
-    const uint32_t nb = st->nbuckets + 1u, sh = st->vshift;
-    for (uint32_t b = threadIdx.x; b < kWavesPerBlock * nb; b += kBlock) s_hist[b] = 0;
-    for (uint32_t b = threadIdx.x; b < (uint32_t)(kWavesPerBlock * kBins); b += kBlock) s_match[b] = 0ull;
-    scan_bins_to_lds<MAXB>(bin_total, nb, s_base, s_w);   // ends with a barrier
-    const uint32_t w = threadIdx.x / kWave;
-    uint32_t* hist_w = s_hist + w * nb;
-    const uint32_t wbase = tile_base + w * (kItems * kWave) + lane_id();
-    float4 rec[kItems];
-    uint32_t dig[kItems], lrank[kItems];
-#pragma unroll
-    for (int j = 0; j < kItems; ++j) {
-        const uint32_t i = wbase + j * kWave;
-        if (i < n) rec[j] = make_float4(x[i], y[i], z[i], u2f(vkey[i]));
-    }
-#pragma unroll
-    for (int j = 0; j < kItems; ++j) {
-        const uint32_t i = wbase + j * kWave;
-        const bool active = i < n;
-        uint32_t d = 0;
-        if (active) { const uint32_t id = f2u(rec[j].w); d = id == kNoKey ? nb - 1u : id >> sh; }
-        const uint64_t peers = match_digit_lds(s_match + w * kBins, d, active);
-        const uint32_t rank = __popcll(peers & lanemask_lt());
-        uint32_t old = 0;
-        if (active) old = hist_w[d];
-        if (active && rank == 0) hist_w[d] = old + (uint32_t)__popcll(peers);
-        dig[j] = d; lrank[j] = old + rank;
-    }
-    __syncthreads();
-    const uint32_t ntiles = (n + kTile - 1) / kTile;
-    constexpr int kPer = (kBins + kBlock - 1) / kBlock;
-    uint32_t tcnt[kPer], gstart[kPer];
-    uint32_t tsum = 0;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const uint32_t b = threadIdx.x * kPer + k;
-        tcnt[k] = 0; gstart[k] = 0;
-        if (b < nb) {
-            uint32_t run = 0;
-#pragma unroll
-            for (int q = 0; q < kWavesPerBlock; ++q) {
-                const uint32_t t = s_hist[q * nb + b];
-                s_hist[q * nb + b] = run;
-                run += t;
-            }
-            tcnt[k] = run;
-            gstart[k] = s_base[b] + table_x[(size_t)b * ntiles + blockIdx.x];
-        }
-        tsum += tcnt[k];
-    }
-    uint32_t ttot;
-    uint32_t lrun = block_excl_scan(tsum, s_w, &ttot);
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const uint32_t b = threadIdx.x * kPer + k;
-        if (b < nb) { s_lbase[b] = lrun; s_delta[b] = gstart[k] - lrun; }
-        lrun += tcnt[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kItems; ++j) {
-        const uint32_t i = wbase + j * kWave;
-        if (i < n) s_stage[s_lbase[dig[j]] + hist_w[dig[j]] + lrank[j]] = rec[j];
-    }
-    __syncthreads();
-    for (uint32_t e = threadIdx.x; e < ttot; e += kBlock) {
-        const float4 v = s_stage[e];
-        const uint32_t id = f2u(v.w);
-        const uint32_t d = id == kNoKey ? nb - 1u : id >> sh;
-        out[e + s_delta[d]] = v;
-    }
-}
-
-// One block per bucket.  With kStreamWaves > 1 the bucket's voxels are dealt out to the block's waves
-// (voxel & (waves-1)) and every wave walks all of the bucket's records, accumulating the ones it owns;
-// measured on C3: 1 wave 66 us, 2 waves 70 us, 4 waves 77 us per batch - the kernel is bound by the chain of
-// LDS round trips of the longest bucket (about 8 per step), not by waves in flight, so one wave it is.
-// Dynamic LDS: float4 acc[vcap] {sum x, sum y, sum z, count} and unsigned long long peers[vcap].
-constexpr int kStreamWaves = 1;
-__global__ __launch_bounds__(kStreamWaves * kWave) void k_voxel_stream(const Frame* frames) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    const Frame& F = frames[blockIdx.y];
-    const DevState* st = &F.st;
-    const float4* __restrict__ rec = F.rec_b;
-    const uint32_t* __restrict__ bin_total = F.bin_total;
-    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
-    if (stream_off(st)) return;
-    const uint32_t b = blockIdx.x;
-    if (b >= st->nbuckets) return;
-    const uint32_t vcap = st->vcap, sh = st->vshift, m = st->m;
-    float4* acc = reinterpret_cast<float4*>(s_dyn);
-    unsigned long long* peers_w = reinterpret_cast<unsigned long long*>(s_dyn + (size_t)vcap * sizeof(float4));
-    const uint32_t lane = lane_id();
-    const uint32_t wv = threadIdx.x / kWave;
-    // records of the bucket: [start, start + count)
-    uint32_t before = 0;
-    for (uint32_t t = lane; t < b; t += kWave) before += bin_total[t];
-    const uint32_t start = wave_sum(before), count = bin_total[b];
-    const uint32_t id0 = b << sh;
-    const uint32_t nv = min(1u << sh, m - id0);   // voxels of this bucket
-    for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) { acc[v] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u)); peers_w[v] = 0ull; }
-    __syncthreads();
-    const uint32_t steps = (count + kWave - 1) / kWave;
-    // records two steps ahead are in flight while a step runs (clamped, unconditional loads: a load
-    // under a branch would be waited for at the branch's join)
-    const uint32_t last = start + count - 1u;
-    auto step = [&](const float4& r, uint32_t i) {
-        const uint32_t lv0 = f2u(r.w) - id0;
-        const bool active = i < count && (lv0 & (uint32_t)(kStreamWaves - 1)) == wv;   // this wave's voxels only
-        const uint32_t lv = active ? lv0 : 0u;
-        const uint64_t peers = match_digit_lds(peers_w, lv, active);
-        const uint32_t rank = active ? (uint32_t)__popcll(peers & lanemask_lt()) : 0xFFFFFFFFu;
-        for (uint32_t q = 0; __any(active && rank >= q); ++q) {   // same voxel: lane order = index order
-            if (rank == q) {
-                float4 a = acc[lv];
-                a.x += r.x; a.y += r.y; a.z += r.z; a.w = u2f(f2u(a.w) + 1u);
-                acc[lv] = a;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    };
-    // kStreamDepth register sets, each refilled right after it is consumed: a record is requested
-    // kStreamDepth - 1 steps (a few thousand cycles) before it is needed, and no set is ever copied
-    constexpr uint32_t kStreamDepth = 8;
-    float4 rs[kStreamDepth];
-#pragma unroll
-    for (uint32_t k = 0; k < kStreamDepth; ++k) {
-        rs[k] = rec[min(start + k * kWave + lane, last)];
-        __builtin_amdgcn_sched_barrier(0);   // keep the issue order = the order of use (the waits count loads in order)
-    }
-    for (uint32_t sidx = 0; sidx < steps; sidx += kStreamDepth) {
-#pragma unroll
-        for (uint32_t k = 0; k < kStreamDepth; ++k) {
-            const uint32_t i = (sidx + k) * kWave + lane;
-            if (sidx + k < steps) step(rs[k], i);   // wave-uniform
-            // not under the branch: a load issued inside it would be waited for at its join
-            rs[k] = rec[min(start + i + kStreamDepth * kWave, last)];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __syncthreads();
-    for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) {
-        const float4 a = acc[v];
-        const float fc = (float)f2u(a.w);
-        cx[id0 + v] = a.x / fc; cy[id0 + v] = a.y / fc; cz[id0 + v] = a.z / fc;
-    }
+    if (threadIdx.x == 0 && base + kVmapTile >= words) st->n_cells = before + tot;   // the last tile
 }
 
 }  // namespace pcop

@@ -229,9 +229,9 @@ def test_voxel_stage_sorted_records_are_stable(ctx, oracle):
     assert rec.tobytes() == pts[order].tobytes()
 
 
-def test_voxel_stage_stream_ids_and_records(ctx, oracle):
-    """Stage-wise, streaming path: every point's voxel id is the rank of its key among the occupied cells, the
-    partitioned records are ordered by (bucket, point index), and the occupancy flags are all zero again."""
+def test_voxel_stage_stream_buckets_and_records(ctx, oracle):
+    """Stage-wise, streaming path: the buckets are runs of consecutive coarse key bins within the two limits
+    (points, cells), they tile the cloud, and the partitioned 12-byte records are ordered by (bucket, point index)."""
     if ctx.voxel_path != "stream":
         pytest.skip("buffers of the streaming path")
     pts = synth.uniform_field(30_000, 9)
@@ -241,17 +241,21 @@ def test_voxel_stage_stream_ids_and_records(ctx, oracle):
     assert st.vpath == 1 and st.m > 0
     keys, grid, _ = oracle.voxel_keys(pts, 0.1)
     assert list(grid[:3]) == list(st.min_b) and list(grid[3:6]) == list(st.div_b)
-    uniq, ids_ref = np.unique(keys.astype(np.int64), return_inverse=True)
-    assert st.m == len(uniq)
-    ids = ctx.debug_buffer("vkey", np.uint32, len(pts))
-    assert np.array_equal(ids, ids_ref.astype(np.uint32))
-    assert st.nbuckets == ((st.m - 1) >> st.vshift) + 1 and st.nbuckets <= 256 and (1 << st.vshift) <= st.vcap
-    rec = ctx.debug_buffer("rec_b", np.float32, 4 * len(pts)).reshape(-1, 4)
-    order = np.lexsort((np.arange(len(pts)), ids_ref >> st.vshift))       # by bucket, ties by point index
-    assert rec[:, :3].tobytes() == pts[order].tobytes()
-    assert np.array_equal(rec[:, 3].copy().view(np.uint32), ids_ref[order].astype(np.uint32))
-    flags = ctx.debug_buffer("vflag", np.uint8, 1 << 26)
-    assert not flags.any()
+    assert st.m == len(np.unique(keys))
+    nb = st.nbuckets
+    info = ctx.debug_buffer("binfo", np.uint32, 4 * nb).reshape(-1, 4).astype(np.int64)   # first record, records, first key, keys
+    assert 1 <= nb <= st.nb_cap
+    assert info[0, 0] == 0 and np.array_equal(info[1:, 0], np.cumsum(info[:-1, 1])) and info[:, 1].sum() == len(pts)
+    assert (info[:, 1] >= 1).all() and (info[:, 1] <= 2048).all() and (info[:, 3] <= (1 << 17)).all()
+    assert (info[:, 2] % (1 << st.cshift) == 0).all() and (info[1:, 2] >= info[:-1, 2] + info[:-1, 3]).all()
+    k64 = keys.astype(np.int64)
+    bucket = np.searchsorted(info[:, 2], k64, side="right") - 1
+    assert (k64 < info[bucket, 2] + info[bucket, 3]).all()
+    b2b = ctx.debug_buffer("bin2bucket", np.uint16, 1 << st.gbits)
+    assert np.array_equal(b2b[k64 >> st.cshift], bucket.astype(np.uint16))
+    rec = ctx.debug_buffer("rec_a", np.float32, 3 * len(pts)).reshape(-1, 3)
+    order = np.lexsort((np.arange(len(pts)), bucket))                   # by bucket, ties by point index
+    assert rec.tobytes() == pts[order].tobytes()
 
 
 @pytest.mark.parametrize("cfg,n,mn,mx", [("C1", 10_000, 5, 20000), ("C1", 10_000, 1, 10**9), ("C2", 30_000, 5, 10**9),
@@ -443,12 +447,12 @@ def test_radix_replanning_and_digit_widths(capi, oracle, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------
-# streaming voxel path: its own re-planning (LDS per bucket, occupancy grid) and its fallbacks
+# streaming voxel path: its own re-planning (buckets provided for, coarse bins) and its fallback
 # ---------------------------------------------------------------------------------------------
 def test_stream_path_grows_and_falls_back(capi, oracle, monkeypatch):
     monkeypatch.setenv("PCOP_VOXEL_PATH", "stream")
     c = capi.Context(1_000_000)
-    # (1) small cloud: streaming path, smallest bucket size
+    # (1) small cloud: streaming path, smallest bucket provision
     p = synth.params_of("C3")
     pts = synth.make_cloud("C3", n=150_000, seed=5)
     c.set_params(publish_clouds=1, **p)
@@ -457,10 +461,10 @@ def test_stream_path_grows_and_falls_back(capi, oracle, monkeypatch):
     assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
     assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
     st = c.debug_state()
-    assert st.vpath == 1 and st.vcap == 512
-    # (2) more than 256 * 512 voxels: one re-run with more LDS per bucket, then it stays there
-    big = synth.make_cloud("C3L10", n=1_000_000, seed=3)
-    pl = synth.params_of("C3L10")
+    assert st.vpath == 1 and st.nb_cap == 1024 and st.nbuckets <= 1024
+    # (2) a million scattered points need more than 1024 buckets: one re-run with more of them, then it stays there
+    big = synth.uniform_field(1_000_000, 11) * f32(3.0)
+    pl = dict(leaf=0.02, tol=0.05, min_cluster=2, max_cluster=20000)
     c.set_params(publish_clouds=1, **pl)
     refb = oracle.process_xyz(big, **pl)
     for rep in range(2):
@@ -468,17 +472,18 @@ def test_stream_path_grows_and_falls_back(capi, oracle, monkeypatch):
         assert_same_cloud(got["voxel_xyz"], refb["voxel_xyz"])
         assert_same_clusters(got["offsets"], got["indices"], refb["offsets"], refb["indices"])
     st = c.debug_state()
-    assert st.vpath == 1 and st.m > 256 * 512 and st.vcap == 2048
+    assert st.vpath == 1 and st.nbuckets > 1024 and st.nb_cap >= st.nbuckets
     # (3) the small cloud again on the grown context
     c.set_params(publish_clouds=1, **p)
     got = c.process_xyz(pts)
     assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
     assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
-    # (4) more than 256 * 2048 voxels: falls back to the sort path (and stays on it for this leaf size)
-    dense = synth.uniform_field(700_000, 11) * f32(2.0)         # grid below 2^26 cells, voxels above 256 * 2048
-    c.set_params(publish_clouds=1, leaf=0.012, tol=0.05, min_cluster=2, max_cluster=20000)
-    refd = oracle.process_xyz(dense, leaf=0.012, tol=0.05, min_cluster=2, max_cluster=20000)
-    assert len(refd["voxel_xyz"]) > 256 * 2048
+    # (4) crowded voxels: more points in one voxel than a bucket holds, whatever the bins: sort path (and it stays
+    #     there for this leaf size)
+    dense = synth.uniform_field(300_000, 13) * f32(0.05)
+    pd = dict(leaf=0.05, tol=0.1, min_cluster=1, max_cluster=20000)
+    c.set_params(publish_clouds=1, **pd)
+    refd = oracle.process_xyz(dense, **pd)
     for rep in range(2):
         got = c.process_xyz(dense)
         assert_same_cloud(got["voxel_xyz"], refd["voxel_xyz"])
@@ -489,23 +494,40 @@ def test_stream_path_grows_and_falls_back(capi, oracle, monkeypatch):
     got = c.process_xyz(pts)
     assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
     assert c.debug_state().vpath == 1
-    assert not c.debug_buffer("vflag", np.uint8, 1 << 26).any()
     c.close()
 
 
-def test_stream_path_grid_too_large_falls_back(capi, oracle, monkeypatch):
-    """A voxel grid of more than 2^26 cells has no occupancy map: sort path, same answer."""
+@pytest.mark.parametrize("bits,n", [(11, 100_000), (12, 250_000), (13, 250_000), (14, 250_000)])
+def test_stream_path_any_bin_count_same_result(capi, oracle, monkeypatch, bits, n):
+    """The coarse bin count is a tuning knob: every value gives the same bytes."""
     monkeypatch.setenv("PCOP_VOXEL_PATH", "stream")
-    c = capi.Context(200_000)
-    pts = synth.uniform_field(100_000, 21) * f32(10.0)          # tens of metres at leaf 0.02: > 2^26 cells
-    c.set_params(publish_clouds=1, leaf=0.02, tol=0.1, min_cluster=2, max_cluster=20000)
-    ref = oracle.process_xyz(pts, leaf=0.02, tol=0.1, min_cluster=2, max_cluster=20000)
+    monkeypatch.setenv("PCOP_BIN_BITS", str(bits))
+    c = capi.Context(300_000)
+    p = synth.params_of("C3")
+    pts = synth.make_cloud("C3", n=n, seed=6)
+    c.set_params(publish_clouds=1, **p)
     got = c.process_xyz(pts)
+    ref = oracle.process_xyz(pts, **p)
     st = c.debug_state()
-    assert st.vpath == 0 and int(st.div_b[0]) * int(st.div_b[1]) * int(st.div_b[2]) > (1 << 26)
+    assert st.vpath == 1 and st.gbits == bits
     assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
     assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
-    assert not c.debug_buffer("vflag", np.uint8, 1 << 26).any()
+    c.close()
+
+
+def test_stream_path_huge_sparse_grid(capi, oracle, monkeypatch):
+    """A voxel grid of more than 2^26 cells (tens of metres at leaf 0.02): still the streaming path, same answer."""
+    monkeypatch.setenv("PCOP_VOXEL_PATH", "stream")
+    c = capi.Context(200_000)
+    pts = synth.uniform_field(100_000, 21) * f32(10.0)
+    c.set_params(publish_clouds=1, leaf=0.02, tol=0.1, min_cluster=2, max_cluster=20000)
+    ref = oracle.process_xyz(pts, leaf=0.02, tol=0.1, min_cluster=2, max_cluster=20000)
+    for rep in range(2):
+        got = c.process_xyz(pts)
+        st = c.debug_state()
+        assert int(st.div_b[0]) * int(st.div_b[1]) * int(st.div_b[2]) > (1 << 26)
+        assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
     c.close()
 
 

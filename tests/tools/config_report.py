@@ -40,6 +40,6 @@ for cfg in cfgs:
           "GPU latency %.3f ms, %8.1f frames/s (batch %d, 1 ctx) | oracle 1 core %.2f s = %.3f frames/s | voxel path %s, csr passes %d"
           % (cfg, n, got["num_voxels"], len(got["offsets"]) - 1, st.n_cells, ok_vox, err, ok_idx,
              1e3 * float(np.median(lat)), fps, B, t_or, 1.0 / t_or,
-             "stream (%d buckets x %d voxels)" % (st.nbuckets, 1 << st.vshift) if st.vpath else "sort (%d passes)" % st.plan_voxel.npass,
+             "stream (%d buckets, %d coarse bins)" % (st.nbuckets, 1 << st.gbits) if st.vpath else "sort (%d passes)" % st.plan_voxel.npass,
              st.plan_csr.npass), flush=True)
     ctx.close()
