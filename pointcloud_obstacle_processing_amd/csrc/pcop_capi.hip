@@ -33,6 +33,7 @@ inline bool compare_clusters(const ClusterRef& a, const ClusterRef& b) { return 
 struct GraphKey {
     uint32_t kind, bucket, npass_voxel, npass_csr, nframes;
     uint32_t stream, nb_cap, gbits;  // streaming voxel path: on?, buckets provided for (LDS, grids), log2 of the coarse bins (LDS)
+    // (lds_ordered is fixed for the life of a context: not part of the key)
     uint32_t cgrid, ctiles;          // dense cell grid: on?, occupancy tiles (grid)
     bool operator<(const GraphKey& o) const {
         if (cgrid != o.cgrid) return cgrid < o.cgrid;
@@ -106,6 +107,9 @@ struct pcop_ctx {
     uint32_t nb_cap = kNbMin;                               // buckets the launch provides LDS and blocks for (grows on demand)
     uint32_t gbits = 13;                                    // log2 of the coarse key bins (tuned from the fullest bin seen; any value gives the same result)
     bool gbits_fixed = false;                               // PCOP_BIN_BITS given: no tuning
+    // LDS atomic adds of one wave instruction return their old values in lane order on this device (checked by
+    // k_lds_order_probe when the context is made; PCOP_LDS_ORDER=0 skips the check and keeps the peer-mask ranks)
+    bool lds_ordered = false;
     // dense cell grid: on unless PCOP_CELL_PATH=hash; a frame whose grid exceeds kCmapCells is re-run on the hash
     // table and the context stays there until the tolerance changes
     bool cell_grid = true, cgrid_ok = true;
@@ -231,13 +235,26 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
             const size_t bins = (size_t)1 << c->gbits;
             k_bin_hist<<<bt, kBinThreads, bins * 4u, s>>>(fr);
             mark(c, "k_bin_hist");
-            k_bin_plan<<<dim3(1, nf), kBinThreads, bins * 8u + 16u, s>>>(fr);
+            k_bin_colsum<<<dim3((uint32_t)div_up((uint32_t)bins, kWave), nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_bin_colsum");
+            k_bin_plan<<<dim3(1, nf), kBinThreads, plan_lds_bytes((uint32_t)bins), s>>>(fr);
             mark(c, "k_bin_plan");
-            k_bin_offsets<<<dim3(c->nb_cap, nf), kWave, 0, s>>>(fr);
-            mark(c, "k_bin_offsets");
-            k_bin_scatter<<<bt, kScatThreads, scatter_lds_bytes(c->nb_cap), s>>>(fr);
+            k_bin_tilecnt<<<bt, kBlock, (bins + 8u) * 2u, s>>>(fr);
+            mark(c, "k_bin_tilecnt");
+            k_bin_colscan<<<dim3(div_up(c->nb_cap, kBlock), nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_bin_colscan");
+            if (c->lds_ordered) {
+                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, true><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr);
+                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, true><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr);
+                else k_bin_scatter<8, true><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr);
+            } else {
+                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, false><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr);
+                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, false><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr);
+                else k_bin_scatter<8, false><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr);
+            }
             mark(c, "k_bin_scatter");
-            k_bucket_reduce<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
+            if (c->lds_ordered) k_bucket_reduce<true><<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
+            else k_bucket_reduce<false><<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
             mark(c, "k_bucket_reduce");
         } else {
             for (uint32_t p = 0; p < c->npass_voxel; ++p) {
@@ -615,7 +632,10 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         TRY(dev_alloc(c, &f.ctab, tiles << kBinBitsMax));
         TRY(dev_alloc(c, &f.bin2bucket, ((size_t)1 << kBinBitsMax) + 8));
         TRY(dev_alloc(c, &f.binfo, (size_t)kNbMax + 1));
-        TRY(dev_alloc(c, &f.tbase, tiles * kNbMax));
+        TRY(dev_alloc(c, &f.binsum, ((size_t)1 << kBinBitsMax) + 8));
+        f.tstride = (uint32_t)((tiles + 7) / 8 * 8); f.pad_f = 0;
+        TRY(dev_alloc(c, &f.tcnt, (size_t)f.tstride * kNbMax + 8));
+        TRY(dev_alloc(c, &f.tbase, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.bucket_pub, (size_t)kNbMax));
     }
     TRY(host_alloc(c, &sl.h_args, 1));
@@ -710,6 +730,21 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
         for (uint32_t f = 0; f < c->max_frames; ++f) hf[f] = c->slots[f].f;
         if (hipMemcpy(c->d_frames, hf.data(), sizeof(Frame) * c->max_frames, hipMemcpyHostToDevice) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess) { c->err = "frame table upload failed"; rc = PCOP_ERR_HIP; }
+    }
+    if (!rc && c->voxel_stream) {   // may the ranks of the streaming path come straight from LDS atomics on this device?
+        const char* e = getenv("PCOP_LDS_ORDER");
+        if (!(e && atoi(e) == 0)) {
+            uint32_t* d_bad = nullptr;
+            uint32_t bad = 1;
+            if (hipMalloc(reinterpret_cast<void**>(&d_bad), 4) == hipSuccess) {
+                if (hipMemsetAsync(d_bad, 0, 4, c->stream) == hipSuccess) {
+                    k_lds_order_probe<<<64, kBlock, 0, c->stream>>>(d_bad);
+                    if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) bad = 1;
+                }
+                hipFree(d_bad);
+            }
+            c->lds_ordered = bad == 0;
+        }
     }
     if (rc) { fprintf(stderr, "pcop_create: %s\n", c->err.c_str()); pcop_destroy(c); return rc; }
     *out = c;
@@ -1143,7 +1178,7 @@ int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* byt
         {"comp_rank", f.comp_rank, h * 4}, {"pt_slot", f.pt_slot, n * 4}, {"pt_rank", f.pt_rank, n * 4},
         {"pt_root", f.pt_root, n * 4}, {"idx_a", f.idx_a, n * 4}, {"idx_b", f.idx_b, n * 4},
         {"d_offsets", f.d_offsets, (n + 1) * 4}, {"bin_total", f.bin_total, (size_t)kMaxBins * 4},
-        {"cell_list", f.cell_list, n * 4},
+        {"cell_list", f.cell_list, n * 4}, {"partials", f.partials, (size_t)kReduceBlocks * sizeof(MinMaxPartial)},
         {"binfo", f.binfo, f.binfo.get() ? (size_t)(kNbMax + 1) * 16 : 0}, {"bin2bucket", f.bin2bucket, f.bin2bucket.get() ? (size_t)2 << kBinBitsMax : 0},
         {"cflag", f.cflag, f.cflag.get() ? (size_t)kCmapCells : 0}, {"slot_meta", f.slot_meta, h * 16},
     };

@@ -7,8 +7,8 @@
 //     k_minmax, k_voxel_setup pcl::getMinMax3D; min_b/div_b/divb_mul, the overflow rule, the plan
 //    streaming path (default; no scattered global access anywhere):
 //     k_bin_hist              per 16384-point tile: counts of the coarse key bins (key >> cshift)
-//     k_bin_plan              bins -> buckets of consecutive bins, at most kBucketCap points each
-//     k_bin_offsets           per (tile, bucket): where the tile's points start inside the bucket
+//     k_bin_colsum, k_bin_plan  bins -> buckets of consecutive bins, at most kBucketCap points each
+//     k_bin_tilecnt, k_bin_colscan  per (tile, bucket): where the tile's points start inside the bucket
 //     k_bin_scatter           ONE stable partition of packed 12-byte xyz records by bucket
 //     k_bucket_reduce         per bucket: occupancy bits in LDS -> local voxel ids, stable LDS counting
 //                             sort, one lane per voxel sums its run in order -> centroids, M
@@ -201,7 +201,10 @@ struct Frame {
     DevPtr<uint16_t> ctab;            // [tile][coarse bin]: points of the tile in the bin
     DevPtr<uint16_t> bin2bucket;      // [coarse bin]: bucket of the bin
     DevPtr<uint4> binfo;              // [bucket]: {first record, records, first voxel key, voxel keys spanned}
-    DevPtr<uint32_t> tbase;           // [tile][kNbMax]: records of the lower tiles in the bucket
+    DevPtr<uint32_t> binsum;          // [coarse bin]: points of the frame in the bin
+    DevPtr<uint16_t> tcnt;            // [bucket][tstride]: points of the tile in the bucket
+    DevPtr<uint32_t> tbase;           // [bucket][tstride]: points of the lower tiles in the bucket
+    uint32_t tstride, pad_f;          // tiles a context provides for, rounded up to a multiple of 8
     DevPtr<uint32_t> bucket_pub;      // [bucket]: its voxel count + 1 once known (0 = not yet)
     // dense cell grid (null when the context was created without it)
     DevPtr<uint8_t> cflag;            // one byte per grid cell: occupied?  all zero between frames
@@ -232,19 +235,24 @@ __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// inclusive scan of one value per lane across the wave
+// Inclusive scan of one value per lane across the wave, by data-parallel-primitive moves (no LDS traffic, unlike
+// __shfl_up): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then the last lane of rows 0 and 2 is added to rows 1
+// and 3, then the last lane of row 1 to rows 2 and 3.  A lane without a source adds 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, kWave);
-        if ((int)lane_id() >= d) v += t;
-    }
+    v = dpp_add<0x111, 0xF>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);   // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), kWave - 1);
 }
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 #pragma unroll

@@ -654,10 +654,10 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 // together, in index order, and the voxels in key order - not a full sort of the cloud in HBM:
 //   k_bin_hist      : per tile of kBinTile points, the counts of the coarse key bins (key >> cshift, at most
 //                     2^kBinBitsMax of them) in an LDS histogram -> ctab[tile][bin]
-//   k_bin_plan      : one block per frame: bin totals, then buckets = runs of consecutive bins with at most
-//                     kBucketCap points and kBucketCells cells each (a bin above half the capacity stands alone,
-//                     the others are grouped by windows of their running sum) -> bin2bucket, binfo
-//   k_bin_offsets   : per (tile, bucket) the points of the lower tiles -> tbase
+//   k_bin_colsum    : bin totals over the tiles
+//   k_bin_plan      : one block per frame: buckets = runs of consecutive bins with at most kBucketCap points and
+//                     kBucketCells cells each, packed greedily -> bin2bucket, binfo
+//   k_bin_tilecnt, k_bin_colscan : per (tile, bucket) the points of the lower tiles -> tbase
 //   k_bin_scatter   : ONE stable partition of packed 12-byte xyz records by bucket (peer masks through LDS,
 //                     per-wave counts, chunks of kScatChunk points staged in LDS so that stores are contiguous)
 //   k_bucket_reduce : a bucket lives in LDS: occupancy bits of its key range -> local voxel ids (rank of the key),
@@ -670,6 +670,15 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 __device__ __forceinline__ bool stream_off(const DevState* st) {
     return voxel_stage_off(st) || !st->vpath || st->n_valid == 0;
 }
+
+// Diagnostic build only (-DPCOP_STAMPS): the shader clock at phase borders of one block of a kernel, into a buffer that
+// no kernel reads (the min/max partials, dead after k_voxel_setup).  tools/stamps.py prints the differences.
+#ifdef PCOP_STAMPS
+#define PCOP_STAMP(F, kern, idx, blk) do { if (threadIdx.x == 0 && blockIdx.x == (blk) && blockIdx.y == 0) \
+    reinterpret_cast<unsigned long long*>((F).partials.get())[(kern) * 32 + (idx)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PCOP_STAMP(F, kern, idx, blk) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -712,223 +721,372 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has 16384 points: fits
 }
 
-// One block per frame.  Thread t owns the `per` consecutive bins starting at t * per.
+// Bin totals over the tiles: a block takes 64 bins (a wave reads 128 contiguous bytes of a row), its four waves
+// every fourth tile each.
+__global__ __launch_bounds__(kBlock) void k_bin_colsum(const Frame* frames) {
+    __shared__ uint32_t s_part[kBlock];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint16_t* __restrict__ ctab = F.ctab;
+    uint32_t* __restrict__ binsum = F.binsum;
+    if (stream_off(st)) return;
+    const uint32_t G = 1u << st->gbits;
+    const uint32_t bin = blockIdx.x * kWave + lane_id();
+    if (blockIdx.x * kWave >= G) return;
+    const uint32_t ntiles = (st->n_in + kBinTile - 1u) / kBinTile;
+    const uint32_t w = threadIdx.x / kWave;
+    const uint32_t bc = min(bin, G - 1u);
+    uint32_t c = 0u;
+    for (uint32_t t0 = w; t0 < ntiles; t0 += 4u * 16u) {
+        uint32_t v[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) v[k] = ctab[(size_t)min(t0 + 4u * k, ntiles - 1u) * G + bc];   // clamped, unconditional
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) c += (t0 + 4u * k < ntiles) ? v[k] : 0u;
+    }
+    s_part[threadIdx.x] = c;
+    __syncthreads();
+    if (w == 0u && bin < G) binsum[bin] = s_part[lane_id()] + s_part[kWave + lane_id()] + s_part[2 * kWave + lane_id()] + s_part[3 * kWave + lane_id()];
+}
+
+// Dynamic LDS of k_bin_plan for G bins.
+__host__ __device__ constexpr size_t plan_lds_bytes(uint32_t G) { return ((size_t)G + (G >> 4) + 24u) * 4u + ((size_t)G + 8u) * 2u; }
+
+// One block per frame: the bucket plan.  Thread t owns the `per` consecutive bins starting at t * per.
+// The bins are cut into groups of bmax (a bucket may span kBucketCells cells), every group into windows of kBucketCap
+// points by the running sum at the start of a bin; the bins that start in one window hold less than one capacity
+// plus the window's last bin, so a window is one bucket, or two when the last bin has to stand alone.  Constant work
+// per bin, no searches; windows and buckets are numbered by prefix sums.  Segments without points are dropped.
+// s_P is padded by one word per 16 so that a thread's 16 consecutive words fall on different LDS banks than its neighbours'.
 __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     constexpr int NW = kBinThreads / kWave;
-    constexpr uint32_t kHalf = kBucketCap / 2u;
     constexpr int kPerMax = (1 << kBinBitsMax) / kBinThreads;   // 16
     __shared__ uint32_t s_w[NW];
     __shared__ uint32_t s_max[NW];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
-    const uint16_t* __restrict__ ctab = F.ctab;
+    const uint32_t* __restrict__ binsum = F.binsum;
     uint16_t* __restrict__ bin2bucket = F.bin2bucket;
     uint4* __restrict__ binfo = F.binfo;
     uint32_t* __restrict__ bucket_pub = F.bucket_pub;
     if (stream_off(st)) return;
     const uint32_t G = 1u << st->gbits, cs = st->cshift;
-    const uint32_t ntiles = (st->n_in + kBinTile - 1u) / kBinTile;
     const uint32_t per = G >= kBinThreads ? G / kBinThreads : 1u;
-    // LDS: exclusive prefix of the bin totals (G + 1 words), first bin of every segment (G + 1 halves), bucket of every segment (G halves)
-    uint32_t* s_P = reinterpret_cast<uint32_t*>(s_dyn);
-    uint16_t* s_first = reinterpret_cast<uint16_t*>(s_dyn + ((size_t)G + 1u) * 4u);
-    uint16_t* s_segb = s_first + G + 2u;
+    uint32_t* s_Pp = reinterpret_cast<uint32_t*>(s_dyn);                                   // points before bin i (i = 0 .. G), padded
+    uint16_t* s_first = reinterpret_cast<uint16_t*>(s_dyn + ((size_t)G + (G >> 4) + 24u) * 4u);   // first bin of every window, then of every segment
+    auto P = [&](uint32_t i) -> uint32_t& { return s_Pp[i + (i >> 4)]; };
     const uint32_t b0 = threadIdx.x * per;
     const bool mine = b0 < G;
+    PCOP_STAMP(F, 0, 0, 0);
     for (uint32_t q = threadIdx.x; q < kNbMax; q += kBinThreads) bucket_pub[q] = 0u;   // k_bucket_reduce publishes here
-    // bin totals over the tiles
     uint32_t c[kPerMax];
+    if (per == 16u) {   // the usual sizes: 16-byte loads
+        const uint4* q = reinterpret_cast<const uint4*>(binsum + b0);
+        const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+        c[0] = v0.x; c[1] = v0.y; c[2] = v0.z; c[3] = v0.w; c[4] = v1.x; c[5] = v1.y; c[6] = v1.z; c[7] = v1.w;
+        c[8] = v2.x; c[9] = v2.y; c[10] = v2.z; c[11] = v2.w; c[12] = v3.x; c[13] = v3.y; c[14] = v3.z; c[15] = v3.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < kPerMax; ++k) c[k] = 0u;
-    if (mine) {
-        if (per == 16u) {
-#pragma unroll 4
-            for (uint32_t t = 0; t < ntiles; ++t) {
-                const uint4* q = reinterpret_cast<const uint4*>(ctab + (size_t)t * G + b0);
-                const uint4 a = q[0], b = q[1];
-                const uint32_t wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        for (int k = 0; k < kPerMax; ++k) c[k] = binsum[min(b0 + (uint32_t)k, G - 1u)];   // clamped, unconditional: one round trip for all
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { c[2 * k] += wv[k] & 0xFFFFu; c[2 * k + 1] += wv[k] >> 16; }
-            }
-        } else if (per == 8u) {
-#pragma unroll 4
-            for (uint32_t t = 0; t < ntiles; ++t) {
-                const uint4 a = *reinterpret_cast<const uint4*>(ctab + (size_t)t * G + b0);
-                const uint32_t wv[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { c[2 * k] += wv[k] & 0xFFFFu; c[2 * k + 1] += wv[k] >> 16; }
-            }
-        } else {
-            for (uint32_t t = 0; t < ntiles; ++t) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if ((uint32_t)k < per) c[k] += ctab[(size_t)t * G + b0 + k];
-            }
-        }
+        for (int k = 0; k < kPerMax; ++k) c[k] = (mine && (uint32_t)k < per) ? c[k] : 0u;
     }
     uint32_t csum = 0u, cmax = 0u;
 #pragma unroll
     for (int k = 0; k < kPerMax; ++k) { csum += c[k]; cmax = max(cmax, c[k]); }
     uint32_t total;
-    uint32_t run = block_excl_scan_n<NW>(csum, s_w, &total);
+    const uint32_t run0 = block_excl_scan_n<NW>(csum, s_w, &total);
     cmax = wave_max(cmax);
     if (lane_id() == 0) s_max[threadIdx.x / kWave] = cmax;
     if (mine) {
-        uint32_t r = run;
+        uint32_t r = run0;
 #pragma unroll
         for (int k = 0; k < kPerMax; ++k)
-            if ((uint32_t)k < per) { s_P[b0 + k] = r; r += c[k]; }
+            if ((uint32_t)k < per) { P(b0 + k) = r; r += c[k]; }
     }
-    if (threadIdx.x == 0) s_P[G] = total;
+    if (threadIdx.x == 0) { P(G) = total; P(G + 1u) = total; }
     __syncthreads();
+    PCOP_STAMP(F, 0, 1, 0);
     uint32_t maxbin = 0u;
 #pragma unroll
     for (int i = 0; i < NW; ++i) maxbin = max(maxbin, s_max[i]);
     if (threadIdx.x == 0) st->maxbin = maxbin;
-    const uint32_t bmax = min(G, kBucketCells >> cs);   // bins a bucket may span (>= 1: k_voxel_setup checked)
+    const uint32_t bmax = min(G, kBucketCells >> cs);   // bins a bucket may span
     if (maxbin > kBucketCap || bmax == 0u) {            // bins too coarse for this cloud: the host asks for finer ones
         if (threadIdx.x == 0) atomicOr(&st->err, (uint32_t)kErrReplanBins);
         return;
     }
-    // running sum of the light bins (at most half a bucket each)
-    uint32_t lsum = 0u;
-#pragma unroll
-    for (int k = 0; k < kPerMax; ++k) lsum += c[k] <= kHalf ? c[k] : 0u;
-    uint32_t ltot;
-    uint32_t lrun = block_excl_scan_n<NW>(lsum, s_w, &ltot);
-    // segment starts: a multiple of bmax; a heavy bin; the bin after a heavy bin; a new window of the light sum
-    uint32_t startbits = 0u, nstart = 0u;
+    // window of a bin: (points of its group before it) / capacity.  bmax is a power of two (both G and the cell limit are).
+    auto window = [&](uint32_t b, uint32_t pb) -> uint32_t { return (pb - P(b & ~(bmax - 1u))) / kBucketCap; };
+    auto wstart = [&](uint32_t b, uint32_t pb, uint32_t bprev_p) -> bool {   // a window starts at bin b (b < G)
+        return (b & (bmax - 1u)) == 0u || window(b, pb) != window(b - 1u, bprev_p);
+    };
+    uint32_t wbits = 0u, nws = 0u;
     if (mine) {
-        uint32_t cprev = b0 ? s_P[b0] - s_P[b0 - 1u] : 0u;
-        uint32_t lx = lrun;                                              // light sum before bin b0 + k
-        uint32_t lprev = lx - (cprev <= kHalf ? cprev : 0u);            // ... before bin b0 + k - 1
+        uint32_t r = run0, rprev = b0 ? P(b0 - 1u) : 0u;
+#pragma unroll
+        for (int k = 0; k < kPerMax; ++k) {
+            if ((uint32_t)k < per) {
+                if (wstart(b0 + k, r, rprev)) { wbits |= 1u << k; ++nws; }
+                rprev = r; r += c[k];
+            }
+        }
+    }
+    uint32_t nwin;
+    const uint32_t win0 = block_excl_scan_n<NW>(nws, s_w, &nwin);   // windows that start before bin b0
+    if (mine) {
+        uint32_t wi = win0;
+#pragma unroll
+        for (int k = 0; k < kPerMax; ++k)
+            if ((uint32_t)k < per && ((wbits >> k) & 1u)) s_first[wi++] = (uint16_t)(b0 + k);
+    }
+    __syncthreads();
+    PCOP_STAMP(F, 0, 2, 0);
+    // bucket starts: the window starts, and a window's last bin when the window holds more than one capacity
+    uint32_t sbits = 0u, nstart = 0u;
+    if (mine) {
+        uint32_t r = run0, wi = win0;
 #pragma unroll
         for (int k = 0; k < kPerMax; ++k) {
             if ((uint32_t)k < per) {
                 const uint32_t b = b0 + k;
-                const bool s = b == 0u || (b % bmax) == 0u || c[k] > kHalf || cprev > kHalf || (lx / kHalf) != (lprev / kHalf);
-                if (s) { startbits |= 1u << k; ++nstart; }
-                cprev = c[k]; lprev = lx; lx += c[k] <= kHalf ? c[k] : 0u;
+                const bool ws = (wbits >> k) & 1u;
+                if (ws) ++wi;                                   // bin b is in window wi - 1
+                const uint32_t pend = r + c[k];                 // = P(b + 1)
+                bool lastw;                                      // the next bin starts a window (or there is none)
+                if ((uint32_t)k + 1u < per) lastw = (wbits >> (k + 1)) & 1u;
+                else lastw = b + 1u >= G || wstart(b + 1u, pend, r);
+                const uint32_t wf = s_first[wi - 1u];
+                const bool alone = lastw && wf != b && pend - P(wf) > kBucketCap;
+                if (ws || alone) { sbits |= 1u << k; ++nstart; }
+                r = pend;
             }
         }
     }
     uint32_t nseg;
-    uint32_t seg0 = block_excl_scan_n<NW>(nstart, s_w, &nseg);   // segments that start before bin b0
+    const uint32_t seg0 = block_excl_scan_n<NW>(nstart, s_w, &nseg);   // segments that start before bin b0 (the scan's barriers end the reads of the window starts)
     if (mine) {
-        uint32_t sidx = seg0;
+        uint32_t si = seg0;
 #pragma unroll
         for (int k = 0; k < kPerMax; ++k)
-            if ((uint32_t)k < per && ((startbits >> k) & 1u)) s_first[sidx++] = (uint16_t)(b0 + k);
+            if ((uint32_t)k < per && ((sbits >> k) & 1u)) s_first[si++] = (uint16_t)(b0 + k);
     }
     if (threadIdx.x == 0) s_first[nseg] = (uint16_t)G;   // G <= 2^14 fits
     __syncthreads();
+    PCOP_STAMP(F, 0, 3, 0);
     // buckets = the segments that hold points, numbered in order
-    uint32_t nfull = 0u, fullbits = 0u;
+    uint32_t fbits = 0u, nfull = 0u;
     if (mine) {
-        uint32_t sidx = seg0;
+        uint32_t si = seg0, r = run0;
 #pragma unroll
         for (int k = 0; k < kPerMax; ++k) {
-            if ((uint32_t)k < per && ((startbits >> k) & 1u)) {
-                const uint32_t nxt = s_first[sidx + 1u];
-                if (s_P[nxt] - s_P[b0 + k] > 0u) { fullbits |= 1u << k; ++nfull; }
-                ++sidx;
+            if ((uint32_t)k < per) {
+                if ((sbits >> k) & 1u) {
+                    if (P(s_first[si + 1u]) != r) { fbits |= 1u << k; ++nfull; }
+                    ++si;
+                }
+                r += c[k];
             }
         }
     }
     uint32_t nb;
-    uint32_t bk0 = block_excl_scan_n<NW>(nfull, s_w, &nb);
+    const uint32_t bk0 = block_excl_scan_n<NW>(nfull, s_w, &nb);
     if (threadIdx.x == 0) {
         st->nbuckets = nb;
         if (nb > kNbMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
         else if (nb > st->nb_cap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
     }
     if (nb > kNbMax) return;
+    PCOP_STAMP(F, 0, 4, 0);
     if (mine) {
-        uint32_t sidx = seg0, bk = bk0;
-#pragma unroll
-        for (int k = 0; k < kPerMax; ++k) {
-            if ((uint32_t)k < per && ((startbits >> k) & 1u)) {
-                if ((fullbits >> k) & 1u) {
-                    const uint32_t b = b0 + k, nxt = s_first[sidx + 1u];
-                    binfo[bk] = make_uint4(s_P[b], s_P[nxt] - s_P[b], b << cs, (nxt - b) << cs);
-                    s_segb[sidx] = (uint16_t)bk;
-                    ++bk;
-                } else {
-                    s_segb[sidx] = 0u;
-                }
-                ++sidx;
-            }
-        }
-    }
-    __syncthreads();
-    if (mine) {   // bucket of every bin: that of its segment (bins of empty segments hold no points)
-        uint32_t sidx = seg0;   // segments started before b0; the segment of bin b0 + k is (starts up to and including it) - 1
+        uint32_t si = seg0, bk = bk0, r = run0;
 #pragma unroll
         for (int k = 0; k < kPerMax; ++k) {
             if ((uint32_t)k < per) {
-                if ((startbits >> k) & 1u) ++sidx;
-                bin2bucket[b0 + k] = s_segb[sidx - 1u];
+                const uint32_t b = b0 + k;
+                if ((sbits >> k) & 1u) {
+                    if ((fbits >> k) & 1u) {   // first record, records, first key, keys spanned
+                        const uint32_t nx = s_first[si + 1u];
+                        binfo[bk] = make_uint4(r, P(nx) - r, b << cs, (nx - b) << cs);
+                        ++bk;
+                    }
+                    ++si;
+                }
+                bin2bucket[b] = (uint16_t)(bk ? bk - 1u : 0u);   // the last bucket started up to here (a bin outside any bucket holds no points)
+                r += c[k];
             }
         }
     }
+    PCOP_STAMP(F, 0, 15, 0);
 }
 
-// One wave per bucket: tbase[tile][bucket] = points of the lower tiles in the bucket.
-__global__ __launch_bounds__(kWave) void k_bin_offsets(const Frame* frames) {
+// Points of every (tile, bucket): the tile's row of bin counts as a running sum in LDS, read at the bucket borders.
+// A thread sums G / 256 consecutive bins in registers (16-byte loads), one block scan joins the threads.
+// tcnt is bucket-major: [bucket][tile].
+__global__ __launch_bounds__(kBlock) void k_bin_tilecnt(const Frame* frames) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_dyn);   // points of the row before bin i, i = 0 .. G
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const uint16_t* __restrict__ ctab = F.ctab;
     const uint4* __restrict__ binfo = F.binfo;
-    uint32_t* __restrict__ tbase = F.tbase;
+    uint16_t* __restrict__ tcnt = F.tcnt;
     if (stream_off(st)) return;
-    const uint32_t b = blockIdx.x;
-    if (b >= st->nbuckets) return;
-    const uint32_t G = 1u << st->gbits, cs = st->cshift;
-    const uint32_t ntiles = (st->n_in + kBinTile - 1u) / kBinTile;
-    const uint4 info = binfo[b];
-    const uint32_t first = info.z >> cs, nbins = info.w >> cs;
-    uint32_t carry = 0u;
-    for (uint32_t t0 = 0; t0 < ntiles; t0 += kWave) {
-        const uint32_t t = t0 + lane_id();
-        uint32_t cnt = 0u;
-        if (t < ntiles) {
-            const uint16_t* __restrict__ row = ctab + (size_t)t * G + first;
-            for (uint32_t k = 0; k < nbins; ++k) cnt += row[k];
+    const uint32_t tile = blockIdx.x;
+    if (tile * kBinTile >= st->n_in) return;
+    const uint32_t G = 1u << st->gbits, cs = st->cshift, nb = st->nbuckets, ts = F.tstride;
+    const uint16_t* __restrict__ row = ctab + (size_t)tile * G;
+    constexpr uint32_t kVecMax = (1u << kBinBitsMax) / kBlock / 8u;   // 16-byte loads per thread: at most 8
+    if (G >= 8u * kBlock) {
+        const uint32_t nvec = G / kBlock / 8u;   // 1, 2, 4 or 8
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(row) + (size_t)threadIdx.x * nvec;
+        uint4 v[kVecMax];
+#pragma unroll
+        for (uint32_t k = 0; k < kVecMax; ++k) v[k] = src[min(k, nvec - 1u)];
+        uint32_t sum = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kVecMax; ++k) {
+            if (k < nvec) {
+                const uint32_t wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum += (wv[j] & 0xFFFFu) + (wv[j] >> 16);
+            }
         }
-        const uint32_t incl = wave_incl_scan(cnt);
-        if (t < ntiles) tbase[(size_t)t * kNbMax + b] = carry + incl - cnt;
-        carry += __shfl(incl, kWave - 1, kWave);
+        uint32_t tot;
+        uint32_t run = block_excl_scan(sum, s_w, &tot);
+        uint4* dst = reinterpret_cast<uint4*>(s_pre) + (size_t)threadIdx.x * nvec;
+#pragma unroll
+        for (uint32_t k = 0; k < kVecMax; ++k) {
+            if (k < nvec) {
+                const uint32_t wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // a tile has 16384 points: the running sums fit 16 bits (mod 2^16 for the last one)
+                    const uint32_t lo = run & 0xFFFFu; run += wv[j] & 0xFFFFu;
+                    const uint32_t hi = run & 0xFFFFu; run += wv[j] >> 16;
+                    o[j] = lo | (hi << 16);
+                }
+                dst[k] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        if (threadIdx.x == 0) s_pre[G] = (uint16_t)tot;
+    } else {   // small grids: one wave, 64 bins at a time
+        if (threadIdx.x < kWave) {
+            uint32_t carry = 0u;
+            for (uint32_t i0 = 0; i0 < G; i0 += kWave) {
+                const uint32_t i = i0 + lane_id();
+                const uint32_t v = i < G ? row[i] : 0u;
+                const uint32_t incl = wave_incl_scan(v);
+                if (i < G) s_pre[i] = (uint16_t)(carry + incl - v);
+                carry += __shfl(incl, kWave - 1, kWave);
+            }
+            if (lane_id() == 0) s_pre[G] = (uint16_t)carry;
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += kBlock) {
+        const uint4 info = binfo[b];
+        const uint32_t first = info.z >> cs, end = first + ((info.w + (1u << cs) - 1u) >> cs);
+        tcnt[(size_t)b * ts + tile] = (uint16_t)(s_pre[end] - s_pre[first]);
     }
 }
 
-// Peers of this lane's value among the active lanes of the wave, through two peer-mask words in LDS: one indexed
-// by the low 6 bits of the value, one by the bits above (fewer than 64 values).  Lanes that share both words hold
-// the same value.  All words are zero on entry and are left zero (every lane clears its own two, unconditionally, so
-// nothing waits for the reads).  A wave's LDS operations execute in program order.
-__device__ __forceinline__ uint64_t match_split_lds(unsigned long long* m_lo, unsigned long long* m_hi, uint32_t d, bool active) {
+// tbase[bucket][tile] = points of the lower tiles in the bucket: one thread per bucket, eight tiles per step.
+__global__ __launch_bounds__(kBlock) void k_bin_colscan(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const uint16_t* __restrict__ tcnt = F.tcnt;
+    uint32_t* __restrict__ tbase = F.tbase;
+    if (stream_off(st)) return;
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= st->nbuckets) return;
+    const uint32_t ntiles = (st->n_in + kBinTile - 1u) / kBinTile, ts = F.tstride;   // ts: a multiple of 8
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(tcnt + (size_t)b * ts);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(tbase + (size_t)b * ts);
+    uint32_t run = 0u;
+    for (uint32_t g0 = 0; g0 * 8u < ntiles; g0 += 4u) {   // four 16-byte loads in flight (entries past ntiles are never read by anyone)
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) v[k] = src[min(g0 + k, (ntiles - 1u) / 8u)];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if ((g0 + k) * 8u < ntiles) {
+                const uint32_t wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                uint32_t o[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[2 * j] = run; run += wv[j] & 0xFFFFu; o[2 * j + 1] = run; run += wv[j] >> 16; }
+                dst[2u * (g0 + k)] = make_uint4(o[0], o[1], o[2], o[3]);
+                dst[2u * (g0 + k) + 1u] = make_uint4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+}
+
+// Peers of this lane's value among the active lanes of the wave, through two peer-mask words in LDS: word `a` of
+// m_lo and word `b` of m_hi, where (a, b) determines the value (a = its low 6 bits, b = its high bits shifted by a, so
+// that values with equal high bits still spread over the words of m_hi).  Lanes that share both words hold the same
+// value.  All words are zero on entry and are left zero (every lane clears its own two, unconditionally, so nothing
+// waits for the reads).  A wave's LDS operations execute in program order.
+__device__ __forceinline__ uint64_t match_split_lds(unsigned long long* m_lo, unsigned long long* m_hi, uint32_t a, uint32_t b, bool active) {
     unsigned long long plo = 0ull, phi = 0ull;
     const unsigned long long bit = 1ull << lane_id();
-    if (active) { atomicOr(m_lo + (d & 63u), bit); atomicOr(m_hi + (d >> 6), bit); }
+    if (active) { atomicOr(m_lo + a, bit); atomicOr(m_hi + b, bit); }
     __builtin_amdgcn_wave_barrier();
-    if (active) { plo = m_lo[d & 63u]; phi = m_hi[d >> 6]; }
+    if (active) { plo = m_lo[a]; phi = m_hi[b]; }
     __builtin_amdgcn_wave_barrier();
-    if (active) { m_lo[d & 63u] = 0ull; m_hi[d >> 6] = 0ull; }
+    if (active) { m_lo[a] = 0ull; m_hi[b] = 0ull; }
     __builtin_amdgcn_wave_barrier();
     return plo & phi;
 }
 
-// Dynamic LDS of k_bin_scatter for nbc buckets.
-__host__ __device__ constexpr size_t scatter_lds_bytes(uint32_t nbc) {
-    return (size_t)kScatChunk * 12u + (size_t)kScatChunk * 2u + (size_t)nbc * (4u + 12u + 2u) + 8u + 4u * (kScatThreads / kWave + 1u);
+// Checks on the device, once per context, what the ORDERED variants rely on: lanes of one wave instruction that add to
+// the same LDS word get their old values in lane order, and a following instruction continues from there.
+// ok[0] counts violations; patterns: every lane picks one of `range` words, pseudo-randomly, some lanes sit out.
+__global__ __launch_bounds__(kBlock) void k_lds_order_probe(uint32_t* __restrict__ violations) {
+    __shared__ uint32_t cnt[kWavesPerBlock][2048];
+    const uint32_t lane = lane_id(), w = threadIdx.x / kWave;
+    uint32_t bad = 0u;
+    for (uint32_t trial = 0; trial < 64u; ++trial) {
+        for (uint32_t i = lane; i < 2048u; i += kWave) cnt[w][i] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ranges[8] = {1u, 2u, 4u, 16u, 64u, 256u, 2048u, 33u};
+        const uint32_t range = ranges[trial & 7u];
+        uint32_t h = (blockIdx.x * 64u + trial) * 0x9E3779B9u + (threadIdx.x + 1u) * 0x85EBCA6Bu;
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+        uint32_t a = h % range;
+        if ((trial & 7u) == 7u) a = (a * 32u) & 2047u;   // one bank, different words
+        const bool active = ((h >> 20) & 15u) != 0u;
+        uint32_t old = 0u, old2 = 0u;
+        if (active) old = atomicAdd(&cnt[w][a], 1u);
+        if (active) old2 = atomicAdd(&cnt[w][a], 1u << 16);
+        uint32_t expect = 0u, total = 0u;
+        for (uint32_t l = 0; l < kWave; ++l) {
+            const uint32_t al = __shfl(a, l, kWave);
+            const bool actl = __shfl(active ? 1u : 0u, l, kWave) != 0u;
+            if (actl && al == a) { ++total; if (l < lane) ++expect; }
+        }
+        if (active && (old != expect || old2 != (total | (expect << 16)))) ++bad;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (bad) atomicAdd(violations, bad);
 }
 
+// Dynamic LDS of k_bin_scatter for nbc buckets.
+__host__ __device__ constexpr size_t scatter_lds_bytes(uint32_t nbc) {
+    return (size_t)kScatChunk * 12u + (size_t)kScatChunk * 2u + (size_t)nbc * (4u + 16u) + 8u + 4u * (kScatThreads / kWave + 1u);
+}
+
+// ORDERED: the device hands out the old values of an LDS atomic add in lane order among the lanes of a wave
+// instruction that hit the same word (k_lds_order_probe checked it when the context was made): the rank of a point
+// inside (wave, bucket) is then the value one atomic returns.  Otherwise the ranks come from peer masks.
+template <uint32_t PB, bool ORDERED>   // PB: buckets per thread in the per-bucket steps: the launch provides for PB * 512 buckets
 __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     constexpr uint32_t NW = kScatThreads / kWave;   // 8 waves; a wave ranks 512 consecutive points of a chunk
-    constexpr uint32_t NWW = (NW + 2u) / 3u;        // per bucket: the waves' counts, three 10-bit fields per word
     constexpr uint32_t kMatchWords = 128u;          // per wave: 64 words for the low 6 bits of the bucket, 64 for the high 6
-    static_assert(kScatItems * kWave <= 1023u, "a wave's count of one bucket fits 10 bits");
+    static_assert(NW == 8u && kScatChunk <= 65535u, "per bucket: eight 16-bit fields, one per wave");
     static_assert(NW * kMatchWords * 8u <= kScatChunk * 12u, "the peer masks fit the staging area");
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
@@ -940,38 +1098,46 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
     const uint32_t n = st->n_in;
     const uint32_t tile_base = blockIdx.x * kBinTile;
     if (tile_base >= n) return;
-    const uint32_t nbc = st->nb_cap, nb = st->nbuckets, G = 1u << st->gbits, cs = st->cshift;
+    const uint32_t nbc = PB * kScatThreads, nb = st->nbuckets, G = 1u << st->gbits, cs = st->cshift;
+    if (st->nb_cap != nbc) return;   // (the host launches the instance that matches)
     Rec3* stage = reinterpret_cast<Rec3*>(s_dyn);
     unsigned long long* s_match = reinterpret_cast<unsigned long long*>(s_dyn);   // shares the staging area (used in turns)
     uint16_t* sbkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kScatChunk * 12u);
-    uint32_t* cur = reinterpret_cast<uint32_t*>(s_dyn + (size_t)kScatChunk * 14u);
-    uint32_t* wcnt = cur + nbc;
-    uint16_t* lbase = reinterpret_cast<uint16_t*>(wcnt + (size_t)NWW * nbc);
-    uint32_t* s_w = reinterpret_cast<uint32_t*>(lbase + nbc + 4u);
+    uint4* wcnt = reinterpret_cast<uint4*>(s_dyn + (size_t)kScatChunk * 14u);     // [word][bucket]: the waves' counts (two 16-bit fields per word), then their starts in the staged chunk
+    uint32_t* wcnt32 = reinterpret_cast<uint32_t*>(wcnt);
+    uint32_t* cur = wcnt32 + (size_t)4u * nbc;   // per bucket: where the tile's next point goes (between chunks), minus its start in the staged chunk (inside one)
+    uint32_t* s_w = cur + nbc;
     const float* __restrict__ x = st->src_x; const float* __restrict__ y = st->src_y; const float* __restrict__ z = st->src_z;
     const bool drop = st->is_dense == 0;
     VoxelKey key; key.init(st);
     const uint32_t w = threadIdx.x / kWave, lane = lane_id();
-    const uint32_t wword = w / 3u, wshift = 10u * (w % 3u);
+    const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
     // where this tile's points start in every bucket
-    for (uint32_t b = threadIdx.x; b < nb; b += kScatThreads) cur[b] = binfo[b].x + tbase[(size_t)blockIdx.x * kNbMax + b];
-    const uint32_t pb = nbc / kScatThreads;   // buckets per thread in the per-bucket steps: 2, 4 or 8 consecutive ones
+    for (uint32_t b = threadIdx.x; b < nbc; b += kScatThreads) cur[b] = b < nb ? binfo[b].x + tbase[(size_t)b * F.tstride + blockIdx.x] : 0u;
+    constexpr uint32_t pb = PB;
     unsigned long long* m_lo = s_match + w * kMatchWords;
     unsigned long long* m_hi = m_lo + 64u;
+    // The records of the next chunk are requested while the current one is ranked and staged.
+    Rec3 rec[kScatItems], recn[kScatItems];
+    auto request = [&](Rec3* r, uint32_t cb) {
+#pragma unroll
+        for (uint32_t j = 0; j < kScatItems; ++j) {
+            const uint32_t i = min(cb + w * (kScatItems * kWave) + lane + j * kWave, n - 1u);   // clamped, unconditional
+            r[j].x = x[i]; r[j].y = y[i]; r[j].z = z[i];
+        }
+    };
+    request(recn, tile_base);
+    PCOP_STAMP(F, 1, 0, 30);
     for (uint32_t ch = 0; ch < kBinTile / kScatChunk; ++ch) {
         const uint32_t cbase = tile_base + ch * kScatChunk;
         if (cbase >= n) break;
-        for (uint32_t i = threadIdx.x; i < NW * kMatchWords; i += kScatThreads) s_match[i] = 0ull;
-        for (uint32_t i = threadIdx.x; i < NWW * nbc; i += kScatThreads) wcnt[i] = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < kScatItems; ++j) rec[j] = recn[j];
+        if (!ORDERED) for (uint32_t i = threadIdx.x; i < NW * kMatchWords; i += kScatThreads) s_match[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < nbc; i += kScatThreads) wcnt[i] = make_uint4(0u, 0u, 0u, 0u);   // (as 16-byte stores: the layout is [4 words][bucket])
         const uint32_t wbase = cbase + w * (kScatItems * kWave) + lane;
-        Rec3 rec[kScatItems];
         uint32_t bin[kScatItems], bkt[kScatItems], rank[kScatItems];
         bool act[kScatItems];
-#pragma unroll
-        for (uint32_t j = 0; j < kScatItems; ++j) {
-            const uint32_t i = min(wbase + j * kWave, n - 1u);
-            rec[j].x = x[i]; rec[j].y = y[i]; rec[j].z = z[i];
-        }
 #pragma unroll
         for (uint32_t j = 0; j < kScatItems; ++j) {
             act[j] = wbase + j * kWave < n && (!drop || finite3(rec[j].x, rec[j].y, rec[j].z));
@@ -980,83 +1146,103 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
         }
 #pragma unroll
         for (uint32_t j = 0; j < kScatItems; ++j) bkt[j] = bin2bucket[bin[j]];   // all requested before any is used
+        __builtin_amdgcn_sched_barrier(0);   // the next chunk's records are requested after the bucket lookups: loads return in order
+        if (ch + 1u < kBinTile / kScatChunk) request(recn, cbase + kScatChunk);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (ch == 1u) PCOP_STAMP(F, 1, 1, 30);
         // ranks inside (wave, bucket): stable by construction (steps in order, lanes in order)
+        if constexpr (ORDERED) {
+#pragma unroll
+            for (uint32_t j = 0; j < kScatItems; ++j) {
+                uint32_t old = 0u;
+                if (act[j]) old = atomicAdd(&wcnt32[wword * nbc + bkt[j]], 1u << wshift);
+                rank[j] = (old >> wshift) & 0xFFFFu;
+            }
+        } else
 #pragma unroll
         for (uint32_t j = 0; j < kScatItems; ++j) {
             const uint32_t d = bkt[j];
-            const uint64_t peers = match_split_lds(m_lo, m_hi, d, act[j]);
+            const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 63u, act[j]);   // d < 4096
             const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
             uint32_t old = 0u;
-            if (act[j] && lr == 0u) old = atomicAdd(&wcnt[wword * nbc + d], (uint32_t)__popcll(peers) << wshift);
+            if (act[j] && lr == 0u) old = atomicAdd(&wcnt32[wword * nbc + d], (uint32_t)__popcll(peers) << wshift);
             const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
             old = __shfl(old, leader, kWave);
-            rank[j] = ((old >> wshift) & 1023u) + lr;
+            rank[j] = ((old >> wshift) & 0xFFFFu) + lr;
         }
         __syncthreads();
-        // per bucket: points of the chunk, start inside the staged chunk
-        uint32_t tot[8];
+        if (ch == 1u) PCOP_STAMP(F, 1, 2, 30);
+        // per bucket: points of the chunk; then every wave's start inside the staged chunk (bucket-major, waves in order)
+        uint32_t tot[PB], lstart[PB];
+        uint4 cw[PB];
         uint32_t tsum = 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) {
-            tot[k] = 0u;
+        for (uint32_t k = 0; k < PB; ++k) {
+            tot[k] = 0u; lstart[k] = 0u; cw[k] = make_uint4(0u, 0u, 0u, 0u);
             if (k < pb) {
                 const uint32_t b = threadIdx.x * pb + k;
-#pragma unroll
-                for (uint32_t q = 0; q < NWW; ++q) {
-                    const uint32_t v = wcnt[q * nbc + b];
-                    tot[k] += (v & 1023u) + ((v >> 10) & 1023u) + ((v >> 20) & 1023u);
-                }
+                cw[k] = make_uint4(wcnt32[b], wcnt32[nbc + b], wcnt32[2u * nbc + b], wcnt32[3u * nbc + b]);
+                tot[k] = (cw[k].x & 0xFFFFu) + (cw[k].x >> 16) + (cw[k].y & 0xFFFFu) + (cw[k].y >> 16) +
+                         (cw[k].z & 0xFFFFu) + (cw[k].z >> 16) + (cw[k].w & 0xFFFFu) + (cw[k].w >> 16);
             }
             tsum += tot[k];
         }
         uint32_t ctot;
         uint32_t lrun = block_excl_scan_n<NW>(tsum, s_w, &ctot);
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k)
-            if (k < pb) { lbase[threadIdx.x * pb + k] = (uint16_t)lrun; lrun += tot[k]; }
+        for (uint32_t k = 0; k < PB; ++k) {
+            if (k < pb) {
+                const uint32_t b = threadIdx.x * pb + k;
+                const uint32_t wv[4] = {cw[k].x, cw[k].y, cw[k].z, cw[k].w};
+                uint32_t o[4], r = lrun;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const uint32_t lo = r; r += wv[q] & 0xFFFFu; const uint32_t hi = r; r += wv[q] >> 16; o[q] = lo | (hi << 16); }
+                wcnt32[b] = o[0]; wcnt32[nbc + b] = o[1]; wcnt32[2u * nbc + b] = o[2]; wcnt32[3u * nbc + b] = o[3];
+                lstart[k] = lrun;
+                cur[b] -= lrun;        // global position of a staged record = cur[bucket] + its place in the staged chunk
+                lrun += tot[k];
+            }
+        }
         __syncthreads();
+        if (ch == 1u) PCOP_STAMP(F, 1, 3, 30);
         // stage the chunk in output order (bucket-major, stable inside a bucket)
 #pragma unroll
         for (uint32_t j = 0; j < kScatItems; ++j) {
             if (act[j]) {
                 const uint32_t d = bkt[j];
-                uint32_t woff = 0u;   // points of the lower waves in this bucket
-#pragma unroll
-                for (uint32_t q = 0; q < NWW; ++q) {
-                    const uint32_t v = wcnt[q * nbc + d];
-                    const uint32_t f0 = v & 1023u, f1 = (v >> 10) & 1023u, f2 = (v >> 20) & 1023u;
-                    if (q < wword) woff += f0 + f1 + f2;
-                    else if (q == wword) woff += (wshift >= 10u ? f0 : 0u) + (wshift >= 20u ? f1 : 0u);
-                }
-                const uint32_t slot = (uint32_t)lbase[d] + woff + rank[j];
+                const uint32_t slot = ((wcnt32[wword * nbc + d] >> wshift) & 0xFFFFu) + rank[j];
                 stage[slot] = rec[j];
                 sbkt[slot] = (uint16_t)d;
             }
         }
         __syncthreads();
+        if (ch == 1u) PCOP_STAMP(F, 1, 4, 30);
         for (uint32_t e = threadIdx.x; e < ctot; e += kScatThreads) {
             const Rec3 r = stage[e];
-            const uint32_t d = sbkt[e];
-            out[cur[d] + (e - (uint32_t)lbase[d])] = r;
+            out[cur[sbkt[e]] + e] = r;
         }
         __syncthreads();
+        if (ch == 1u) PCOP_STAMP(F, 1, 5, 30);
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k)
-            if (k < pb) cur[threadIdx.x * pb + k] += tot[k];
+        for (uint32_t k = 0; k < PB; ++k)   // back to "where the tile's next point goes"
+            if (k < pb) cur[threadIdx.x * pb + k] += lstart[k] + tot[k];
     }
 }
 
+template <bool ORDERED>   // as in k_bin_scatter
 __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     constexpr uint32_t NW = kBlock / kWave;                    // 4 waves; a wave ranks 512 consecutive points of the bucket
     constexpr uint32_t kItemsB = kBucketCap / kBlock;          // 8
     constexpr uint32_t kMapWords = kBucketCells / 32u;         // 4096
     constexpr uint32_t kPerW = kMapWords / kBlock;             // at most 16 occupancy words per thread
-    static_assert(kBucketCap * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
-    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kBucketCap * 12u];   // occupancy bits + running counts, then the staged records
-    __shared__ uint32_t s_wc[2u * kBucketCap];                 // per voxel: counts of waves 0,1 (low / high half) and of waves 2,3
-    __shared__ uint16_t s_run[kBucketCap + 2u];                // per voxel: start of its run in the staged bucket
-    __shared__ unsigned long long s_match[NW * 96u];           // per wave: 64 + 32 peer-mask words (voxel ids below 2048)
+    constexpr uint32_t kPlane = kBucketCap + kBucketCap / 32u + 8u;   // a staged coordinate plane: slot s lives at s + (s >> 5)
+    static_assert(kPlane * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPlane * 12u];   // occupancy bits + running counts, then the staged records (three planes)
+    __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kBucketCap];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3
+    __shared__ __attribute__((aligned(16))) uint16_t s_run[kBucketCap + 8u];   // per voxel id: its points, then the start of its run in the staged bucket
+    __shared__ __attribute__((aligned(16))) uint16_t s_vr[kBucketCap + 8u];    // per voxel id: occupied ids before it = its rank in the bucket
+    __shared__ unsigned long long s_match[ORDERED ? 1u : NW * 96u];   // per wave: 64 + 32 peer-mask words (voxel ids below 2048)
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
@@ -1071,70 +1257,89 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(s_mem);
     uint16_t* wpre = reinterpret_cast<uint16_t*>(s_mem + kMapWords * 4u);
-    Rec3* stage = reinterpret_cast<Rec3*>(s_mem);
+    float* stage_x = reinterpret_cast<float*>(s_mem); float* stage_y = stage_x + kPlane; float* stage_z = stage_y + kPlane;
+    // A bucket that spans at most kBucketCap cells sorts by the cell itself (ids of empty cells get empty runs);
+    // a wider one first ranks its occupied cells through an occupancy map, so that ids stay below the point count.
+    const bool direct = span <= kBucketCap;
     const uint32_t words = (span + 31u) / 32u;
     bool bad = cnt == 0u || cnt > kBucketCap || span > kBucketCells;   // never: k_bin_plan keeps both limits
     const uint32_t w = threadIdx.x / kWave, lane = lane_id();
-    for (uint32_t i = threadIdx.x; i < min(words, kMapWords); i += kBlock) bitmap[i] = 0u;
-    for (uint32_t i = threadIdx.x; i < 2u * kBucketCap; i += kBlock) s_wc[i] = 0u;
-    for (uint32_t i = threadIdx.x; i < NW * 96u; i += kBlock) s_match[i] = 0ull;
     VoxelKey key; key.init(st);
     Rec3 rec[kItemsB];
     uint32_t lk[kItemsB], id[kItemsB], rank[kItemsB];
     bool act[kItemsB];
     const uint32_t pbase = w * (kItemsB * kWave) + lane;   // position in the bucket = index order
+    PCOP_STAMP(F, 2, 0, 300);
     const uint32_t last = bad ? 0u : cnt - 1u;
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) rec[j] = recs[info.x + min(pbase + j * kWave, last)];
+    // (the LDS is cleared while the records are on their way)
+    if (!direct) for (uint32_t i = threadIdx.x; i < min(words, kMapWords); i += kBlock) bitmap[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < 2u * kBucketCap / 4u; i += kBlock) reinterpret_cast<uint4*>(s_wc)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (!ORDERED) for (uint32_t i = threadIdx.x; i < NW * 96u; i += kBlock) s_match[i] = 0ull;
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
         lk[j] = key(rec[j]) - key_lo;
         act[j] = !bad && pbase + j * kWave < cnt;
         if (act[j] && lk[j] >= span) { bad = true; act[j] = false; }
+        id[j] = act[j] ? lk[j] : 0u;
     }
     bad = __syncthreads_or(bad ? 1 : 0) != 0;
-    if (bad) {   // publish nothing-but-present, so that the higher buckets do not wait
+    PCOP_STAMP(F, 2, 1, 300);
+    if (bad) {   // publish "present, no voxels", so that the higher buckets do not wait
         if (threadIdx.x == 0) { atomicOr(&st->err, (uint32_t)kErrInternal); st_agent(bucket_pub + b, 1u); }
         return;
     }
+    if (!direct) {
 #pragma unroll
-    for (uint32_t j = 0; j < kItemsB; ++j)
-        if (act[j]) atomicOr(&bitmap[lk[j] >> 5], 1u << (lk[j] & 31u));
-    __syncthreads();
-    // running count of the occupied cells: thread t owns the perw consecutive words from t * perw
-    const uint32_t perw = (words + kBlock - 1u) / kBlock;   // 1 .. 16
-    uint32_t wv[kPerW];
-    uint32_t c = 0u;
+        for (uint32_t j = 0; j < kItemsB; ++j)
+            if (act[j]) atomicOr(&bitmap[lk[j] >> 5], 1u << (lk[j] & 31u));
+        __syncthreads();
+    PCOP_STAMP(F, 2, 2, 300);
+        // running count of the occupied cells: thread t owns the perw consecutive words from t * perw
+        const uint32_t perw = (words + kBlock - 1u) / kBlock;   // 1 .. 16
+        uint32_t wv[kPerW];
+        uint32_t c = 0u;
 #pragma unroll
-    for (uint32_t k = 0; k < kPerW; ++k) {
-        const uint32_t wi = threadIdx.x * perw + k;
-        wv[k] = (k < perw && wi < words) ? bitmap[wi] : 0u;
-        c += __popc(wv[k]);
+        for (uint32_t k = 0; k < kPerW; ++k) {
+            const uint32_t wi = threadIdx.x * perw + k;
+            wv[k] = (k < perw && wi < words) ? bitmap[wi] : 0u;
+            c += __popc(wv[k]);
+        }
+        uint32_t nocc;
+        uint32_t run = block_excl_scan(c, s_w, &nocc);
+#pragma unroll
+        for (uint32_t k = 0; k < kPerW; ++k) {
+            const uint32_t wi = threadIdx.x * perw + k;
+            if (k < perw && wi < words) wpre[wi] = (uint16_t)run;
+            run += __popc(wv[k]);
+        }
+        __syncthreads();
+    PCOP_STAMP(F, 2, 3, 300);
+#pragma unroll
+        for (uint32_t j = 0; j < kItemsB; ++j) {   // id = occupied cells of the bucket before this one
+            const uint32_t wi = act[j] ? lk[j] >> 5 : 0u;
+            id[j] = (uint32_t)wpre[wi] + __popc(bitmap[wi] & ((1u << (lk[j] & 31u)) - 1u));
+        }
+        __syncthreads();   // the occupancy words are done with: the staging area may be written from here on
+    PCOP_STAMP(F, 2, 4, 300);
     }
-    uint32_t nvox;
-    uint32_t run = block_excl_scan(c, s_w, &nvox);
-    if (threadIdx.x == 0) st_agent(bucket_pub + b, nvox + 1u);   // publish: the higher buckets add this up
+    // ranks inside (wave, id)
+    const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
+    if constexpr (ORDERED) {
 #pragma unroll
-    for (uint32_t k = 0; k < kPerW; ++k) {
-        const uint32_t wi = threadIdx.x * perw + k;
-        if (k < perw && wi < words) wpre[wi] = (uint16_t)run;
-        run += __popc(wv[k]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < kItemsB; ++j) {   // local voxel id = occupied cells of the bucket before this one
-        const uint32_t wi = act[j] ? lk[j] >> 5 : 0u;
-        id[j] = (uint32_t)wpre[wi] + __popc(bitmap[wi] & ((1u << (lk[j] & 31u)) - 1u));
-    }
-    __syncthreads();   // the occupancy words are done with: the staging area may be written from here on
-    // ranks inside (wave, voxel)
+        for (uint32_t j = 0; j < kItemsB; ++j) {
+            uint32_t old = 0u;
+            if (act[j]) old = atomicAdd(&s_wc[wword * kBucketCap + id[j]], 1u << wshift);
+            rank[j] = (old >> wshift) & 0xFFFFu;
+        }
+    } else {
     unsigned long long* m_lo = s_match + w * 96u;
     unsigned long long* m_hi = m_lo + 64u;
-    const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
-        const uint32_t d = act[j] ? id[j] : 0u;
-        const uint64_t peers = match_split_lds(m_lo, m_hi, d, act[j]);
+        const uint32_t d = id[j];
+        const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 31u, act[j]);   // d < 2048
         const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
         uint32_t old = 0u;
         if (act[j] && lr == 0u) old = atomicAdd(&s_wc[wword * kBucketCap + d], (uint32_t)__popcll(peers) << wshift);
@@ -1142,51 +1347,88 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
         old = __shfl(old, leader, kWave);
         rank[j] = ((old >> wshift) & 0xFFFFu) + lr;
     }
+    }
     __syncthreads();
-    // run starts: thread t owns voxels t * 8 .. t * 8 + 7
-    uint32_t tot[kItemsB];
-    uint32_t tsum = 0u;
+    PCOP_STAMP(F, 2, 5, 300);
+    // points per id (a thread takes ids t, t + 256, ...: neighbouring words), then run starts and ranks of the occupied ids
+    // (thread t owns ids t * 8 .. t * 8 + 7: one 16-byte access each way)
 #pragma unroll
     for (uint32_t k = 0; k < kItemsB; ++k) {
-        const uint32_t v = threadIdx.x * kItemsB + k;
+        const uint32_t v = k * kBlock + threadIdx.x;
         const uint32_t a = s_wc[v], q = s_wc[kBucketCap + v];
-        tot[k] = (a & 0xFFFFu) + (a >> 16) + (q & 0xFFFFu) + (q >> 16);
-        tsum += tot[k];
+        s_run[v] = (uint16_t)((a & 0xFFFFu) + (a >> 16) + (q & 0xFFFFu) + (q >> 16));
+    }
+    __syncthreads();
+    PCOP_STAMP(F, 2, 6, 300);
+    uint4* run4 = reinterpret_cast<uint4*>(s_run) + threadIdx.x;
+    uint4* vr4 = reinterpret_cast<uint4*>(s_vr) + threadIdx.x;
+    const uint4 t4 = *run4;
+    const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
+    uint32_t tsum = 0u;   // low half: points, high half: occupied ids
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t lo = tw[q] & 0xFFFFu, hi = tw[q] >> 16;
+        tsum += lo + hi + (lo ? 0x10000u : 0u) + (hi ? 0x10000u : 0u);
     }
     uint32_t ttot;
     uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
+    const uint32_t nvox = ttot >> 16;
+    if (threadIdx.x == 0) st_agent(bucket_pub + b, nvox + 1u);   // publish: the higher buckets add this up
+    {
+        uint32_t ro[4], vo[4];
 #pragma unroll
-    for (uint32_t k = 0; k < kItemsB; ++k) { s_run[threadIdx.x * kItemsB + k] = (uint16_t)srun; srun += tot[k]; }
-    if (threadIdx.x == 0) s_run[kBucketCap] = (uint16_t)ttot;
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t lo = tw[q] & 0xFFFFu, hi = tw[q] >> 16;
+            const uint32_t r0 = srun & 0xFFFFu, v0 = srun >> 16; srun += lo + (lo ? 0x10000u : 0u);
+            const uint32_t r1 = srun & 0xFFFFu, v1 = srun >> 16; srun += hi + (hi ? 0x10000u : 0u);
+            ro[q] = r0 | (r1 << 16); vo[q] = v0 | (v1 << 16);
+        }
+        *run4 = make_uint4(ro[0], ro[1], ro[2], ro[3]);
+        *vr4 = make_uint4(vo[0], vo[1], vo[2], vo[3]);
+    }
+    if (threadIdx.x == 0) s_run[kBucketCap] = (uint16_t)(ttot & 0xFFFFu);
     __syncthreads();
+    PCOP_STAMP(F, 2, 7, 300);
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
         if (act[j]) {
             const uint32_t d = id[j];
             const uint32_t a = s_wc[d], q = s_wc[kBucketCap + d];
-            uint32_t woff = 0u;   // points of the lower waves in this voxel
+            uint32_t woff = 0u;   // points of the lower waves with this id
             if (w >= 1u) woff += a & 0xFFFFu;
             if (w >= 2u) woff += a >> 16;
             if (w >= 3u) woff += q & 0xFFFFu;
-            stage[(uint32_t)s_run[d] + woff + rank[j]] = rec[j];
+            const uint32_t slot = (uint32_t)s_run[d] + woff + rank[j];
+            const uint32_t ps = slot + (slot >> 5);
+            stage_x[ps] = rec[j].x; stage_y[ps] = rec[j].y; stage_z[ps] = rec[j].z;
         }
     }
     __syncthreads();
-    // one lane per voxel: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count)
+    PCOP_STAMP(F, 2, 8, 300);
+    // one lane per id: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count)
     float ox[kItemsB], oy[kItemsB], oz[kItemsB];
+    uint32_t ov[kItemsB];
 #pragma unroll
     for (uint32_t k = 0; k < kItemsB; ++k) {
         const uint32_t v = k * kBlock + threadIdx.x;
-        ox[k] = oy[k] = oz[k] = 0.0f;
-        if (v < nvox) {
-            const uint32_t s = s_run[v], e = s_run[v + 1u];
+        ox[k] = oy[k] = oz[k] = 0.0f; ov[k] = 0xFFFFFFFFu;
+        const uint32_t s0 = s_run[v], e0 = s_run[v + 1u];
+        if (e0 > s0) {
             float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-            for (uint32_t q = s; q < e; ++q) { const Rec3 r = stage[q]; sx += r.x; sy += r.y; sz += r.z; }
-            const float fc = (float)(e - s);
+            for (uint32_t q = s0; q < e0; q += 4u) {   // four records requested at a time (clamped), added in order
+                float vx[4], vy[4], vz[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) { const uint32_t qq = min(q + u, e0 - 1u), ps = qq + (qq >> 5); vx[u] = stage_x[ps]; vy[u] = stage_y[ps]; vz[u] = stage_z[ps]; }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
+            }
+            const float fc = (float)(e0 - s0);
             ox[k] = sx / fc; oy[k] = sy / fc; oz[k] = sz / fc;
+            ov[k] = s_vr[v];
         }
     }
-    // voxels of the lower buckets (published early, so they are usually there by now; the wait is bounded)
+    PCOP_STAMP(F, 2, 20, 300);
+    // voxels of the lower buckets (published before their sums, so they are usually there by now; the wait is bounded)
     uint32_t lower = 0u;
     for (uint32_t t = threadIdx.x; t < b; t += kBlock) {
         uint32_t v = ld_agent(bucket_pub + t), spins = 0u;
@@ -1198,13 +1440,13 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
         lower += v - 1u;
     }
     __syncthreads();   // s_w is reused
+    PCOP_STAMP(F, 2, 9, 300);
     const uint32_t before = block_sum(lower, s_w);
     if (threadIdx.x == 0 && b + 1u == nb) finish_voxel(st, before + nvox);   // the last bucket knows M
 #pragma unroll
-    for (uint32_t k = 0; k < kItemsB; ++k) {
-        const uint32_t v = k * kBlock + threadIdx.x;
-        if (v < nvox) { cx[before + v] = ox[k]; cy[before + v] = oy[k]; cz[before + v] = oz[k]; }
-    }
+    for (uint32_t k = 0; k < kItemsB; ++k)
+        if (ov[k] != 0xFFFFFFFFu) { cx[before + ov[k]] = ox[k]; cy[before + ov[k]] = oy[k]; cz[before + ov[k]] = oz[k]; }
+    PCOP_STAMP(F, 2, 21, 300);
 }
 
 // ------------------------------------------------------------------------------------------

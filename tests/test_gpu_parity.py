@@ -462,8 +462,9 @@ def test_stream_path_grows_and_falls_back(capi, oracle, monkeypatch):
     assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
     st = c.debug_state()
     assert st.vpath == 1 and st.nb_cap == 1024 and st.nbuckets <= 1024
-    # (2) a million scattered points need more than 1024 buckets: one re-run with more of them, then it stays there
-    big = synth.uniform_field(1_000_000, 11) * f32(3.0)
+    # (2) points scattered over a wide, sparse grid need more than 1024 buckets (a bucket spans at most 2^17 cells):
+    #     one re-run with more of them, then it stays there
+    big = synth.uniform_field(300_000, 11) * f32(6.0)
     pl = dict(leaf=0.02, tol=0.05, min_cluster=2, max_cluster=20000)
     c.set_params(publish_clouds=1, **pl)
     refb = oracle.process_xyz(big, **pl)

@@ -2,7 +2,7 @@
 Only the batched launches (the most frequent grid of each kernel) are averaged."""
 import csv, collections, glob, sys
 for d in sys.argv[1:]:
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"))[0]
     rows = list(csv.DictReader(open(f)))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
