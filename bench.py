@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path (VoxelGrid -> radius graph -> Euclidean clusters) on MI355X.
 
-Metric (BASELINE.json): frames/s at a 1M-point cloud.  Workload: config C3 — 1,000,000 points,
+Metric (BASELINE.json): frames/s at a 1M-point cloud.  Workload: config C3 - 1,000,000 points,
 80 % ground plane + 20 % on 20 hovering boxes on a 4.5 m field, leaf 0.02 m, tolerance 0.1 m,
-cluster size 5..20000.  One "step" = one batch of F frames (distinct seeded
-clouds, already resident in HBM as XYZ SoA planes) pushed through the whole chain, F contexts in
-flight per GPU (contexts x batch: the frames of a batch share their kernel launches); cluster
-indices are written back to pinned host memory inside the timed region.
+cluster size 5..20000.  Every rank keeps F = contexts x batch distinct seeded clouds
+resident in HBM as XYZ SoA planes; one "round" pushes all of them through the whole chain once (the
+frames of a batch share their kernel launches, the contexts overlap on separate streams) and one
+"step" is `--rounds` rounds, so that the driver's 20 steps time about half a second of GPU work.
+Cluster indices are written back to pinned host memory inside the timed region.
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), frames sharded by rank,
-the 32-byte pcop_params struct broadcast from rank 0, no data-path collective ("weak" scaling).
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), frames sharded by rank, the
+32-byte pcop_params struct broadcast from rank 0, no data-path collective ("weak" scaling).  Run as
+`python bench.py --gpus N` (this script starts the N ranks itself) or under torchrun (RANK / WORLD_SIZE
+in the environment); a world size that does not match --gpus is an error, never a silent downgrade.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,63 +32,94 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy rate
 
 
-def kernel_alg_bytes(name, occurrence, n, m, n_cells):
-    """Algorithmic (compulsory) bytes of one launch of a kernel of the frame; DESIGN.md §Roofline.
-    n = input points, m = voxels.  `occurrence` = index of this launch among launches of the same name."""
-    if name == "k_minmax":
-        return 12 * n
-    if name == "k_bin_hist":
-        return 12 * n                   # read the xyz planes
-    if name == "k_bin_scatter":
-        return 12 * n + 12 * n          # xyz planes in, packed xyz records out
-    if name == "k_bucket_reduce":
-        return 12 * n + 12 * m          # records in, centroids out
-    if name == "k_radix_hist":
-        return 12 * n                   # xyz planes (pass 0) or packed 12-byte records
-    if name == "k_radix_scatter":
-        return (12 + 12) * n            # read every record once, write it once
-    if name == "k_voxel_reduce":
-        return 12 * n + 12 * m
-    if name == "k_cell_insert":
-        return 12 * m + 8 * m
-    if name == "k_cell_place":
-        return 12 * m + 8 * m + 16 * m
-    if name == "k_cell_mark":
-        return 12 * m + 4 * m
-    if name == "k_cell_count":
-        return 4 * m + 8 * m
-    if name == "k_cell_starts":
-        return 28 * n_cells
-    if name in ("k_cell_union", "k_cell_hook", "k_cgrid_union", "k_cgrid_hook"):
-        return 12 * m + 4 * m          # SURVEY §8d: neighbour + cluster pass reads 12·M, writes 4·M
-    if name == "k_cell_flatten":
-        return 8 * m
-    if name in ("k_csr_hist", "k_csr_scatter"):
-        return 8 * m
-    if name in ("k_kept_count", "k_kept_apply"):
-        return 4 * m
-    if name in ("k_slot_count", "k_slot_apply", "k_cell_compress"):
-        return 16 * n_cells
-    if name == "k_emit":
-        return 28 * m
-    return 0
+def kernel_alg_bytes(name, n, m, n_cells):
+    """Algorithmic (compulsory) bytes of one launch of a kernel for one frame; DESIGN.md 4.
+    n = input points, m = voxels."""
+    table = {
+        "k_minmax": 12 * n,                     # read the xyz planes
+        "k_bin_hist": 12 * n,                   # read the xyz planes
+        "k_bin_scatter": 12 * n + 12 * n,       # xyz planes in, packed xyz records out
+        "k_bucket_reduce": 12 * n + 12 * m,     # records in, centroids out
+        "k_radix_hist": 12 * n,
+        "k_radix_scatter": 24 * n,
+        "k_voxel_reduce": 12 * n + 12 * m,
+        "k_cell_insert": 20 * m,
+        "k_cell_place": 36 * m,
+        "k_cell_mark": 16 * m,
+        "k_cell_count": 12 * m,
+        "k_cell_starts": 28 * n_cells,
+        "k_cell_union": 16 * m, "k_cell_hook": 16 * m, "k_cgrid_union": 16 * m, "k_cgrid_hook": 16 * m,  # SURVEY 8d: reads 12 M, writes 4 M
+        "k_cell_flatten": 8 * m,
+        "k_csr_hist": 8 * m, "k_csr_scatter": 8 * m,
+        "k_kept_apply": 4 * m,
+        "k_slot_count": 16 * n_cells, "k_slot_apply": 16 * n_cells, "k_cell_compress": 16 * n_cells,
+        "k_emit": 28 * m,
+    }
+    return table.get(name, 0)
 
 
-kernel_alg_bytes.voxel_passes = 3
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="frames per context, processed in the same launches")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rounds", type=int, default=20, help="rounds (every resident frame once) per step")
+    ap.add_argument("--batch", type=int, default=16, help="frames per context, processed in the same launches")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) in flight per GPU")
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and the parity check that uses its results)")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry", action="store_true", help="no GPU work: the launcher, the rendezvous, the parameter broadcast and the frame sharding only")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torchrun around it.  The parent touches neither torch nor HIP.
+# ---------------------------------------------------------------------------------------------------------
+def launch_workers(args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--worker"] + ["--worker"]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=120)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+        rc = rc or p.returncode
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if rc or not line:
+        sys.stderr.write("bench.py: a rank failed (rc %s); rank 0 printed:\n%s\n" % (rc, out0))
+        sys.exit(rc or 1)
+    print(line[-1])
+    sys.exit(0)
+
+
+def latest_pmc_traffic():
+    """The newest profiles/rNN_pmc_traffic.json (the PMC passes of this command are a separate rocprofv3 run)."""
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")):
+        mt = re.match(r"r(\d+)_pmc_traffic\.json$", os.path.basename(f))
+        if mt and (best is None or int(mt.group(1)) > best[0]):
+            best = (int(mt.group(1)), f)
+    return best[1] if best else None
+
+
+def worker(args):
+    import numpy as np
     import torch  # first: its bundled HIP runtime must be the one libpcop.so binds to
     import torch.distributed as dist
 
@@ -91,48 +127,81 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus), file=sys.stderr)
-        args.gpus = world
-    torch.cuda.set_device(local_rank)
-    # PCOP_BENCH_FORCE_DIST=1 exercises the RCCL path (init, broadcast, barrier, all-reduce) with one rank too
+        sys.stderr.write("bench.py: WORLD_SIZE (%d) does not match --gpus (%d)\n" % (world, args.gpus))
+        sys.exit(2)
+    on_gpu = not args.dry
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    # PCOP_BENCH_FORCE_DIST=1 exercises the collective path (init, broadcast, barrier, all-reduce) with one rank too
     use_dist = world > 1 or os.environ.get("PCOP_BENCH_FORCE_DIST") == "1"
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from pointcloud_obstacle_processing_amd import capi, sharding, synth
 
-    # ---- parameters: rank 0 decides, everyone else receives the 32-byte struct over RCCL ----------
+    # ---- parameters: rank 0 decides, everyone else receives the 32-byte struct ----------------------
     p = synth.params_of(args.config)
     params = capi.Params(np.float32(p["leaf"]), np.float32(p["tol"]), p["min_cluster"], p["max_cluster"], 0)
     if use_dist:
-        params = sharding.broadcast_params(params if rank == 0 else None, src=0, device=torch.device("cuda", local_rank))
+        params = sharding.broadcast_params(params if rank == 0 else None, src=0, device=dev if args.backend == "nccl" else None)
 
-    # ---- frames: F per rank, seeds sharded by rank --------------------------------------------------
+    # ---- frames: F per rank, seeds sharded by rank ----------------------------------------------------
     B, NC = args.batch, args.contexts
     F = B * NC
     n_pts = synth.CONFIGS[args.config]["n"]
     seeds = sharding.frame_seeds(base_seed=3000, frames_per_rank=F, rank=rank)
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    if args.dry:   # launcher / rendezvous / sharding only
+        all_seeds = [None] * world
+        if use_dist:
+            dist.all_gather_object(all_seeds, seeds)
+        else:
+            all_seeds = [seeds]
+        fence()
+        t0 = time.perf_counter()
+        fence()
+        dt = max(time.perf_counter() - t0, 1e-9)
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "dry run: no GPU work", "value": 0.0, "unit": "frames/s", "n_gpus": world, "dry": True,
+                              "leaf": float(params.leaf), "tol": float(params.tol), "seeds": all_seeds, "frames_per_step": F * world * args.rounds}))
+        return
+
     ctxs, ptrs = [], []
     for ci in range(NC):
         c = capi.Context(n_pts, device=local_rank, max_frames=B)
         c.set_params_struct(params)
         mine = [c.upload_soa(synth.make_cloud(args.config, seed=s)) for s in seeds[ci * B:(ci + 1) * B]]
         ctxs.append(c)
-        ptrs.append(([p for p, _ in mine], [n for _, n in mine]))
+        ptrs.append(([q for q, _ in mine], [n for _, n in mine]))
 
-    # One step = every context's batch processed once.  Submission is rolling: a context's previous batch
+    # One round = every context's batch processed once.  Submission is rolling: a context's previous batch
     # is collected (results on the host) right before its next one is queued, so the other contexts' batches
     # keep the GPU busy meanwhile; drain() collects what is still in flight.  Every frame counted in a timed
     # region is submitted and collected inside it.
     pending = [False] * NC
     last_out = [None]
 
-    def step():
+    def one_round():
         for ci, (c, (pp, nn)) in enumerate(zip(ctxs, ptrs)):
             if pending[ci]:
                 last_out[0] = c.wait_batch(want_arrays=False)[-1]
@@ -146,18 +215,13 @@ def main():
                 pending[ci] = False
         return last_out[0]
 
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
+    for _ in range(args.warmup * args.rounds):
+        one_round()
     last = drain()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for _ in range(args.steps * args.rounds):
+        one_round()
     last = drain()
     fence()
     dt = time.perf_counter() - t0
@@ -165,15 +229,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    frames = world * args.steps * F
+    frames = world * args.steps * args.rounds * F
     fps = frames / dt
     m_vox = last["num_voxels"]
 
     result = None
+    rc = 0
     if rank == 0:
         # ---- single-frame latency (one context, nothing else on the GPU) -----------------------------
         c0, ptr0, n0 = ctxs[0], ptrs[0][0][0], ptrs[0][1][0]
-        m_vox = last["num_voxels"]
         lat = []
         for _ in range(20):
             t1 = time.perf_counter()
@@ -190,13 +254,11 @@ def main():
             prof.submit_batch_device(pp, nn)
             prof.wait_batch(want_arrays=False)
         acc = {}
-        reps = 10
         n_cells = 0
-        for _ in range(reps):
+        for _ in range(10):
             prof.submit_batch_device(pp, nn)
             prof.wait_batch(want_arrays=False)
-            st = prof.debug_state()
-            n_cells = st.n_cells
+            n_cells = prof.debug_state().n_cells
             seen = {}
             for nm, ms in prof.stage_times():
                 occ = seen.get(nm, 0)
@@ -204,40 +266,41 @@ def main():
                 a = acc.setdefault((nm, occ), [0.0, 0])
                 a[0] += ms
                 a[1] += 1
-        per_launch = {k: v[0] / v[1] for k, v in acc.items()}
-        by_name = {}
-        for (nm, occ), ms in per_launch.items():
-            by_name.setdefault(nm, []).append((occ, ms))
-        totals = {nm: sum(ms for _, ms in v) for nm, v in by_name.items()}
-        dom = max((nm for nm in totals if nm.startswith("k_")), key=lambda k: totals[k])
-        dom_launches = by_name[dom]
-        dom_ms = sum(ms for _, ms in dom_launches) / len(dom_launches)
-        # one launch covers B frames
-        dom_bytes = B * sum(kernel_alg_bytes(dom, occ, n0, m_vox, n_cells) for occ, _ in dom_launches) / len(dom_launches)
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        frame_bytes = 12 * n0 + 28 * m_vox
         prof.close()
-        # the same figures for every kernel that takes at least 5 % of the batch, largest first
+        by_name = {}
+        for (nm, occ), (ms, cnt) in acc.items():
+            by_name.setdefault(nm, []).append(ms / cnt)
+        totals = {nm: sum(v) for nm, v in by_name.items()}
+
+        def roof(nm):
+            ls = by_name[nm]
+            ms = sum(ls) / len(ls)   # average duration of one launch (a launch covers B frames)
+            nbytes = B * kernel_alg_bytes(nm, n0, m_vox, n_cells)
+            return ms, nbytes, (nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
+
+        dom = max((nm for nm in totals if nm.startswith("k_")), key=lambda k: totals[k])
+        dom_ms, dom_bytes, achieved = roof(dom)
         total_ms = sum(totals.values())
         by_kernel = []
         for nm in sorted(totals, key=lambda k: -totals[k]):
             if not nm.startswith("k_") or totals[nm] < 0.05 * total_ms:
                 continue
-            ls = by_name[nm]
-            ms = sum(t for _, t in ls) / len(ls)
-            nbytes = B * sum(kernel_alg_bytes(nm, occ, n0, m_vox, n_cells) for occ, _ in ls) / len(ls)
-            by_kernel.append({"kernel": nm, "launches_per_batch": len(ls), "avg_launch_ms": round(ms, 5),
-                              "alg_bytes_per_launch": nbytes, "achieved_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
-                              "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-        # HBM bytes per launch from the committed PMC passes of this command (profiles/), if they match
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            for k, v in pmc.items():
-                if k.split("::")[-1].split("<")[0] == dom and v.get("batch") == B:
-                    traffic = v["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+            ms, nbytes, gbs = roof(nm)
+            by_kernel.append({"kernel": nm, "launches_per_batch": len(by_name[nm]), "avg_launch_ms": round(ms, 5),
+                              "alg_bytes_per_launch": nbytes, "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        # HBM bytes per launch of the dominant kernel: from the newest committed PMC passes of this command (a separate
+        # rocprofv3 run: counters cannot be collected inside this process), when they were taken at this batch size
+        traffic, traffic_source = None, None
+        f = latest_pmc_traffic()
+        if f:
+            try:
+                for k, v in json.load(open(f)).items():
+                    if k.split("::")[-1].split("<")[0].split("(")[0] == dom and v.get("batch") == B:
+                        traffic = v["hbm_bytes_per_launch"]
+                        traffic_source = "profiles/" + os.path.basename(f) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
+            except Exception:
+                traffic = None
+        frame_bytes = 12 * n0 + 28 * m_vox
 
         result = {
             "metric": "frames/sec at 1M-pt cloud, 1/2/4/8 MI355X; HBM GB/s vs roofline",
@@ -246,13 +309,13 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-pt ground-plane + 20 boxes (L=4.5 m), leaf %g m, tol %g m, clusters %d..%d"
                        % (args.config, n0, p["leaf"], p["tol"], p["min_cluster"], p["max_cluster"]),
-                       "frames_in_flight_per_gpu": F, "batch_per_launch": B, "contexts_per_gpu": NC,
-                       "frames_per_step": F * world, "voxels_per_frame": int(m_vox),
+                       "frames_in_flight_per_gpu": F, "batch_per_launch": B, "contexts_per_gpu": NC, "rounds_per_step": args.rounds,
+                       "frames_per_step": F * world * args.rounds, "timed_region_s": dt, "voxels_per_frame": int(m_vox),
                        "input": "XYZ SoA resident in HBM", "parallelism": "frame-sharded, %d rank(s)" % world},
             "latency_ms_single_frame": lat_ms,
-            "roofline": {"bound": "hbm", "kernel": dom, "launches_per_frame": len(dom_launches),
+            "roofline": {"bound": "hbm", "kernel": dom, "launches_per_frame": len(by_name[dom]),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes,
+                         "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom_bytes,
                          "frames_per_launch": B, "peak_measured_copy": 6290.0},
             "roofline_by_kernel": by_kernel,
             "frame_roofline": {"alg_bytes_per_frame": frame_bytes,
@@ -262,21 +325,72 @@ def main():
             "kernel_ms": {nm: round(t, 5) for nm, t in sorted(totals.items(), key=lambda kv: -kv[1])},
         }
 
-        # ---- CPU baseline: the oracle (a restatement of the PCL path, not PCL) on this box's host cores ----
+        # ---- end to end: the same pipeline fed from pinned host memory (12 MB per frame over PCIe inside the timed region) ----
+        if not args.no_end_to_end:
+            import ctypes as C
+            host = [torch.from_numpy(np.ascontiguousarray(synth.make_cloud(args.config, seed=s).T.reshape(-1))).pin_memory() for s in seeds[:4]]
+            hp = (C.c_void_p * B)(*[C.c_void_p(host[i % len(host)].data_ptr()) for i in range(B)])
+            cnt = (C.c_size_t * B)(*[n0] * B)
+            res = (capi.Result * B)()
+
+            def h_submit(c):
+                c._chk(c.lib.pcop_submit_batch(c.h, hp, capi.LAYOUT_SOA, cnt, B, 1, capi.MEM_HOST))
+
+            def h_wait(c):
+                c._chk(c.lib.pcop_wait_batch(c.h, res, B))
+
+            for c in ctxs:
+                h_submit(c)
+                h_wait(c)
+            e_rounds = max(4, 384 // F)
+            for c in ctxs:
+                h_submit(c)
+            t1 = time.perf_counter()
+            for _ in range(e_rounds):
+                for c in ctxs:
+                    h_wait(c)
+                    h_submit(c)
+            edt = time.perf_counter() - t1
+            for c in ctxs:
+                h_wait(c)
+            efps = e_rounds * F / edt
+            result["end_to_end"] = {"value": efps, "unit": "frames/s", "frames": e_rounds * F,
+                                    "input": "XYZ SoA in pinned host memory; the H2D copy of 12 MB per frame is inside the timed region",
+                                    "pcie_GBs": efps * 12.0 * n0 / 1e9}
+
+        # ---- CPU baseline: the oracle (a restatement of the PCL path, not PCL) on this box's host cores; its results for the
+        #      first frames are then compared with what the GPU gives for the same clouds (outside every timed region) ----
         if not args.no_cpu_baseline:
             from oracle import oracle as O
             O.build()
             clouds = [synth.make_cloud(args.config, seed=s) for s in seeds[: min(2, len(seeds))]]
+            refs = []
             t1 = time.perf_counter()
             done = 0
             while done < args.cpu_frames and time.perf_counter() - t1 < 25.0:
-                O.process_xyz(clouds[done % len(clouds)], **p)
+                r = O.process_xyz(clouds[done % len(clouds)], **p)
+                if done < len(clouds):
+                    refs.append(r)
                 done += 1
             cdt = time.perf_counter() - t1
             result["cpu_baseline"] = {"value": done / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
                                       "sample": "%d frames of %s (%d pts) through oracle/pcl_restatement.cpp "
                                                 "(kd-tree built twice, sorted radius search, serial BFS), 1 thread, "
                                                 "host has %d cores" % (done, args.config, n0, os.cpu_count())}
+            chk = capi.Context(n_pts, device=local_rank)
+            chk.set_params(leaf=p["leaf"], tol=p["tol"], min_cluster=p["min_cluster"], max_cluster=p["max_cluster"], publish_clouds=1)
+            bad = []
+            for i, ref in enumerate(refs):
+                got = chk.process_xyz(clouds[i])
+                same = (got["voxel_xyz"] is not None and got["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes()
+                        and np.array_equal(got["offsets"], ref["offsets"]) and np.array_equal(got["indices"], ref["indices"]))
+                if not same:
+                    bad.append(seeds[i])
+            chk.close()
+            result["parity_checked"] = len(refs)
+            result["parity"] = "bit-exact vs the CPU restatement (centroids, cluster offsets, indices)" if not bad else "MISMATCH on seeds %s" % bad
+            if bad:
+                rc = 1
 
     for c in ctxs:
         c.close()
@@ -285,6 +399,19 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+    if rc:
+        sys.stderr.write("bench.py: GPU results differ from the CPU restatement\n")
+        sys.exit(rc)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if args.gpus > 1 and "RANK" not in os.environ and not args.worker:
+        launch_workers(args)   # does not return
+    worker(args)
 
 
 if __name__ == "__main__":

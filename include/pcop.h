@@ -194,7 +194,8 @@ int pcop_process_filtered(pcop_ctx* ctx, pcop_result* out);
  * sequential double sum in the reference and is formed on the host in the same order, as is the final
  * `distance > threshold` selection.  xyz / layout as in pcop_voxel_downsample (host memory); out_xyz receives
  * the kept points in input order and the same layout (room for n points).  distances (n floats) and threshold
- * may be NULL.  1 <= mean_k <= 31; a cloud with fewer than mean_k + 1 points, or with a non-finite coordinate,
+ * may be NULL.  1 <= mean_k <= 31.  An empty cloud gives an empty cloud (as sor2.filter does: the robot sees
+ * nothing in range and cloud_cb carries on); a cloud with 1 .. mean_k points, or with a non-finite coordinate,
  * is refused (PCOP_ERR_PARAM / PCOP_ERR_NONFINITE): the reference reads past its search result on the former. */
 int pcop_statistical_outlier_removal(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int mean_k, float stddev_mul,
                                      float* out_xyz, size_t* n_out, float* distances, double* threshold);

@@ -469,8 +469,10 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             if (hs->err & kErrReplanVoxel) kb_voxel = std::max(kb_voxel, hs->plan_voxel.key_bits);
             if (hs->err & kErrReplanCsr) kb_csr = std::max(kb_csr, hs->plan_csr.key_bits);
         }
-        if (e & kErrNonFinite) { c->in_flight = false; c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
-        if (e & kErrRange) { c->in_flight = false; c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
+        // every error return leaves the occupancy flags all zero again (a frame given up half-way may have marked cells
+        // beyond the tiles its scan was launched with)
+        if (e & kErrNonFinite) { c->in_flight = false; scrub_flags(c); c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
+        if (e & kErrRange) { c->in_flight = false; scrub_flags(c); c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
         if (e & kErrInternal) { c->in_flight = false; scrub_flags(c); c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
         if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanBins | kErrReplanCpath | kErrReplanCtiles)) {
             if (attempt >= 6) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
@@ -772,6 +774,7 @@ int pcop_max_frames(const pcop_ctx* c) { return c ? (int)c->max_frames : 0; }
 
 int pcop_set_params(pcop_ctx* c, const pcop_params* p) {
     if (!c || !p) return PCOP_ERR_ARG;
+    if (c->in_flight) { c->err = "parameters cannot change while a batch is in flight (its re-planning and ordering read them)"; return PCOP_ERR_STATE; }
     if (!c->params_set || p->leaf != c->params.leaf) c->stream_ok = true;   // a new leaf size is a new voxel grid
     if (!c->params_set || p->tol != c->params.tol) c->cgrid_ok = true;      // a new tolerance is a new cell grid
     c->params = *p;
@@ -938,6 +941,7 @@ int pcop_occupancy_filter(pcop_ctx* c, const float* xyz, int layout, size_t n, i
     if ((std::fabs(p->x_min) + std::fabs(p->x_max) + std::fabs(p->y_min) + std::fabs(p->y_max)) / p->block_size > 1.0e8f) { c->err = "limits / block_size too large"; return PCOP_ERR_PARAM; }
     if ((rc = set_device(c))) return rc;
     Slot& sl = c->slots[0];
+    sl.have_result = false;   // slot 0's staging buffers are about to be overwritten
     if ((rc = stage_input(c, sl, xyz, layout, n, mem))) return rc;
     const size_t cells = (size_t)p->grid_width * p->grid_height, rows = (size_t)p->grid_height;
     if (!c->occ_xyz) {
@@ -1024,6 +1028,7 @@ int pcop_process_filtered(pcop_ctx* c, pcop_result* out) {
 // One eager pass of a cluster-only frame up to the point where the requested stage has run; k_emit at the end puts
 // the DevState into pinned host memory and hands the borrowed per-cell counters back clean.
 static int sor_pass(pcop_ctx* c, Slot& sl, double inv_cell, bool with_knn, uint32_t mean_k, double edge) {
+    sl.have_result = false;   // the slot's device state is about to be overwritten: no cluster summaries from it afterwards
     FrameArgs& a = *sl.h_args;
     std::memset(&a, 0, sizeof(a));
     a.n = sl.n; a.is_dense = 1u; a.kind = kFrameClusterOnly; a.trivial = 0u;
@@ -1066,8 +1071,14 @@ int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, 
     if (!c || !n_out || (!out_xyz && n) || (!xyz && n)) return PCOP_ERR_ARG;
     int rc = busy(c);
     if (rc) return rc;
+    c->slots[0].have_result = false;
     if (mean_k < 1 || mean_k + 1 > kKnnMax) { c->err = "mean_k must be 1..31"; return PCOP_ERR_PARAM; }
     if (!std::isfinite(stddev_mul)) { c->err = "stddev multiplier must be finite"; return PCOP_ERR_PARAM; }
+    if (n == 0) {   // sor2.filter on an empty cloud gives an empty cloud and the callback carries on (the robot sees nothing in range)
+        *n_out = 0;
+        if (threshold) *threshold = 0.0;
+        return PCOP_OK;
+    }
     if (n < (size_t)mean_k + 1) { c->err = "fewer points than mean_k + 1: the reference reads past its k-NN result"; return PCOP_ERR_PARAM; }
     if (!c->cell_grid) { c->err = "statistical outlier removal needs the dense cell grid (context created with PCOP_CELL_PATH=hash)"; return PCOP_ERR_STATE; }
     if ((rc = set_device(c))) return rc;

@@ -548,6 +548,77 @@ def test_stream_path_nonfinite_points_dropped(capi, oracle, monkeypatch):
     c.close()
 
 
+def test_error_frame_leaves_no_marks_behind(capi, oracle):
+    """A frame given up with an error (NaN in a cloud declared dense) on a cell grid larger than the occupancy scan was
+    launched for must not leave occupancy flags set: the next frame on the same context equals the oracle."""
+    c = capi.Context(300_000)
+    small = synth.make_cloud("C1")
+    c.set_params(publish_clouds=1, **synth.params_of("C1"))
+    for rep in range(3):
+        c.process_xyz(small)                       # the scan grid shrinks to what this small cloud needs
+    wide = synth.uniform_field(250_000, 31) * f32(4.0)
+    bad = wide.copy()
+    bad[123_456, 2] = np.nan
+    p = dict(leaf=0.05, tol=0.05, min_cluster=2, max_cluster=20000)
+    c.set_params(publish_clouds=1, **p)
+    with pytest.raises(capi.PcopError) as e:
+        c.euclidean_clusters(bad)                  # cell marking sees the NaN while the scan grid is too small
+    assert e.value.status == -6
+    ref = oracle.process_xyz(wide, **p)
+    got = c.process_xyz(wide)
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    assert not c.debug_buffer("cflag", np.uint8, 1 << 24).any()
+    c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# C5 at full size (BASELINE.json configs[4]): 5,000,000 points, leaf 0.01 m, tolerance 0.05 m
+# ---------------------------------------------------------------------------------------------
+_c5_cache = {}
+
+
+def _c5(oracle, seed):
+    if seed not in _c5_cache:
+        pts = synth.make_cloud("C5", seed=seed)
+        _c5_cache[seed] = (pts, oracle.process_xyz(pts, **synth.params_of("C5")))
+    return _c5_cache[seed]
+
+
+@pytest.mark.parametrize("paths", ["stream+grid", "sort+hash"])
+def test_c5_full_size_chain(capi, oracle, monkeypatch, paths):
+    vox, cell = paths.split("+")
+    monkeypatch.setenv("PCOP_VOXEL_PATH", vox)
+    monkeypatch.setenv("PCOP_CELL_PATH", cell)
+    pts, ref = _c5(oracle, 5)
+    assert len(pts) == 5_000_000 and len(ref["voxel_xyz"]) > 4_000_000
+    c = capi.Context(len(pts))
+    c.set_params(publish_clouds=1, **synth.params_of("C5"))
+    for rep in range(2):   # the first call grows the bucket provision, the second runs the settled plan
+        got = c.process_xyz(pts)
+        assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    st = c.debug_state()
+    # C5 does not fit the streaming path yet: its ground plane puts about 30 000 points into one coarse key bin
+    # (2 x 10^8 cells / 2^14 bins) where a bucket holds 2048, so the frame is re-run on the sort path (DESIGN.md 4.1)
+    assert st.vpath == 0 and st.passthrough == 0
+    c.close()
+
+
+def test_c5_batch_of_two(capi, oracle):
+    """Two different 5M-point frames in the same launches."""
+    c = capi.Context(5_000_000, max_frames=2)
+    c.set_params(publish_clouds=1, **synth.params_of("C5"))
+    frames = [_c5(oracle, 5), _c5(oracle, 6)]
+    c.submit_batch_host([f[0] for f in frames])
+    res = c.wait_batch()
+    for got, (_, ref) in zip(res, frames):
+        assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    c.close()
+    _c5_cache.clear()
+
+
 # ---------------------------------------------------------------------------------------------
 # dense cell grid: stage-wise check and its fallback to the hash table
 # ---------------------------------------------------------------------------------------------

@@ -64,6 +64,23 @@ def test_degenerate_shapes_and_duplicates(ctx, oracle):
     check(ctx, oracle, tiny, 15, 1.0)
 
 
+def test_empty_cloud_gives_empty_cloud(ctx):
+    """sor2.filter on an empty input returns an empty cloud (od.cpp:316-340 after a bounds filter that kept nothing)."""
+    got = ctx.statistical_outlier_removal(np.zeros((0, 3), dtype=f32), 15, 4.0)
+    assert len(got["xyz"]) == 0 and len(got["distances"]) == 0
+
+
+def test_params_cannot_change_under_a_batch(ctx, capi):
+    """pcop_set_params between submit and wait would mix two parameter sets in the re-planning and the ordering."""
+    pts = synth.make_cloud("C1")
+    ctx.set_params(publish_clouds=1, **synth.params_of("C1"))
+    ctx.submit_batch_host([pts])
+    with pytest.raises(capi.PcopError) as e:
+        ctx.set_params(leaf=0.5, tol=0.1)
+    assert e.value.status == -8          # PCOP_ERR_STATE
+    assert ctx.wait_batch()[0]["num_voxels"] > 0
+
+
 def test_refusals(ctx, capi):
     pts = np.random.default_rng(8).uniform(0, 1, (100, 3)).astype(f32)
     with pytest.raises(capi.PcopError) as e:

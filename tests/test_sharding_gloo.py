@@ -63,3 +63,41 @@ def test_params_roundtrip():
     p = capi.Params(np.float32(0.015), np.float32(0.4), 5, 20000, 1)
     q = sharding.params_from_bytes(sharding.params_to_bytes(p))
     assert bytes(p) == bytes(q)
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py as the driver runs it: `python bench.py --gpus N` starts the N ranks itself
+# ---------------------------------------------------------------------------------------------
+def _bench(args, env=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=e, capture_output=True, text=True,
+                         timeout=timeout)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out.returncode, (json.loads(lines[-1]) if lines else None), out.stderr
+
+
+def test_bench_launcher_starts_two_ranks():
+    """`bench.py --gpus 2` (no torchrun around it) = two ranks, the parameters of rank 0 on both, disjoint frame seeds."""
+    rc, d, err = _bench(["--gpus", "2", "--backend", "gloo", "--dry", "--batch", "4", "--contexts", "2"])
+    assert rc == 0, err
+    assert d["n_gpus"] == 2 and d["dry"] is True
+    assert len(d["seeds"]) == 2 and len(d["seeds"][0]) == 8 and set(d["seeds"][0]).isdisjoint(d["seeds"][1])
+    assert np.float32(d["leaf"]) == np.float32(0.02) and np.float32(d["tol"]) == np.float32(0.1)
+
+
+def test_bench_refuses_a_world_size_that_does_not_match():
+    """A world size other than --gpus is an error (exit code 2), never a silent downgrade to fewer GPUs."""
+    rc, d, err = _bench(["--gpus", "2", "--backend", "gloo", "--dry"], env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert rc == 2 and d is None and "does not match" in err
+
+
+def test_bench_failed_rank_fails_the_launcher():
+    rc, d, err = _bench(["--gpus", "2", "--backend", "gloo", "--dry", "--config", "no-such-config"])
+    assert rc != 0 and d is None
