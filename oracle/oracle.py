@@ -40,6 +40,11 @@ def lib():
         L.pcop_oracle_voxel_downsample.restype = C.c_int
         L.pcop_oracle_voxel_downsample.argtypes = [fp, C.c_int, C.c_size_t, C.c_float, C.c_int, fp,
                                                    C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.pcop_oracle_voxel_downsample_ex.restype = C.c_int
+        L.pcop_oracle_voxel_downsample_ex.argtypes = [fp, C.c_int, C.c_size_t, C.c_float, C.c_int, C.c_int, fp,
+                                                      C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.pcop_oracle_knife_edge_report.restype = C.c_int
+        L.pcop_oracle_knife_edge_report.argtypes = [fp, C.c_int, C.c_size_t, C.c_float, C.c_int, C.POINTER(C.c_int64)]
         L.pcop_oracle_euclidean_clusters_ex.restype = C.c_int
         L.pcop_oracle_euclidean_clusters_ex.argtypes = [fp, C.c_int, C.c_size_t, C.c_float, C.c_int32, C.c_int32,
                                                         C.c_int, ip, ip, ip]
@@ -147,14 +152,18 @@ def voxel_keys(xyz, leaf, is_dense=True, layout=LAYOUT_AOS12):
     return keys[:n], grid, bool(pt)
 
 
-def voxel_downsample(xyz, leaf, is_dense=True, layout=LAYOUT_AOS12):
-    """-> (centroids (m,3) float32, passthrough bool)."""
+VARIANT_RECIPROCAL = 1   # centroid = sum * (1.0f / n): PCL 1.7 + Eigen 3.2
+VARIANT_DESCENDING = 2   # equal voxel keys keep descending point index: another order an unstable std::sort may leave
+
+
+def voxel_downsample(xyz, leaf, is_dense=True, layout=LAYOUT_AOS12, variant=0):
+    """-> (centroids (m,3) float32, passthrough bool).  variant: the other legal instances of PCL's open choices."""
     flat, n = _pack(xyz, layout)
     out = np.zeros(max(4 * n, 4), dtype=np.float32)
     m = C.c_size_t(0)
     pt = C.c_int(0)
-    rc = lib().pcop_oracle_voxel_downsample(_f(flat), layout, n, np.float32(leaf), int(is_dense), _f(out),
-                                            C.byref(m), C.byref(pt))
+    rc = lib().pcop_oracle_voxel_downsample_ex(_f(flat), layout, n, np.float32(leaf), int(is_dense), int(variant), _f(out),
+                                               C.byref(m), C.byref(pt))
     if rc:
         raise ValueError("oracle voxel_downsample rc=%d" % rc)
     return _unpack(out, layout, m.value, n), bool(pt.value)
@@ -194,6 +203,17 @@ def cluster_summaries(xyz, offsets, indices, layout=LAYOUT_AOS12):
 def knife_edge_pairs(xyz, tol, ulps=4):
     flat, m = _pack(xyz, LAYOUT_AOS12)
     return int(lib().pcop_oracle_knife_edge_pairs(_f(flat), LAYOUT_AOS12, m, np.float32(tol), int(ulps)))
+
+
+def knife_edge_report(xyz, tol, ulps=4):
+    """The margin diagnostic of SURVEY.md 8c on a cloud of any size -> (pairs with d2 within `ulps` ulp of r2,
+    how many of them decide the components)."""
+    flat, m = _pack(xyz, LAYOUT_AOS12)
+    out = (C.c_int64 * 2)()
+    rc = lib().pcop_oracle_knife_edge_report(_f(flat), LAYOUT_AOS12, m, np.float32(tol), int(ulps), out)
+    if rc:
+        raise ValueError("oracle knife_edge_report rc=%d" % rc)
+    return int(out[0]), int(out[1])
 
 
 def process_xyz(xyz, leaf, tol, min_cluster, max_cluster, is_dense=True, layout=LAYOUT_AOS12):

@@ -295,8 +295,20 @@ int pcop_oracle_voxel_keys(const float* xyz, int layout, size_t n, float leaf, i
 // Canonical instance of the implementation-defined parts: equal keys keep
 // ascending point index (PCL's std::sort is unstable), centroid = sum / float(n)
 // (PCL >= 1.8 AccumulatorXYZ).  Output layout = input layout; SOA stride = n.
+// variant: the other legal instances of what PCL leaves open, for the test that shows the
+// cluster indices do not depend on them:
+//   bit 0: centroid = sum * (1.0f / n)  (PCL 1.7 + Eigen 3.2: the Vector4f accumulator's "/= n" multiplies by the reciprocal)
+//   bit 1: equal keys keep DESCENDING point index (one of the orders an unstable std::sort may leave)
+int pcop_oracle_voxel_downsample_ex(const float* xyz, int layout, size_t n, float leaf, int is_dense, int variant,
+                                    float* out_xyz, size_t* out_m, int* passthrough);
+
 int pcop_oracle_voxel_downsample(const float* xyz, int layout, size_t n, float leaf, int is_dense,
                                  float* out_xyz, size_t* out_m, int* passthrough) {
+    return pcop_oracle_voxel_downsample_ex(xyz, layout, n, leaf, is_dense, 0, out_xyz, out_m, passthrough);
+}
+
+int pcop_oracle_voxel_downsample_ex(const float* xyz, int layout, size_t n, float leaf, int is_dense, int variant,
+                                    float* out_xyz, size_t* out_m, int* passthrough) {
     if (!xyz && n) return -1;
     if (!(leaf > 0.0f) || !std::isfinite(leaf)) return -2;
     VoxelSetup s = voxel_setup(xyz, layout, n, leaf, is_dense != 0);
@@ -314,8 +326,9 @@ int pcop_oracle_voxel_downsample(const float* xyz, int layout, size_t n, float l
         iv.push_back({voxel_key(s, p), static_cast<uint32_t>(i)});
     }
     // "Second pass: sort the index_vector" — by key; ties by point index (canonical).
-    std::sort(iv.begin(), iv.end(), [](const KeyIdx& a, const KeyIdx& b) {
-        return a.key < b.key || (a.key == b.key && a.idx < b.idx);
+    const bool descending = (variant & 2) != 0;
+    std::sort(iv.begin(), iv.end(), [descending](const KeyIdx& a, const KeyIdx& b) {
+        return a.key < b.key || (a.key == b.key && (descending ? a.idx > b.idx : a.idx < b.idx));
     });
     // "Third/Fourth pass": one output point per run of equal keys, in key order.
     size_t m = 0, i = 0;
@@ -328,7 +341,8 @@ int pcop_oracle_voxel_downsample(const float* xyz, int layout, size_t n, float l
             ++j;
         }
         const float cnt = static_cast<float>(j - i);
-        store_pt(out_xyz, layout, n, m, P3{sx / cnt, sy / cnt, sz / cnt});
+        if (variant & 1) { const float inv = 1.0f / cnt; store_pt(out_xyz, layout, n, m, P3{sx * inv, sy * inv, sz * inv}); }
+        else store_pt(out_xyz, layout, n, m, P3{sx / cnt, sy / cnt, sz / cnt});
         ++m;
         i = j;
     }
@@ -472,6 +486,76 @@ int64_t pcop_oracle_knife_edge_pairs(const float* xyz, int layout, size_t m, flo
         }
     }
     return cnt;
+}
+
+// The margin diagnostic for clouds of any size (a uniform grid of cell edge tol finds the candidate pairs):
+//   out[0] = unordered pairs with d2 within `ulps` units in the last place of r2 (on either side),
+//   out[1] = how many of them decide the components: a pair just outside the radius whose points lie in
+//            different components, plus the components that would fall apart if every pair just inside
+//            the radius were dropped.  0 means: no last-bit change of one squared distance moves a cluster border.
+int pcop_oracle_knife_edge_report(const float* xyz, int layout, size_t m, float tol, int ulps, int64_t* out) {
+    out[0] = out[1] = 0;
+    if (m == 0) return 0;
+    const float r2 = pcop_oracle_r2(tol);
+    if (!(r2 > 0.0f)) return 0;
+    int32_t r2bits; std::memcpy(&r2bits, &r2, 4);
+    const double inv = 1.0 / std::fabs(static_cast<double>(tol));
+    std::vector<P3> pts(m);
+    std::vector<int64_t> cx(m), cy(m), cz(m);
+    for (size_t i = 0; i < m; ++i) {
+        pts[i] = load_pt(xyz, layout, m, i);
+        if (!finite3(pts[i])) return -3;
+        cx[i] = static_cast<int64_t>(std::floor(pts[i].x * inv)); cy[i] = static_cast<int64_t>(std::floor(pts[i].y * inv));
+        cz[i] = static_cast<int64_t>(std::floor(pts[i].z * inv));
+    }
+    std::vector<uint32_t> order(m);
+    for (size_t i = 0; i < m; ++i) order[i] = static_cast<uint32_t>(i);
+    auto less = [&](uint32_t a, uint32_t b) { return cz[a] != cz[b] ? cz[a] < cz[b] : cy[a] != cy[b] ? cy[a] < cy[b] : cx[a] < cx[b]; };
+    std::sort(order.begin(), order.end(), less);
+    struct Cell { int64_t x, y, z; size_t b, e; };
+    std::vector<Cell> cells;
+    for (size_t i = 0; i < m;) {
+        size_t j = i;
+        while (j < m && cx[order[j]] == cx[order[i]] && cy[order[j]] == cy[order[i]] && cz[order[j]] == cz[order[i]]) ++j;
+        cells.push_back({cx[order[i]], cy[order[i]], cz[order[i]], i, j});
+        i = j;
+    }
+    auto find_cell = [&](int64_t x, int64_t y, int64_t z) -> const Cell* {
+        size_t lo = 0, hi = cells.size();
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            const Cell& c = cells[mid];
+            const bool lt = c.z != z ? c.z < z : c.y != y ? c.y < y : c.x < x;
+            if (lt) lo = mid + 1; else hi = mid;
+        }
+        return (lo < cells.size() && cells[lo].x == x && cells[lo].y == y && cells[lo].z == z) ? &cells[lo] : nullptr;
+    };
+    std::vector<uint32_t> ua(m), ub(m);   // components with every pair inside the radius / without the knife-edge ones
+    for (size_t i = 0; i < m; ++i) ua[i] = ub[i] = static_cast<uint32_t>(i);
+    auto find = [](std::vector<uint32_t>& u, uint32_t v) { while (u[v] != v) { u[v] = u[u[v]]; v = u[v]; } return v; };
+    auto unite = [&](std::vector<uint32_t>& u, uint32_t a, uint32_t b) { a = find(u, a); b = find(u, b); if (a != b) u[std::max(a, b)] = std::min(a, b); };
+    std::vector<std::pair<uint32_t, uint32_t>> near_out;
+    for (const Cell& c : cells) {
+        for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+            const Cell* o = find_cell(c.x + dx, c.y + dy, c.z + dz);
+            if (!o) continue;
+            for (size_t a = c.b; a < c.e; ++a) for (size_t b = o->b; b < o->e; ++b) {
+                const uint32_t i = order[a], j = order[b];
+                if (i >= j) continue;
+                const float d = l2_simple(pts[i], pts[j]);
+                int32_t db; std::memcpy(&db, &d, 4);
+                const bool knife = std::llabs(static_cast<long long>(db) - r2bits) <= ulps;
+                if (knife) ++out[0];
+                if (d < r2) { unite(ua, i, j); if (!knife) unite(ub, i, j); }
+                else if (knife) near_out.push_back({i, j});
+            }
+        }
+    }
+    size_t ca = 0, cb = 0;
+    for (size_t i = 0; i < m; ++i) { if (find(ua, static_cast<uint32_t>(i)) == i) ++ca; if (find(ub, static_cast<uint32_t>(i)) == i) ++cb; }
+    out[1] = static_cast<int64_t>(cb - ca);
+    for (const auto& pr : near_out) if (find(ua, pr.first) != find(ua, pr.second)) ++out[1];
+    return 0;
 }
 
 // Whole chain of SURVEY.md §3.3 on one cloud: voxel grid, then clustering of

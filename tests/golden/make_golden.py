@@ -26,11 +26,15 @@ def main():
         pts = synth.make_cloud(cfg, seed=seed, n=n)
         r = O.process_xyz(pts, **p)
         xyzr = O.cluster_summaries(r["voxel_xyz"], r["offsets"], r["indices"])
+        # margin diagnostic: pairs of voxel centroids whose squared distance is within 4 ulp of r2, and how
+        # many of those decide a cluster border
+        knife, critical = O.knife_edge_report(r["voxel_xyz"], p["tol"], 4)
         np.savez_compressed(os.path.join(HERE, "%s_seed%d.npz" % (cfg.lower(), seed)), config=cfg, seed=seed,
                             n=len(pts), leaf=p["leaf"], tol=p["tol"], min_cluster=p["min_cluster"],
                             max_cluster=p["max_cluster"], input_sha=np.frombuffer(pts.tobytes()[:64], dtype=np.uint8),
-                            voxel_xyz=r["voxel_xyz"], offsets=r["offsets"], indices=r["indices"], xyzr=xyzr)
-        print(cfg, "N", len(pts), "M", len(r["voxel_xyz"]), "K", len(r["offsets"]) - 1)
+                            voxel_xyz=r["voxel_xyz"], offsets=r["offsets"], indices=r["indices"], xyzr=xyzr,
+                            knife_edge_pairs=knife, knife_edge_critical=critical)
+        print(cfg, "N", len(pts), "M", len(r["voxel_xyz"]), "K", len(r["offsets"]) - 1, "knife-edge pairs", knife, "critical", critical)
 
 
 def occupancy_case():
