@@ -75,7 +75,8 @@ typedef struct pcop_result {
     int32_t        num_indices;   /* offsets[K]                                                    */
     const int32_t* offsets;       /* K+1 CSR offsets                                               */
     const int32_t* indices;       /* indices into the downsampled cloud, ascending per cluster     */
-    const float*   voxel_xyz;     /* M x AOS12 centroids; NULL unless publish_clouds != 0          */
+    const float*   voxel_xyz;     /* M centroids in the context's cloud layout (AOS12 unless
+                                     pcop_set_cloud_layout chose another); NULL unless publish_clouds != 0 */
 } pcop_result;
 
 /* Per-stage device times of the last frame (milliseconds, HIP events on the
@@ -151,6 +152,17 @@ int pcop_wait_batch(pcop_ctx* ctx, pcop_result* out, int nframes);
  * xyzr[4*c..] = centre x,y,z and radius r of cluster c (definition: DESIGN.md). */
 int pcop_cluster_summaries(pcop_ctx* ctx, float* xyzr, int32_t cap_clusters);
 int pcop_cluster_summaries_frame(pcop_ctx* ctx, int frame, float* xyzr, int32_t cap_clusters);
+
+/* ---- egress in the layout pcl::toROSMsg gives a PointCloud<PointXYZ> (od.cpp:288-295, 861-866) -------------
+ * The frame API's voxel cloud (pcop_result.voxel_xyz, the `voxel_grid` topic) is written by the GPU in `layout`:
+ * PCOP_LAYOUT_AOS16 = the 16-byte {x, y, z, 1.0f} records of pcl::PointXYZ, i.e. the data blob of the PointCloud2
+ * message as it stands (no host re-pack); PCOP_LAYOUT_AOS12 (the default) = packed xyz.  SOA is not offered here. */
+int pcop_set_cloud_layout(pcop_ctx* ctx, int layout);
+/* The `euc_clusters` cloud of a finished frame (od.cpp:861-866, commented intent): the points of all kept clusters,
+ * cluster after cluster in the order of pcop_result.offsets, gathered on the GPU as 16-byte {x, y, z, 1.0f} records.
+ * *xyz16 points to pinned host memory owned by the context (valid until the next call on it); *n_points =
+ * pcop_result.num_indices. */
+int pcop_cluster_cloud(pcop_ctx* ctx, int frame, const float** xyz16, int32_t* n_points);
 
 /* ---- the step before the hot path: bounds filter + occupancy binning -------------
  * Replaces build_initial_occupancy_grid_dataset (od.cpp:175-269) with its helpers

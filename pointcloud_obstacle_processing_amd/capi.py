@@ -20,7 +20,7 @@ EXPORTS = [
     "pcop_set_profiling", "pcop_get_stage_times", "pcop_stream", "pcop_voxel_downsample", "pcop_euclidean_clusters",
     "pcop_process_pointcloud2", "pcop_process_xyz", "pcop_submit_xyz", "pcop_wait", "pcop_cluster_summaries",
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
-    "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
+    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
     "pcop_cluster_summaries_frame", "pcop_occupancy_grid_dims", "pcop_occupancy_filter", "pcop_process_filtered",
     "pcop_statistical_outlier_removal",
 ]
@@ -63,7 +63,7 @@ class DevState(C.Structure):
     _fields_ = [("err", C.c_uint32), ("n_in", C.c_uint32), ("is_dense", C.c_uint32), ("n_valid", C.c_uint32),
                 ("passthrough", C.c_uint32), ("m", C.c_uint32), ("kind", C.c_uint32), ("trivial", C.c_uint32),
                 ("emit_cloud", C.c_uint32), ("out_layout", C.c_uint32), ("out_soa_stride", C.c_uint32),
-                ("reserved0", C.c_uint32), ("inv_leaf", C.c_float), ("vmin", C.c_float * 3), ("vmax", C.c_float * 3),
+                ("tile", C.c_uint32), ("inv_leaf", C.c_float), ("vmin", C.c_float * 3), ("vmax", C.c_float * 3),
                 ("min_b", C.c_int32 * 3), ("div_b", C.c_int32 * 3), ("mul", C.c_uint32 * 3), ("plan_voxel", RadixPlan),
                 ("src_x", C.c_void_p), ("src_y", C.c_void_p), ("src_z", C.c_void_p), ("inv_cell", C.c_double),
                 ("c_n", C.c_uint32), ("c_from_input", C.c_uint32), ("r2", C.c_float), ("min_cluster", C.c_uint32),
@@ -103,6 +103,10 @@ def load_library():
     L.pcop_wait_batch.argtypes = [vp, C.POINTER(Result), C.c_int]
     L.pcop_cluster_summaries_frame.restype = C.c_int
     L.pcop_cluster_summaries_frame.argtypes = [vp, C.c_int, fp, C.c_int32]
+    L.pcop_set_cloud_layout.restype = C.c_int
+    L.pcop_set_cloud_layout.argtypes = [vp, C.c_int]
+    L.pcop_cluster_cloud.restype = C.c_int
+    L.pcop_cluster_cloud.argtypes = [vp, C.c_int, C.POINTER(fp), ip]
     L.pcop_occupancy_grid_dims.restype = None
     L.pcop_occupancy_grid_dims.argtypes = [C.c_float] * 5 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.pcop_occupancy_filter.restype = C.c_int
@@ -186,6 +190,7 @@ class Context:
     """One GPU context (pcop_ctx)."""
 
     def __init__(self, max_points, device=0, profiling=False, max_frames=1):
+        self.cloud_layout = LAYOUT_AOS12
         self.lib = load_library()
         self.h = C.c_void_p()
         self.max_frames = int(max_frames)
@@ -241,14 +246,27 @@ class Context:
         return offsets[:k.value + 1].copy(), indices[:offsets[k.value]].copy()
 
     # ---- frame API --------------------------------------------------------------------
-    @staticmethod
-    def _result(r):
+    def set_cloud_layout(self, layout):
+        """Layout of the frame API's voxel cloud: LAYOUT_AOS12 (default) or LAYOUT_AOS16 = pcl::PointXYZ records {x,y,z,1}."""
+        self._chk(self.lib.pcop_set_cloud_layout(self.h, int(layout)))
+        self.cloud_layout = int(layout)
+
+    def cluster_cloud(self, frame=0):
+        """The euc_clusters cloud of a finished frame -> (n, 4) float32 records {x, y, z, 1.0}, gathered on the GPU."""
+        p, n = C.POINTER(C.c_float)(), C.c_int32(0)
+        self._chk(self.lib.pcop_cluster_cloud(self.h, int(frame), C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, 4), dtype=np.float32)
+        return np.ctypeslib.as_array(p, shape=(n.value * 4,)).reshape(n.value, 4).copy()
+
+    def _result(self, r):
         k, t, m = r.num_clusters, r.num_indices, r.num_voxels
         offsets = np.ctypeslib.as_array(r.offsets, shape=(k + 1,)).copy()
         indices = np.ctypeslib.as_array(r.indices, shape=(max(t, 1),))[:t].copy()
         vox = None
         if r.voxel_xyz:
-            vox = np.ctypeslib.as_array(r.voxel_xyz, shape=(max(m, 1) * 3,))[:3 * m].reshape(m, 3).copy()
+            w = 4 if self.cloud_layout == LAYOUT_AOS16 else 3
+            vox = np.ctypeslib.as_array(r.voxel_xyz, shape=(max(m, 1) * w,))[:w * m].reshape(m, w).copy()
         return dict(passthrough=bool(r.passthrough), num_voxels=m, offsets=offsets, indices=indices, voxel_xyz=vox)
 
     def process_xyz(self, xyz, is_dense=True, layout=LAYOUT_AOS12):

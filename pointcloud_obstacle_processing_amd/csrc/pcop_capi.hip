@@ -32,6 +32,7 @@ inline bool compare_clusters(const ClusterRef& a, const ClusterRef& b) { return 
 
 struct GraphKey {
     uint32_t kind, bucket, npass_voxel, npass_csr, nframes;
+    uint32_t tile;                   // streaming voxel path: points per tile
     uint32_t stream, nb_cap, gbits;  // streaming voxel path: on?, buckets provided for (LDS, grids), log2 of the coarse bins (LDS)
     // (lds_ordered is fixed for the life of a context: not part of the key)
     uint32_t cgrid, ctiles;          // dense cell grid: on?, occupancy tiles (grid)
@@ -39,6 +40,7 @@ struct GraphKey {
         if (cgrid != o.cgrid) return cgrid < o.cgrid;
         if (ctiles != o.ctiles) return ctiles < o.ctiles;
         if (stream != o.stream) return stream < o.stream;
+        if (tile != o.tile) return tile < o.tile;
         if (nb_cap != o.nb_cap) return nb_cap < o.nb_cap;
         if (gbits != o.gbits) return gbits < o.gbits;
         if (kind != o.kind) return kind < o.kind;
@@ -61,6 +63,8 @@ struct Slot {
     int32_t *h_offsets = nullptr, *h_indices = nullptr;             // PCL order
     float* h_vox = nullptr;
     float* h_xyzr = nullptr;
+    float* h_clu = nullptr;       // the euc_clusters cloud (16-byte records), filled by pcop_cluster_cloud
+    int32_t last_indices = 0;     // indices of the last ordered result
     std::vector<int32_t> order;   // order[c] = discovery id of output cluster c
     const float *src_x = nullptr, *src_y = nullptr, *src_z = nullptr;
     uint32_t n = 0;
@@ -89,6 +93,7 @@ struct pcop_ctx {
     int is_dense = 1;
     uint32_t kind = kFrameChain;
     int out_layout = PCOP_LAYOUT_AOS12;
+    int cloud_layout = PCOP_LAYOUT_AOS12;   // layout of the frame API's voxel cloud (pcop_set_cloud_layout)
     bool emit_cloud = false;
     bool in_flight = false;
     uint32_t npass_voxel = kMaxPasses, npass_csr = kMaxPasses;
@@ -204,6 +209,10 @@ uint32_t hash_cap_for(uint32_t n) {
     return cap;
 }
 
+// Points per tile of the streaming voxel path: large tiles keep the per-tile tables small, small ones give a single
+// frame (or a small batch) enough blocks to fill the chip.  Any value gives the same result.
+uint32_t tile_for(uint32_t nb, uint32_t nf) { return (uint64_t)nf * div_up(nb, kBinTile) >= 256u ? kBinTile : kBinTileSmall; }
+
 bool grid_on(const pcop_ctx* c) { return c->cell_grid && c->cgrid_ok && !c->crowded_cells && c->kind != kFrameVoxelOnly; }
 bool stream_on(const pcop_ctx* c) { return c->voxel_stream && c->stream_ok && c->kind != kFrameClusterOnly; }
 
@@ -214,8 +223,6 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
     hipStream_t s = c->stream;
     Frame* fr = c->d_frames;
     constexpr uint32_t kBinsGrid = (1u << MAXB) + 1u;
-    k_frame_init<<<dim3(1, nf), 64, 0, s>>>(fr);
-    mark(c, "k_frame_init");
     const dim3 pg(std::max(1u, div_up(nb, kTile)), nf);        // partition tiles
     const dim3 sg(std::max(1u, div_up(nb, kScanTile)), nf);    // scan tiles over points
     // Grid-strided kernels: the counts they loop over (voxels, cells) are only known on the device and are
@@ -224,14 +231,23 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
     // over for the whole batch, not to cover the bucket.
     const dim3 tg(std::min(stride_grid(nb), std::max(64u, c->stride_blocks / nf)), nf);
     const uint32_t cell_blocks = std::max(64u, c->cell_blocks / nf);
+    // k_voxel_setup also writes DevState from the mailbox and, when the dense cell grid is on, sets that up as well
+    // (both need nothing but the bounds), so a frame has no separate init and grid set-up launches.  Only a cluster-only
+    // frame on the hash table of cells has no bounds pass: it keeps its k_frame_init.
+    const uint32_t fold_grid = (kind != kFrameVoxelOnly && grid_on(c)) ? 4u : 0u;
+    if (kind == kFrameClusterOnly && !grid_on(c)) {
+        k_frame_init<<<dim3(1, nf), 64, 0, s>>>(fr);
+        mark(c, "k_frame_init");
+    }
     if (kind != kFrameClusterOnly) {
         k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_minmax");
         const bool stream = stream_on(c);
-        k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, stream ? 1u : 0u);
+        k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, (stream ? 1u : 0u) | 2u | fold_grid);
         mark(c, "k_voxel_setup");
         if (stream) {
-            const dim3 bt(std::max(1u, div_up(nb, kBinTile)), nf);   // tiles of the coarse histogram and of the partition
+            const uint32_t tile = tile_for(nb, nf);
+            const dim3 bt(std::max(1u, div_up(nb, tile)), nf);       // tiles of the coarse histogram and of the partition
             const size_t bins = (size_t)1 << c->gbits;
             k_bin_hist<<<bt, kBinThreads, bins * 4u, s>>>(fr);
             mark(c, "k_bin_hist");
@@ -275,11 +291,9 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
             if (kind == kFrameClusterOnly) {   // the bounding box of the cloud (a chain frame has it from the voxel stage)
                 k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr);
                 mark(c, "k_minmax");
-                k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, 0u);
+                k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, 2u | 4u);
                 mark(c, "k_voxel_setup");
             }
-            k_cgrid_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr);
-            mark(c, "k_cgrid_setup");
             k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "k_cell_mark");
             k_occ_scan<<<dim3(c->ctiles, nf), kBlock, 0, s>>>(fr);
@@ -354,11 +368,13 @@ int enqueue_batch(pcop_ctx* c) {
         a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
         a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.debug_skip_union = c->debug_skip_union;
         a.voxel_stream = stream_on(c) ? 1u : 0u; a.nb_cap = c->nb_cap; a.cell_grid = grid_on(c) ? 1u : 0u; a.gbits = c->gbits;
+        a.tile = 0u; a.pad0 = 0u;   // set below, once the launch bucket is known
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         nmax = std::max(nmax, sl.n);
     }
     c->frame_npass_csr = c->npass_csr;
     const uint32_t nb = bucket_of(c, nmax);
+    for (uint32_t f = 0; f < c->nframes; ++f) c->slots[f].h_args->tile = tile_for(nb, c->nframes);
     c->ev_used = 0;
     if (c->profiling || !c->use_graph) {
         mark(c, "start");
@@ -366,7 +382,7 @@ int enqueue_batch(pcop_ctx* c) {
         HIPCHK(c, hipGetLastError());
     } else {
         const bool st_on = stream_on(c);
-        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? 1u : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
+        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? tile_for(nb, c->nframes) : 0u, st_on ? 1u : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
                            grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
@@ -437,6 +453,7 @@ void order_frame(pcop_ctx* c, Slot& sl, pcop_result* out) {
         sl.h_offsets[i + 1] = pos;
     }
     sl.have_result = clustered;
+    sl.last_indices = pos;
     if (out) {
         out->passthrough = (int32_t)hs->passthrough;
         out->num_voxels = (int32_t)m;
@@ -630,7 +647,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         TRY(dev_alloc(c, &f.ctile, (size_t)kCmapCells / 32u / kVmapTile));
     }
     if (c->voxel_stream) {
-        const size_t tiles = (n + kBinTile - 1) / kBinTile + 1;
+        const size_t tiles = (n + kBinTileSmall - 1) / kBinTileSmall + 1;
         TRY(dev_alloc(c, &f.ctab, tiles << kBinBitsMax));
         TRY(dev_alloc(c, &f.bin2bucket, ((size_t)1 << kBinBitsMax) + 8));
         TRY(dev_alloc(c, &f.binfo, (size_t)kNbMax + 1));
@@ -644,7 +661,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
     TRY(host_alloc(c, &sl.h_state, 1));
     TRY(host_alloc(c, &sl.h_offsets_disc, n + 2)); TRY(host_alloc(c, &sl.h_indices_disc, n + 1));
     TRY(host_alloc(c, &sl.h_offsets, n + 2)); TRY(host_alloc(c, &sl.h_indices, n + 1));
-    TRY(host_alloc(c, &sl.h_vox, 4 * n)); TRY(host_alloc(c, &sl.h_xyzr, 4 * (n + 1)));
+    TRY(host_alloc(c, &sl.h_vox, 4 * n)); TRY(host_alloc(c, &sl.h_xyzr, 4 * (n + 1))); TRY(host_alloc(c, &sl.h_clu, 4 * (n + 1)));
 #undef TRY
     f.args = sl.h_args;
     f.h_state = sl.h_state;
@@ -863,7 +880,7 @@ int pcop_submit_batch(pcop_ctx* c, const float* const* xyz, int layout, const si
     for (int f = 0; f < nframes; ++f)
         if ((rc = stage_input(c, c->slots[f], xyz[f], layout, n[f], mem))) return rc;
     c->nframes = (uint32_t)nframes;
-    return submit_common(c, kFrameChain, c->params.publish_clouds != 0, PCOP_LAYOUT_AOS12, is_dense);
+    return submit_common(c, kFrameChain, c->params.publish_clouds != 0, c->cloud_layout, is_dense);
 }
 
 int pcop_wait_batch(pcop_ctx* c, pcop_result* out, int nframes) {
@@ -916,7 +933,7 @@ int pcop_process_pointcloud2(pcop_ctx* c, const uint8_t* data, uint32_t width, u
         HIPCHK(c, hipGetLastError());
     }
     c->nframes = 1;
-    if ((rc = submit_common(c, kFrameChain, c->params.publish_clouds != 0, PCOP_LAYOUT_AOS12, is_dense))) return rc;
+    if ((rc = submit_common(c, kFrameChain, c->params.publish_clouds != 0, c->cloud_layout, is_dense))) return rc;
     return finish_batch(c, out, out ? 1 : 0);
 }
 
@@ -1021,7 +1038,7 @@ int pcop_process_filtered(pcop_ctx* c, pcop_result* out) {
     sl.src_x = c->occ_xyz; sl.src_y = c->occ_xyz + c->cap; sl.src_z = c->occ_xyz + 2 * c->cap;
     c->nframes = 1;
     // the cloud build_initial_occupancy_grid_dataset fills by push_back keeps PointCloud's default is_dense = true (od.cpp:214)
-    if ((rc = submit_common(c, kFrameChain, c->params.publish_clouds != 0, PCOP_LAYOUT_AOS12, 1))) return rc;
+    if ((rc = submit_common(c, kFrameChain, c->params.publish_clouds != 0, c->cloud_layout, 1))) return rc;
     return finish_batch(c, out, out ? 1 : 0);
 }
 
@@ -1035,7 +1052,7 @@ static int sor_pass(pcop_ctx* c, Slot& sl, double inv_cell, bool with_knn, uint3
     a.inv_leaf = 1.0f; a.r2 = 1.0f; a.inv_cell = inv_cell;
     a.min_cluster = 1u; a.max_cluster = 0xFFFFFFFFu;
     a.out_layout = (uint32_t)PCOP_LAYOUT_AOS12; a.out_soa_stride = sl.n;
-    a.cell_grid = 1u; a.nb_cap = c->nb_cap; a.gbits = c->gbits;
+    a.cell_grid = 1u; a.nb_cap = c->nb_cap; a.gbits = c->gbits; a.tile = kBinTile;
     a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
     Frame* fr = c->d_frames;
     hipStream_t s = c->stream;
@@ -1168,6 +1185,31 @@ int pcop_cluster_summaries_frame(pcop_ctx* c, int frame, float* xyzr, int32_t ca
     HIPCHK(c, hipMemcpyAsync(sl.h_xyzr, sl.f.d_xyzr, (size_t)k * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (uint32_t i = 0; i < k; ++i) std::memcpy(xyzr + 4 * (size_t)i, sl.h_xyzr + 4 * (size_t)sl.order[i], 16);
+    return PCOP_OK;
+}
+
+int pcop_set_cloud_layout(pcop_ctx* c, int layout) {
+    if (!c || (layout != PCOP_LAYOUT_AOS16 && layout != PCOP_LAYOUT_AOS12)) return PCOP_ERR_ARG;
+    int rc = busy(c);
+    if (rc) return rc;
+    c->cloud_layout = layout;
+    return PCOP_OK;
+}
+
+int pcop_cluster_cloud(pcop_ctx* c, int frame, const float** xyz16, int32_t* n_points) {
+    if (!c || !xyz16 || !n_points || frame < 0 || (uint32_t)frame >= c->max_frames) return PCOP_ERR_ARG;
+    Slot& sl = c->slots[frame];
+    if (!sl.have_result || c->in_flight) { c->err = "no finished clustered frame in this slot"; return PCOP_ERR_STATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    *xyz16 = sl.h_clu;
+    *n_points = sl.last_indices;
+    if (sl.last_indices == 0) return PCOP_OK;
+    // h_indices (PCL order) and h_clu are pinned host memory: the kernel reads the one and writes the other over the bus
+    k_cluster_cloud<<<std::min(1024u, std::max(1u, div_up((uint32_t)sl.last_indices, kBlock))), kBlock, 0, c->stream>>>(
+        c->d_frames + frame, sl.h_indices, (uint32_t)sl.last_indices, reinterpret_cast<float4*>(sl.h_clu));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PCOP_OK;
 }
 

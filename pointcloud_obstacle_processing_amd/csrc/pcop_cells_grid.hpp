@@ -25,17 +25,18 @@ namespace pcop {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool cgrid_off(const DevState* st) { return cluster_stage_off(st) || !st->cpath; }
 
-__global__ __launch_bounds__(kBlock) void k_cgrid_setup(Frame* frames) {
-    Frame& F = frames[blockIdx.y];
+// The whole block: grid origin and size from the bounding box in st->vmin / vmax (a superset of what the cell stage will
+// see), the scan tiles' publish words cleared.  npts_max bounds the points that will enter the cell stage; empty: none will.
+__device__ __forceinline__ void cgrid_setup_block(Frame& F, uint32_t npts_max, bool empty) {
     DevState* st = &F.st;
     if (cluster_stage_off(st) || !st->cgrid_req) return;
-    uint32_t* __restrict__ ctile = F.ctile; uint32_t* __restrict__ tile_pub = F.tile_a;
+    uint32_t* __restrict__ ctile = F.ctile; uint32_t* __restrict__ tile_pub = F.tile_b;   // (tile_a carries the voxel stage's publish words until k_voxel_reduce is through)
     for (uint32_t t = threadIdx.x; t < kCmapCells / 32u / kVmapTile; t += kBlock) ctile[t] = 0u;
-    const uint32_t ntiles = (st->c_n + kScanTile - 1) / kScanTile;   // k_cell_starts publishes here
+    const uint32_t ntiles = (npts_max + kScanTile - 1) / kScanTile;   // k_cell_starts publishes here
     for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock) tile_pub[t] = 0u;
     if (threadIdx.x != 0) return;
     st->n_cells = 0;
-    if (st->c_n == 0) { st->cpath = 1u; st->cmap_words = 0u; return; }
+    if (empty) { st->cpath = 1u; st->cmap_words = 0u; return; }
     const double ig = st->inv_cell;
     long long dim[3];
     for (int a = 0; a < 3; ++a) {
@@ -54,6 +55,11 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_setup(Frame* frames) {
     st->c_rowbits = (uint32_t)rowbits; st->c_plane = (uint32_t)plane;
     st->cmap_words = (uint32_t)(total / 32);
     st->cpath = 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cgrid_setup(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    cgrid_setup_block(F, F.st.c_n, F.st.c_n == 0u);
 }
 
 __global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames) {
     DevState* st = &F.st;
     const uint32_t* __restrict__ ccount = F.hcount; const uint32_t* __restrict__ cmin = F.hmin;
     const uint32_t* __restrict__ cell_pos = F.cell_list;
-    uint32_t* __restrict__ tile_pub = F.tile_a;
+    uint32_t* __restrict__ tile_pub = F.tile_b;
     uint32_t* __restrict__ cell_start = F.cell_start; uint32_t* __restrict__ parent = F.parent;
     uint32_t* __restrict__ comp_size = F.comp_size; uint32_t* __restrict__ comp_rank = F.comp_rank;
     uint4* __restrict__ slot_meta = F.slot_meta;

@@ -312,6 +312,25 @@ __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t n
 }
 
 // ------------------------------------------------------------------------------------------
+// The `euc_clusters` cloud: the points of the kept clusters in the host's (PCL) order, as pcl::PointXYZ records.
+// order_idx: the ordered point indices (pinned host memory, read over the bus); out: pinned host memory.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cluster_cloud(const Frame* frames, const int32_t* __restrict__ order_idx, uint32_t count,
+                                                          float4* __restrict__ out) {
+    const Frame& F = frames[0];
+    const DevState* st = &F.st;
+    const float* __restrict__ cen_x = F.cen_x; const float* __restrict__ cen_y = F.cen_y; const float* __restrict__ cen_z = F.cen_z;
+    const bool sel = st->c_from_input != 0;
+    const float* __restrict__ x = sel ? st->src_x : cen_x;
+    const float* __restrict__ y = sel ? st->src_y : cen_y;
+    const float* __restrict__ z = sel ? st->src_z : cen_z;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += gridDim.x * blockDim.x) {
+        const uint32_t p = (uint32_t)order_idx[j];
+        out[j] = make_float4(x[p], y[p], z[p], 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // PointWithRad per cluster (msg/PointWithRad.msg): one wave per cluster.
 // centre = double mean rounded to float; r = max calculate_distance() (od.cpp:457-464).
 // ------------------------------------------------------------------------------------------

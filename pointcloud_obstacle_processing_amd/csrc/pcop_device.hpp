@@ -60,7 +60,8 @@ constexpr int kCellBias = 1 << 20;               // cell coordinates are stored 
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint32_t kVmapTile = 1024;            // occupancy words per block of k_occ_scan
 // streaming voxel path
-constexpr uint32_t kBinTile = 16384;            // points per block of k_bin_hist / k_bin_scatter
+constexpr uint32_t kBinTile = 16384;            // points per block of k_bin_hist / k_bin_scatter: kBinTileSmall when that fills the chip better
+constexpr uint32_t kBinTileSmall = 4096;
 constexpr uint32_t kBinThreads = 1024;          // threads of k_bin_hist / k_bin_plan
 constexpr uint32_t kBinBitsMin = 11, kBinBitsMax = 14;   // coarse key bins per frame: 2^11 .. 2^14 (a host hint; any value gives the same result)
 constexpr uint32_t kBucketCap = 2048;           // points per bucket (k_bucket_reduce: 256 threads x 8 records, all in LDS)
@@ -124,6 +125,7 @@ struct FrameArgs {
     uint32_t emit_cloud, out_layout, out_soa_stride, debug_skip_union;
     uint32_t voxel_stream, nb_cap;            // streaming voxel path requested; buckets the launch has LDS for
     uint32_t cell_grid, gbits;                // dense cell grid requested (else: the hash table of cells); log2 of the coarse bins wanted
+    uint32_t tile, pad0;                      // streaming voxel path: points per tile (kBinTile or kBinTileSmall)
     DevPtr<const float> src_x, src_y, src_z;
 };
 
@@ -136,7 +138,7 @@ struct DevState {
     uint32_t passthrough;   // VoxelGrid overflow rule fired
     uint32_t m;             // voxels (downsampled points)
     uint32_t kind, trivial, emit_cloud, out_layout, out_soa_stride;
-    uint32_t reserved0;
+    uint32_t tile;          // streaming voxel path: points per tile of k_bin_hist / k_bin_scatter
     // voxel grid (pcl::VoxelGrid members)
     float    inv_leaf;
     float    vmin[3], vmax[3];

@@ -61,10 +61,9 @@ struct VoxelKey {
 // ------------------------------------------------------------------------------------------
 // frame init + layout conversion
 // ------------------------------------------------------------------------------------------
-__global__ void k_frame_init(Frame* frames) {
-    Frame& F = frames[blockIdx.y];
+__device__ __forceinline__ void frame_init(Frame& F) {   // one thread: the mailbox -> DevState
     DevState* st = &F.st;
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    {
         const FrameArgs a = *F.args;
         DevState s;
         memset(&s, 0, sizeof(s));
@@ -74,7 +73,7 @@ __global__ void k_frame_init(Frame* frames) {
         s.min_cluster = a.min_cluster; s.max_cluster = a.max_cluster;
         s.src_x = a.src_x; s.src_y = a.src_y; s.src_z = a.src_z;
         s.debug_skip_union = a.debug_skip_union;
-        s.nb_cap = a.nb_cap; s.gbits = a.gbits; s.cgrid_req = a.cell_grid;
+        s.nb_cap = a.nb_cap; s.gbits = a.gbits; s.tile = a.tile ? a.tile : kBinTile; s.cgrid_req = a.cell_grid;
         if (a.kind == kFrameClusterOnly) {   // no voxel stage: cluster the input cloud as it is
             s.c_from_input = 1; s.c_n = a.n; s.n_valid = a.n;
             uint32_t cap = 1024;
@@ -83,6 +82,10 @@ __global__ void k_frame_init(Frame* frames) {
         }
         *st = s;
     }
+}
+
+__global__ void k_frame_init(Frame* frames) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) frame_init(frames[blockIdx.y]);
 }
 
 // Any point_step / field offsets / endianness -> SoA planes (the PointCloud2 -> PointXYZ
@@ -179,13 +182,17 @@ __device__ __forceinline__ void reduce_partials_lds(MinMaxPartial* s_p) {   // k
 __global__ __launch_bounds__(kBlock) void k_minmax(Frame* frames) {
     __shared__ MinMaxPartial s_p[kBlock];
     Frame& F = frames[blockIdx.y];
-    DevState* st = &F.st;
     MinMaxPartial* partials = F.partials;
-    if (st->kind == kFrameClusterOnly && !st->cgrid_req) return;   // bounds of a cluster-only frame: for the dense cell grid
-    const float* __restrict__ x = st->src_x;
-    const float* __restrict__ y = st->src_y;
-    const float* __restrict__ z = st->src_z;
-    const uint32_t n = st->n_in;
+    // Straight from the mailbox (pinned host memory): DevState is written by k_voxel_setup, after this kernel, so that
+    // a frame needs no separate init launch.
+    __shared__ FrameArgs s_args;
+    if (threadIdx.x == 0) s_args = *F.args;
+    __syncthreads();
+    if (s_args.kind == kFrameClusterOnly && !s_args.cell_grid) return;   // bounds of a cluster-only frame: for the dense cell grid
+    const float* __restrict__ x = s_args.src_x;
+    const float* __restrict__ y = s_args.src_y;
+    const float* __restrict__ z = s_args.src_z;
+    const uint32_t n = s_args.n;
     const float fmax = 3.402823466e+38f;
     float mn0 = fmax, mn1 = fmax, mn2 = fmax, mx0 = -fmax, mx1 = -fmax, mx2 = -fmax;
     uint32_t valid = 0, bad = 0;
@@ -221,10 +228,19 @@ __global__ __launch_bounds__(kBlock) void k_minmax(Frame* frames) {
 }
 
 // one block per frame: reduce the block partials and derive the voxel grid
-__global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t nblocks, uint32_t npass, uint32_t maxbits, uint32_t stream) {
+// flags: bit 0 = the streaming voxel path is requested, bit 1 = write DevState from the mailbox first (no k_frame_init
+// launch before), bit 2 = set up the dense cell grid as well (no k_cgrid_setup launch after: it needs the bounds only).
+__device__ __forceinline__ void cgrid_setup_block(Frame& F, uint32_t npts_max, bool empty);
+
+__global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t nblocks, uint32_t npass, uint32_t maxbits, uint32_t flags) {
     __shared__ MinMaxPartial s_p[kBlock];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
+    const uint32_t stream = flags & 1u;
+    if (flags & 2u) {
+        if (threadIdx.x == 0) frame_init(F);
+        __syncthreads();
+    }
     if (st->kind == kFrameClusterOnly && !st->cgrid_req) return;
     const MinMaxPartial* __restrict__ partials = F.partials;
     const float fmax = 3.402823466e+38f;
@@ -244,9 +260,11 @@ __global__ __launch_bounds__(kBlock) void k_voxel_setup(Frame* frames, uint32_t 
             if (p.nonfinite) atomicOr(&st->err, (uint32_t)kErrNonFinite);
             for (int a = 0; a < 3; ++a) { st->vmin[a] = p.mn[a]; st->vmax[a] = p.mx[a]; }
         }
+        if (flags & 4u) { __syncthreads(); cgrid_setup_block(F, st->n_in, st->n_in == 0u); }
         return;
     }
     if (threadIdx.x == 0) voxel_setup(st, s_p[0], npass, maxbits, stream != 0u);
+    if (flags & 4u) { __syncthreads(); cgrid_setup_block(F, st->n_in, s_p[0].valid == 0u); }
     if (stream) return;
     // k_voxel_reduce publishes "heads of tile t, plus one" here; zero = not yet published
     uint32_t* __restrict__ tile_heads = F.tile_a;
@@ -687,8 +705,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     DevState* st = &F.st;
     uint16_t* __restrict__ ctab = F.ctab;
     if (stream_off(st)) return;
-    const uint32_t n = st->n_in;
-    const uint32_t tile_base = blockIdx.x * kBinTile;
+    const uint32_t n = st->n_in, tile = st->tile;
+    const uint32_t tile_base = blockIdx.x * tile;
     if (tile_base >= n) return;
     const uint32_t G = 1u << st->gbits, cs = st->cshift;
     for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) s_hist[b] = 0u;
@@ -697,9 +715,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     const bool drop = st->is_dense == 0;
     VoxelKey key; key.init(st);
     bool bad = false;
-    constexpr int kRound = 8;   // records in flight per thread
-#pragma unroll
-    for (uint32_t r0 = 0; r0 < kBinTile / kBinThreads; r0 += kRound) {
+    constexpr int kRound = kBinTileSmall / kBinThreads;   // records in flight per thread: 4
+    for (uint32_t r0 = 0; r0 < tile / kBinThreads; r0 += kRound) {
         Rec3 r[kRound];
 #pragma unroll
         for (int k = 0; k < kRound; ++k) {   // clamped, unconditional loads
@@ -718,7 +735,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     if (bad) atomicOr(&st->err, (uint32_t)kErrInternal);   // a key beyond the grid: never (the keys are those PCL computes)
     __syncthreads();
     uint16_t* __restrict__ row = ctab + (size_t)blockIdx.x * G;
-    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has 16384 points: fits
+    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has at most 16384 points: fits
 }
 
 // Bin totals over the tiles: a block takes 64 bins (a wave reads 128 contiguous bytes of a row), its four waves
@@ -733,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_colsum(const Frame* frames) {
     const uint32_t G = 1u << st->gbits;
     const uint32_t bin = blockIdx.x * kWave + lane_id();
     if (blockIdx.x * kWave >= G) return;
-    const uint32_t ntiles = (st->n_in + kBinTile - 1u) / kBinTile;
+    const uint32_t ntiles = (st->n_in + st->tile - 1u) / st->tile;
     const uint32_t w = threadIdx.x / kWave;
     const uint32_t bc = min(bin, G - 1u);
     uint32_t c = 0u;
@@ -935,7 +952,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_tilecnt(const Frame* frames) {
     uint16_t* __restrict__ tcnt = F.tcnt;
     if (stream_off(st)) return;
     const uint32_t tile = blockIdx.x;
-    if (tile * kBinTile >= st->n_in) return;
+    if (tile * st->tile >= st->n_in) return;
     const uint32_t G = 1u << st->gbits, cs = st->cshift, nb = st->nbuckets, ts = F.tstride;
     const uint16_t* __restrict__ row = ctab + (size_t)tile * G;
     constexpr uint32_t kVecMax = (1u << kBinBitsMax) / kBlock / 8u;   // 16-byte loads per thread: at most 8
@@ -1002,7 +1019,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_colscan(const Frame* frames) {
     if (stream_off(st)) return;
     const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= st->nbuckets) return;
-    const uint32_t ntiles = (st->n_in + kBinTile - 1u) / kBinTile, ts = F.tstride;   // ts: a multiple of 8
+    const uint32_t ntiles = (st->n_in + st->tile - 1u) / st->tile, ts = F.tstride;   // ts: a multiple of 8
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(tcnt + (size_t)b * ts);
     uint4* __restrict__ dst = reinterpret_cast<uint4*>(tbase + (size_t)b * ts);
     uint32_t run = 0u;
@@ -1095,8 +1112,8 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
     const uint32_t* __restrict__ tbase = F.tbase;
     Rec3* __restrict__ out = reinterpret_cast<Rec3*>(F.rec_a.get());
     if (stream_off(st)) return;
-    const uint32_t n = st->n_in;
-    const uint32_t tile_base = blockIdx.x * kBinTile;
+    const uint32_t n = st->n_in, nchunks = st->tile / kScatChunk;
+    const uint32_t tile_base = blockIdx.x * st->tile;
     if (tile_base >= n) return;
     const uint32_t nbc = PB * kScatThreads, nb = st->nbuckets, G = 1u << st->gbits, cs = st->cshift;
     if (st->nb_cap != nbc) return;   // (the host launches the instance that matches)
@@ -1128,7 +1145,7 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
     };
     request(recn, tile_base);
     PCOP_STAMP(F, 1, 0, 30);
-    for (uint32_t ch = 0; ch < kBinTile / kScatChunk; ++ch) {
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
         const uint32_t cbase = tile_base + ch * kScatChunk;
         if (cbase >= n) break;
 #pragma unroll
@@ -1147,7 +1164,7 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
 #pragma unroll
         for (uint32_t j = 0; j < kScatItems; ++j) bkt[j] = bin2bucket[bin[j]];   // all requested before any is used
         __builtin_amdgcn_sched_barrier(0);   // the next chunk's records are requested after the bucket lookups: loads return in order
-        if (ch + 1u < kBinTile / kScatChunk) request(recn, cbase + kScatChunk);
+        if (ch + 1u < nchunks) request(recn, cbase + kScatChunk);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         if (ch == 1u) PCOP_STAMP(F, 1, 1, 30);

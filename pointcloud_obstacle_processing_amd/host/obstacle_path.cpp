@@ -160,6 +160,9 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
     p.publish_clouds = 1;                            // the voxel cloud is needed on the host for euc_clusters
     int rc = pcop_set_params(ctx_, &p);
     if (rc) { error_ = pcop_last_error(ctx_); return rc; }
+    // both clouds come off the GPU as the 16-byte records of pcl::PointXYZ, the layout pcl::toROSMsg publishes (od.cpp:288-295)
+    rc = pcop_set_cloud_layout(ctx_, PCOP_LAYOUT_AOS16);
+    if (rc) { error_ = pcop_last_error(ctx_); return rc; }
     pcop_result r{};
     rc = pcop_process_pointcloud2(ctx_, cloud_msg.data.data(), cloud_msg.width, cloud_msg.height, cloud_msg.point_step,
                                   cloud_msg.row_step, ox, oy, oz, cloud_msg.is_bigendian ? 1 : 0, cloud_msg.is_dense ? 1 : 0, &r);
@@ -167,11 +170,9 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
     passthrough = r.passthrough;
     // the downsampled cloud (statistical_outlier_input_cloud, od.cpp:740-741)
     voxel_cloud.header = cloud_msg.header;
+    static_assert(sizeof(PointXYZ) == 16, "pcl::PointXYZ is {x, y, z, pad = 1.0f}");
     voxel_cloud.points.resize((size_t)r.num_voxels);
-    for (int32_t i = 0; i < r.num_voxels; ++i) {
-        PointXYZ& q = voxel_cloud.points[(size_t)i];
-        q.x = r.voxel_xyz[3 * i]; q.y = r.voxel_xyz[3 * i + 1]; q.z = r.voxel_xyz[3 * i + 2]; q.pad = 1.0f;
-    }
+    if (r.num_voxels) std::memcpy(static_cast<void*>(&voxel_cloud.points[0]), r.voxel_xyz, (size_t)r.num_voxels * sizeof(PointXYZ));
     voxel_cloud.width = (uint32_t)r.num_voxels; voxel_cloud.height = 1; voxel_cloud.is_dense = true;
     if (params.publish_point_clouds) {               // od.cpp:288-295
         PointCloud2 msg;
@@ -193,8 +194,12 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
     centroid_publisher.publish(centroids);
     // "euc_clusters": the points of all kept clusters, frame "/world" (od.cpp:861-866)
     PointCloudXYZ clustered;
-    clustered.points.reserve((size_t)r.num_indices);
-    for (int32_t j = 0; j < r.num_indices; ++j) clustered.points.push_back(voxel_cloud.points[(size_t)r.indices[j]]);
+    const float* clu = nullptr;
+    int32_t nclu = 0;
+    rc = pcop_cluster_cloud(ctx_, 0, &clu, &nclu);   // gathered on the GPU, cluster after cluster
+    if (rc) { error_ = pcop_last_error(ctx_); return rc; }
+    clustered.points.resize((size_t)nclu);
+    if (nclu) std::memcpy(static_cast<void*>(&clustered.points[0]), clu, (size_t)nclu * sizeof(PointXYZ));
     PointCloud2 clusters;
     to_pointcloud2(clustered, &clusters);
     clusters.header.frame_id = "/world";

@@ -34,7 +34,8 @@ bool xyz_offsets(const sensor_msgs::PointCloud2& m, uint32_t off[3]) {
     return have[0] && have[1] && have[2];
 }
 
-sensor_msgs::PointCloud2 xyz_cloud_msg(const float* xyz, const int32_t* pick, size_t n, const char* frame) {
+// xyz16: n records of 16 bytes {x, y, z, 1.0f} as the GPU wrote them = the data blob pcl::toROSMsg produces
+sensor_msgs::PointCloud2 xyz_cloud_msg(const float* xyz16, size_t n, const char* frame) {
     sensor_msgs::PointCloud2 m;
     m.header.frame_id = frame;
     m.header.stamp = ros::Time::now();
@@ -47,11 +48,7 @@ sensor_msgs::PointCloud2 xyz_cloud_msg(const float* xyz, const int32_t* pick, si
         m.fields.push_back(f);
     }
     m.data.resize(16 * n);
-    for (size_t i = 0; i < n; ++i) {
-        const float* p = xyz + 3 * (pick ? pick[i] : (int32_t)i);
-        const float q[4] = {p[0], p[1], p[2], 1.0f};
-        std::memcpy(&m.data[16 * i], q, 16);
-    }
+    if (n) std::memcpy(&m.data[0], xyz16, 16 * n);
     return m;
 }
 
@@ -64,12 +61,13 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr& cloud_msg) {
     p.leaf = downsample_leaf_size; p.tol = euc_cluster_tolerance;
     p.min_cluster = euc_min_cluster_size; p.max_cluster = euc_max_cluster_size; p.publish_clouds = 1;
     pcop_set_params(g_ctx, &p);
+    pcop_set_cloud_layout(g_ctx, PCOP_LAYOUT_AOS16);
     pcop_result r{};
     const int rc = pcop_process_pointcloud2(g_ctx, cloud_msg->data.data(), cloud_msg->width, cloud_msg->height,
                                             cloud_msg->point_step, cloud_msg->row_step, off[0], off[1], off[2],
                                             cloud_msg->is_bigendian, cloud_msg->is_dense, &r);
     if (rc != PCOP_OK) { ROS_ERROR("pcop: %s (%s)", pcop_status_string(rc), pcop_last_error(g_ctx)); return; }
-    if (publish_point_clouds) downsample_publisher.publish(xyz_cloud_msg(r.voxel_xyz, nullptr, r.num_voxels, "world"));
+    if (publish_point_clouds) downsample_publisher.publish(xyz_cloud_msg(r.voxel_xyz, r.num_voxels, "world"));
     pointcloud_obstacle_processing::PointIndicesArray centroids;
     std::vector<float> xyzr(4 * (size_t)r.num_clusters + 4);
     if (r.num_clusters) pcop_cluster_summaries(g_ctx, xyzr.data(), r.num_clusters);
@@ -79,7 +77,9 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr& cloud_msg) {
         centroids.points.push_back(q);
     }
     centroid_publisher.publish(centroids);
-    euc_cluster_publisher.publish(xyz_cloud_msg(r.voxel_xyz, r.indices, r.num_indices, "/world"));
+    const float* clu = nullptr;
+    int32_t nclu = 0;
+    if (pcop_cluster_cloud(g_ctx, 0, &clu, &nclu) == PCOP_OK) euc_cluster_publisher.publish(xyz_cloud_msg(clu, (size_t)nclu, "/world"));
 }
 
 }  // namespace

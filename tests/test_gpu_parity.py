@@ -548,6 +548,34 @@ def test_stream_path_nonfinite_points_dropped(capi, oracle, monkeypatch):
     c.close()
 
 
+def test_egress_in_toROSMsg_layout(capi, oracle):
+    """od.cpp:288-295, 861-866: the voxel_grid and euc_clusters clouds as pcl::toROSMsg lays them out, 16-byte
+    {x, y, z, 1.0f} records, written by the GPU (no host re-pack)."""
+    p = synth.params_of("C3")
+    pts = synth.make_cloud("C3", n=200_000, seed=12)
+    ref = oracle.process_xyz(pts, **p)
+    c = capi.Context(len(pts))
+    c.set_params(publish_clouds=1, **p)
+    c.set_cloud_layout(capi.LAYOUT_AOS16)
+    got = c.process_xyz(pts)
+    want = np.ones((len(ref["voxel_xyz"]), 4), dtype=np.float32)
+    want[:, :3] = ref["voxel_xyz"]
+    assert got["voxel_xyz"].tobytes() == want.tobytes()
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    clu = c.cluster_cloud()
+    assert clu.tobytes() == want[ref["indices"]].tobytes() and len(clu) == len(ref["indices"])
+    c.set_cloud_layout(capi.LAYOUT_AOS12)                      # and back
+    got = c.process_xyz(pts)
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    # a frame without kept clusters gives an empty cloud
+    c.set_params(publish_clouds=1, leaf=p["leaf"], tol=p["tol"], min_cluster=10**6, max_cluster=10**7)
+    c.process_xyz(pts)
+    assert len(c.cluster_cloud()) == 0
+    with pytest.raises(capi.PcopError):
+        c.set_cloud_layout(capi.LAYOUT_SOA)
+    c.close()
+
+
 def test_error_frame_leaves_no_marks_behind(capi, oracle):
     """A frame given up with an error (NaN in a cloud declared dense) on a cell grid larger than the occupancy scan was
     launched for must not leave occupancy flags set: the next frame on the same context equals the oracle."""
