@@ -212,6 +212,31 @@ int pcop_process_filtered(pcop_ctx* ctx, pcop_result* out);
 int pcop_statistical_outlier_removal(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int mean_k, float stddev_mul,
                                      float* out_xyz, size_t* n_out, float* distances, double* threshold);
 
+/* ---- the node's chain in one call, nothing but results leaving HBM (od.cpp:727-797) -----------------------------
+ * build_initial_occupancy_grid_dataset (od.cpp:727-731) -> downsample_cloud (740-741) -> remove_statistical_outliers
+ * (751-754) -> kd-tree + extract_euclidian_clusters (791-797), in the node's order.  (The plane removal of od.cpp:778-781
+ * sits between the last two in the node; it is not part of this call.)
+ *   occ      NULL: no bounds filter / occupancy binning, the chain starts at the voxel grid.  Otherwise as in
+ *            pcop_occupancy_filter; counts / row_avg / grid (each may be NULL) receive its grid outputs.
+ *   mean_k   0: no outlier removal.  Otherwise as in pcop_statistical_outlier_removal, applied to the voxel cloud.
+ * The kept cloud of every step stays on the device; the point counts flow through device memory.  With outlier removal
+ * the call synchronises once in the middle: the n mean neighbour distances go to the host, which forms the two
+ * sequential double sums of the reference (a parallel sum would round differently) and hands back the threshold.
+ * out->voxel_xyz / num_voxels describe the cloud the cluster indices refer to (the voxel cloud, or what the outlier
+ * removal kept of it); stats (may be NULL) reports the point counts after every step. */
+typedef struct pcop_node_stats {
+    int32_t n_in;          /* points handed in                                   */
+    int32_t n_filtered;    /* points inside the box (== n_in without occ)         */
+    int32_t index_errors;  /* as in pcop_occupancy_filter                         */
+    int32_t n_voxels;      /* voxel grid output                                   */
+    int32_t n_inliers;     /* after the outlier removal (== n_voxels without it)  */
+    int32_t reserved;
+    double  threshold;     /* mean + stddev_mul * sigma (0 without outlier removal) */
+} pcop_node_stats;
+int pcop_process_node(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int is_dense, int mem,
+                      const pcop_occ_params* occ, int64_t* counts, int64_t* row_avg, int8_t* grid,
+                      int mean_k, float stddev_mul, pcop_result* out, pcop_node_stats* stats);
+
 /* Device-side allocation helpers so a host program without its own HIP code
  * (e.g. a ctypes caller) can keep clouds resident in HBM. */
 int pcop_dev_alloc(pcop_ctx* ctx, size_t bytes, void** dev_ptr);

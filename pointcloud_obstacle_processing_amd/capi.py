@@ -20,7 +20,7 @@ EXPORTS = [
     "pcop_set_profiling", "pcop_get_stage_times", "pcop_stream", "pcop_voxel_downsample", "pcop_euclidean_clusters",
     "pcop_process_pointcloud2", "pcop_process_xyz", "pcop_submit_xyz", "pcop_wait", "pcop_cluster_summaries",
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
-    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
+    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
     "pcop_cluster_summaries_frame", "pcop_occupancy_grid_dims", "pcop_occupancy_filter", "pcop_process_filtered",
     "pcop_statistical_outlier_removal",
 ]
@@ -48,6 +48,11 @@ class Result(C.Structure):
     _fields_ = [("passthrough", C.c_int32), ("num_voxels", C.c_int32), ("num_clusters", C.c_int32),
                 ("num_indices", C.c_int32), ("offsets", C.POINTER(C.c_int32)), ("indices", C.POINTER(C.c_int32)),
                 ("voxel_xyz", C.POINTER(C.c_float))]
+
+
+class NodeStats(C.Structure):
+    _fields_ = [("n_in", C.c_int32), ("n_filtered", C.c_int32), ("index_errors", C.c_int32), ("n_voxels", C.c_int32),
+                ("n_inliers", C.c_int32), ("reserved", C.c_int32), ("threshold", C.c_double)]
 
 
 class StageTimes(C.Structure):
@@ -107,6 +112,9 @@ def load_library():
     L.pcop_set_cloud_layout.argtypes = [vp, C.c_int]
     L.pcop_cluster_cloud.restype = C.c_int
     L.pcop_cluster_cloud.argtypes = [vp, C.c_int, C.POINTER(fp), ip]
+    L.pcop_process_node.restype = C.c_int
+    L.pcop_process_node.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_float, C.POINTER(Result), C.POINTER(NodeStats)]
     L.pcop_occupancy_grid_dims.restype = None
     L.pcop_occupancy_grid_dims.argtypes = [C.c_float] * 5 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.pcop_occupancy_filter.restype = C.c_int
@@ -314,6 +322,37 @@ class Context:
         self._chk(self.lib.pcop_statistical_outlier_removal(self.h, flat.ctypes.data, layout, n, int(mean_k), C.c_float(stddev_mul),
                                                             out.ctypes.data, C.byref(n_out), dist.ctypes.data, C.byref(thr)))
         return dict(xyz=unpack_points(out, layout, n_out.value, n), distances=dist[:n], threshold=thr.value)
+
+    def process_node(self, xyz, occ=None, mean_k=0, stddev_mul=1.0, is_dense=True, layout=LAYOUT_AOS12, dev_ptr=None, n=None,
+                     want_grid=False):
+        """The node's chain in one call (od.cpp:727-797): [bounds filter + occupancy binning] -> voxel grid ->
+        [statistical outlier removal] -> clusters.  xyz: (n,3) host array, or dev_ptr/n for SoA planes already in HBM.
+        -> dict of the frame result + stats (+ counts, row_avg, grid with want_grid)."""
+        if dev_ptr is None:
+            flat, n = pack_points(xyz, layout)
+            ptr, mem = flat.ctypes.data, MEM_HOST
+        else:
+            ptr, mem, layout = dev_ptr, MEM_DEVICE, LAYOUT_SOA
+        counts = row_avg = grid = None
+        if occ is not None and want_grid:
+            cells, rows = occ.grid_width * occ.grid_height, occ.grid_height
+            counts = np.zeros(max(cells, 1), dtype=np.int64)
+            row_avg = np.zeros(max(rows, 1), dtype=np.int64)
+            grid = np.zeros(max(cells, 1), dtype=np.int8)
+        r, st = Result(), NodeStats()
+        self._chk(self.lib.pcop_process_node(self.h, C.c_void_p(ptr), layout, int(n), int(is_dense), mem,
+                                             C.cast(C.byref(occ), C.c_void_p) if occ is not None else None,
+                                             counts.ctypes.data if counts is not None else None,
+                                             row_avg.ctypes.data if row_avg is not None else None,
+                                             grid.ctypes.data if grid is not None else None,
+                                             int(mean_k), C.c_float(stddev_mul), C.byref(r), C.byref(st)))
+        out = self._result(r)
+        out.update(n_filtered=st.n_filtered, index_errors=st.index_errors, n_voxels=st.n_voxels, n_inliers=st.n_inliers,
+                   threshold=st.threshold)
+        if counts is not None:
+            out.update(counts=counts[:occ.grid_width * occ.grid_height], row_avg=row_avg[:occ.grid_height],
+                       grid=grid[:occ.grid_width * occ.grid_height])
+        return out
 
     def process_filtered(self):
         r = Result()

@@ -115,6 +115,8 @@ struct pcop_ctx {
     // LDS atomic adds of one wave instruction return their old values in lane order on this device (checked by
     // k_lds_order_probe when the context is made; PCOP_LDS_ORDER=0 skips the check and keeps the peer-mask ranks)
     bool lds_ordered = false;
+    const uint32_t* cur_n_dev = nullptr;     // the batch in flight takes frame 0's point count from the device (the cloud a filter kept)
+    bool retry_to_caller = false;            // finish_batch hands a re-plan back to its caller instead of re-running the plain chain
     // dense cell grid: on unless PCOP_CELL_PATH=hash; a frame whose grid exceeds kCmapCells is re-run on the hash
     // table and the context stays there until the tolerance changes
     bool cell_grid = true, cgrid_ok = true;
@@ -218,8 +220,11 @@ bool stream_on(const pcop_ctx* c) { return c->voxel_stream && c->stream_ok && c-
 
 // The launch sequence of one batch.  nb = launch-size bucket (>= every frame's point count), nf =
 // frames; all real counts are read on the device.  Everything here is capturable into a hipGraph.
+enum LaunchParts : uint32_t { kPartVoxel = 1u, kPartCluster = 2u, kPartEmit = 4u, kPartAll = 7u,
+                              kPartOwnGridSetup = 8u };   // the cluster part sets up its cell grid itself (something ran between the stages)
+
 template <int MAXB>
-void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
+void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, uint32_t parts) {
     hipStream_t s = c->stream;
     Frame* fr = c->d_frames;
     constexpr uint32_t kBinsGrid = (1u << MAXB) + 1u;
@@ -234,13 +239,13 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
     // k_voxel_setup also writes DevState from the mailbox and, when the dense cell grid is on, sets that up as well
     // (both need nothing but the bounds), so a frame has no separate init and grid set-up launches.  Only a cluster-only
     // frame on the hash table of cells has no bounds pass: it keeps its k_frame_init.
-    const uint32_t fold_grid = (kind != kFrameVoxelOnly && grid_on(c)) ? 4u : 0u;
-    if (kind == kFrameClusterOnly && !grid_on(c)) {
+    const uint32_t fold_grid = (kind != kFrameVoxelOnly && grid_on(c) && !(parts & kPartOwnGridSetup)) ? 4u : 0u;
+    if (kind == kFrameClusterOnly && !grid_on(c) && (parts & kPartVoxel)) {
         k_frame_init<<<dim3(1, nf), 64, 0, s>>>(fr);
         mark(c, "k_frame_init");
     }
-    if (kind != kFrameClusterOnly) {
-        k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr);
+    if (kind != kFrameClusterOnly && (parts & kPartVoxel)) {
+        k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, 0u);
         mark(c, "k_minmax");
         const bool stream = stream_on(c);
         k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, (stream ? 1u : 0u) | 2u | fold_grid);
@@ -285,11 +290,15 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
             mark(c, "k_voxel_reduce");
         }
     }
-    if (kind != kFrameVoxelOnly) {
+    if (kind != kFrameVoxelOnly && (parts & kPartCluster)) {
         const dim3 cg(std::max(1u, std::min(cell_blocks, div_up(nb, kBlock))), nf);   // lane = cell, grid-strided
         if (grid_on(c)) {
+            if (parts & kPartOwnGridSetup) {
+                k_cgrid_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr);
+                mark(c, "k_cgrid_setup");
+            }
             if (kind == kFrameClusterOnly) {   // the bounding box of the cloud (a chain frame has it from the voxel stage)
-                k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr);
+                k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, 0u);
                 mark(c, "k_minmax");
                 k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, 2u | 4u);
                 mark(c, "k_voxel_setup");
@@ -341,16 +350,19 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
             mark(c, "k_csr_scatter");
         }
     }
-    k_emit<<<tg, kBlock, 0, s>>>(fr, c->npass_csr);
-    mark(c, "k_emit");
+    if (parts & kPartEmit) {
+        k_emit<<<tg, kBlock, 0, s>>>(fr, c->npass_csr);
+        mark(c, "k_emit");
+    }
 }
 
-void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf) {
-    if (c->maxbits <= kNarrowBits) enqueue_launches_t<kNarrowBits>(c, kind, nb, nf);
-    else enqueue_launches_t<kMaxBits>(c, kind, nb, nf);
+void enqueue_launches(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, uint32_t parts = kPartAll) {
+    if (c->maxbits <= kNarrowBits) enqueue_launches_t<kNarrowBits>(c, kind, nb, nf, parts);
+    else enqueue_launches_t<kMaxBits>(c, kind, nb, nf, parts);
 }
 
-int enqueue_batch(pcop_ctx* c) {
+// Per-frame inputs into the pinned mailboxes; returns the launch bucket.
+uint32_t fill_frame_args(pcop_ctx* c) {
     const pcop_params& p = c->params;
     const float inv_leaf = 1.0f / p.leaf;                         // Array4f::Ones() / leaf_size_
     const double radius = (double)p.tol;
@@ -370,11 +382,17 @@ int enqueue_batch(pcop_ctx* c) {
         a.voxel_stream = stream_on(c) ? 1u : 0u; a.nb_cap = c->nb_cap; a.cell_grid = grid_on(c) ? 1u : 0u; a.gbits = c->gbits;
         a.tile = 0u; a.pad0 = 0u;   // set below, once the launch bucket is known
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
+        a.n_dev = f == 0 ? c->cur_n_dev : nullptr; a.sor_thr = 0.0;
         nmax = std::max(nmax, sl.n);
     }
     c->frame_npass_csr = c->npass_csr;
     const uint32_t nb = bucket_of(c, nmax);
     for (uint32_t f = 0; f < c->nframes; ++f) c->slots[f].h_args->tile = tile_for(nb, c->nframes);
+    return nb;
+}
+
+int enqueue_batch(pcop_ctx* c) {
+    const uint32_t nb = fill_frame_args(c);
     c->ev_used = 0;
     if (c->profiling || !c->use_graph) {
         mark(c, "start");
@@ -491,6 +509,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (e & kErrNonFinite) { c->in_flight = false; scrub_flags(c); c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
         if (e & kErrRange) { c->in_flight = false; scrub_flags(c); c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
         if (e & kErrInternal) { c->in_flight = false; scrub_flags(c); c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
+        if (e & kErrSorFew) { c->in_flight = false; scrub_flags(c); c->err = "fewer points than mean_k + 1"; return PCOP_ERR_STATE; }
         if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanBins | kErrReplanCpath | kErrReplanCtiles)) {
             if (attempt >= 6) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
             if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));
@@ -515,6 +534,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
                     if (hs->err & kErrReplanVcap) c->nb_cap = std::max(c->nb_cap, std::min(kNbMax, pow2_at_least(hs->nbuckets)));
                 }
             }
+            if (c->retry_to_caller) { c->in_flight = false; return 1; }   // (not a pcop_status: the caller runs its own sequence again)
             int rc = enqueue_batch(c);
             if (rc) return rc;
             continue;
@@ -652,7 +672,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         TRY(dev_alloc(c, &f.bin2bucket, ((size_t)1 << kBinBitsMax) + 8));
         TRY(dev_alloc(c, &f.binfo, (size_t)kNbMax + 1));
         TRY(dev_alloc(c, &f.binsum, ((size_t)1 << kBinBitsMax) + 8));
-        f.tstride = (uint32_t)((tiles + 7) / 8 * 8); f.pad_f = 0;
+        f.tstride = (uint32_t)((tiles + 7) / 8 * 8);
         TRY(dev_alloc(c, &f.tcnt, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.tbase, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.bucket_pub, (size_t)kNbMax));
@@ -664,6 +684,8 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
     TRY(host_alloc(c, &sl.h_vox, 4 * n)); TRY(host_alloc(c, &sl.h_xyzr, 4 * (n + 1))); TRY(host_alloc(c, &sl.h_clu, 4 * (n + 1)));
 #undef TRY
     f.args = sl.h_args;
+    f.cap = (uint32_t)n;
+    f.h_aux = sl.h_xyzr;
     f.h_state = sl.h_state;
     f.h_offsets = reinterpret_cast<uint32_t*>(sl.h_offsets_disc);
     f.h_indices = reinterpret_cast<uint32_t*>(sl.h_indices_disc);
@@ -678,6 +700,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
 }
 
 int submit_common(pcop_ctx* c, uint32_t kind, bool emit_cloud, int out_layout, int is_dense) {
+    c->cur_n_dev = nullptr; c->retry_to_caller = false;
     c->is_dense = is_dense; c->kind = kind; c->emit_cloud = emit_cloud; c->out_layout = out_layout;
     return enqueue_batch(c);
 }
@@ -944,22 +967,20 @@ void pcop_occupancy_grid_dims(float x_min, float x_max, float y_min, float y_max
     if (grid_height) *grid_height = (int32_t)std::ceil((std::fabs(x_min) + std::fabs(x_max)) / block_size);
 }
 
-int pcop_occupancy_filter(pcop_ctx* c, const float* xyz, int layout, size_t n, int mem, const pcop_occ_params* p,
-                          float* out_xyz, size_t* n_out, int64_t* counts, int64_t* row_avg, int8_t* grid,
-                          int32_t* index_errors) {
-    if (!c || !p) return PCOP_ERR_ARG;
-    int rc = busy(c);
-    if (rc) return rc;
+// The occupancy step, part one: argument checks.
+static int occ_check(pcop_ctx* c, const pcop_occ_params* p) {
     const float lim[6] = {p->x_min, p->x_max, p->y_min, p->y_max, p->z_min, p->z_max};
     for (float v : lim) if (!std::isfinite(v)) { c->err = "occupancy limits must be finite"; return PCOP_ERR_PARAM; }
     if (!(p->block_size > 0.0f) || !std::isfinite(p->block_size) || !std::isfinite(p->dev_percent)) { c->err = "block_size must be finite and > 0"; return PCOP_ERR_PARAM; }
     if (p->grid_width <= 0 || p->grid_height <= 0 || (int64_t)p->grid_width * p->grid_height > (1 << 26)) { c->err = "occupancy grid must have 1 .. 2^26 cells"; return PCOP_ERR_PARAM; }
     // the walks of od.cpp:139-147 end only if the limits are reachable in a sane number of steps
     if ((std::fabs(p->x_min) + std::fabs(p->x_max) + std::fabs(p->y_min) + std::fabs(p->y_max)) / p->block_size > 1.0e8f) { c->err = "limits / block_size too large"; return PCOP_ERR_PARAM; }
-    if ((rc = set_device(c))) return rc;
-    Slot& sl = c->slots[0];
-    sl.have_result = false;   // slot 0's staging buffers are about to be overwritten
-    if ((rc = stage_input(c, sl, xyz, layout, n, mem))) return rc;
+    return PCOP_OK;
+}
+
+// ... part two: buffers and launches on the slot's staged cloud (no synchronisation; the kept cloud and its point count
+// stay on the device: c->occ_xyz, c->occ_totals[0]).
+static int occ_launch(pcop_ctx* c, Slot& sl, size_t n, const pcop_occ_params* p) {
     const size_t cells = (size_t)p->grid_width * p->grid_height, rows = (size_t)p->grid_height;
     if (!c->occ_xyz) {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->occ_xyz), std::max<size_t>(c->cap, 1) * 3 * sizeof(float)));
@@ -1001,6 +1022,23 @@ int pcop_occupancy_filter(pcop_ctx* c, const float* xyz, int layout, size_t n, i
     k_occ_finish<<<(uint32_t)rows, kBlock, 0, c->stream>>>(op, c->occ_counts, c->occ_partials, c->occ_rowavg, c->occ_grid);
     mark(c, "k_occ_finish");
     HIPCHK(c, hipGetLastError());
+    return PCOP_OK;
+}
+
+int pcop_occupancy_filter(pcop_ctx* c, const float* xyz, int layout, size_t n, int mem, const pcop_occ_params* p,
+                          float* out_xyz, size_t* n_out, int64_t* counts, int64_t* row_avg, int8_t* grid,
+                          int32_t* index_errors) {
+    if (!c || !p) return PCOP_ERR_ARG;
+    int rc = busy(c);
+    if (rc) return rc;
+    if ((rc = occ_check(c, p))) return rc;
+    if ((rc = set_device(c))) return rc;
+    Slot& sl = c->slots[0];
+    sl.have_result = false;   // slot 0's staging buffers are about to be overwritten
+    if ((rc = stage_input(c, sl, xyz, layout, n, mem))) return rc;
+    if ((rc = occ_launch(c, sl, n, p))) return rc;
+    const size_t cells = (size_t)p->grid_width * p->grid_height, rows = (size_t)p->grid_height;
+    float* ox = c->occ_xyz; float* oy = ox + c->cap; float* oz = oy + c->cap;
     uint32_t totals[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(totals, c->occ_totals, sizeof(totals), hipMemcpyDeviceToHost, c->stream));
     if (counts) HIPCHK(c, hipMemcpyAsync(counts, c->occ_counts, cells * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
@@ -1042,46 +1080,8 @@ int pcop_process_filtered(pcop_ctx* c, pcop_result* out) {
     return finish_batch(c, out, out ? 1 : 0);
 }
 
-// One eager pass of a cluster-only frame up to the point where the requested stage has run; k_emit at the end puts
-// the DevState into pinned host memory and hands the borrowed per-cell counters back clean.
-static int sor_pass(pcop_ctx* c, Slot& sl, double inv_cell, bool with_knn, uint32_t mean_k, double edge) {
-    sl.have_result = false;   // the slot's device state is about to be overwritten: no cluster summaries from it afterwards
-    FrameArgs& a = *sl.h_args;
-    std::memset(&a, 0, sizeof(a));
-    a.n = sl.n; a.is_dense = 1u; a.kind = kFrameClusterOnly; a.trivial = 0u;
-    a.inv_leaf = 1.0f; a.r2 = 1.0f; a.inv_cell = inv_cell;
-    a.min_cluster = 1u; a.max_cluster = 0xFFFFFFFFu;
-    a.out_layout = (uint32_t)PCOP_LAYOUT_AOS12; a.out_soa_stride = sl.n;
-    a.cell_grid = 1u; a.nb_cap = c->nb_cap; a.gbits = c->gbits; a.tile = kBinTile;
-    a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
-    Frame* fr = c->d_frames;
-    hipStream_t s = c->stream;
-    const uint32_t n = sl.n;
-    const dim3 tg(stride_grid(n), 1), sg(std::max(1u, div_up(n, kScanTile)), 1);
-    c->ev_used = 0;
-    mark(c, "start");
-    k_frame_init<<<dim3(1, 1), 64, 0, s>>>(fr);
-    k_minmax<<<dim3(kReduceBlocks, 1), kBlock, 0, s>>>(fr);
-    k_voxel_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr, kReduceBlocks, 1u, (uint32_t)kNarrowBits, 0u);
-    mark(c, "bounds");
-    if (with_knn) {
-        k_cgrid_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr);
-        k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
-        k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
-        k_cell_count<<<tg, kBlock, 0, s>>>(fr);
-        k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
-        k_cell_place<<<tg, kBlock, 0, s>>>(fr);
-        mark(c, "cell_grid");
-        k_knn_mean<<<tg, kBlock, 0, s>>>(fr, mean_k, edge);
-        mark(c, "k_knn_mean");
-    }
-    k_emit<<<tg, kBlock, 0, s>>>(fr, 1u);
-    mark(c, "k_emit");
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(s));
-    collect_times(c);
-    return PCOP_OK;
-}
+// StatisticalOutlierRemoval::applyFilterIndices, second half: sequential double sums in index order, then the threshold.
+static double sor_threshold(const float* dist, size_t n, float stddev_mul);
 
 int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, size_t n, int mean_k, float stddev_mul,
                                      float* out_xyz, size_t* n_out, float* distances, double* threshold) {
@@ -1101,54 +1101,175 @@ int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, 
     if ((rc = set_device(c))) return rc;
     Slot& sl = c->slots[0];
     if ((rc = stage_input(c, sl, xyz, layout, n, PCOP_MEM_HOST))) return rc;
-    // bounds (and the non-finite check) first: the cell edge depends on the density
-    if ((rc = sor_pass(c, sl, 1.0, false, 0u, 1.0))) return rc;
-    if (sl.h_state->err & kErrNonFinite) { c->err = "non-finite coordinates"; return PCOP_ERR_NONFINITE; }
-    double ext[3], longest = 0.0;
-    for (int a = 0; a < 3; ++a) { ext[a] = std::max((double)sl.h_state->vmax[a] - (double)sl.h_state->vmin[a], 1e-6); longest = std::max(longest, ext[a]); }
-    // about four points per cell if the cloud filled its box; surfaces end up sparser, the ring search does not care
-    double edge = std::cbrt(ext[0] * ext[1] * ext[2] * 4.0 / (double)n);
-    edge = std::max(edge, longest / 2000.0);
-    auto cells_of = [&](double e) {
-        double t = 1.0;
-        for (int a = 0; a < 3; ++a) t *= std::floor(ext[a] / e) + 1.0 + 2.0 * kCellMargin + (a == 0 ? 32.0 : 0.0);
-        return t;
-    };
-    while (cells_of(edge) > 0.5 * (double)kCmapCells) edge *= 1.26;
-    for (int attempt = 0;; ++attempt) {
-        if ((rc = sor_pass(c, sl, 1.0 / edge, true, (uint32_t)mean_k, edge))) return rc;
-        const uint32_t e = sl.h_state->err;
-        if (e & kErrReplanCpath) {
-            if (attempt >= 8) { scrub_flags(c); c->err = "no cell grid fits this cloud"; return PCOP_ERR_STATE; }
-            edge *= 2.0;
-            continue;
-        }
-        if (e) { scrub_flags(c); c->err = "internal error in the k-NN pass"; return PCOP_ERR_STATE; }
-        break;
-    }
-    std::vector<float> dist(n);
-    HIPCHK(c, hipMemcpy(dist.data(), sl.f.cen_x.get(), n * sizeof(float), hipMemcpyDeviceToHost));
-    // StatisticalOutlierRemoval::applyFilterIndices, second half: sequential double sums in index order
-    double sum = 0.0, sq_sum = 0.0;
-    for (size_t i = 0; i < n; ++i) { sum += dist[i]; sq_sum += dist[i] * dist[i]; }
-    const double valid = (double)n;
-    const double mean = sum / valid;
-    const double variance = (sq_sum - sum * sum / valid) / (valid - 1.0);
-    const double thr = mean + (double)stddev_mul * std::sqrt(variance);
+    // One pass of a cluster-only frame: bounds, a cell grid sized from them on the device (k_sor_setup), the k-NN kernel
+    // writing the mean distances to pinned host memory, k_emit handing the borrowed per-cell counters back clean.
+    FrameArgs& a = *sl.h_args;
+    std::memset(&a, 0, sizeof(a));
+    a.n = sl.n; a.is_dense = 1u; a.kind = kFrameClusterOnly; a.trivial = 0u;
+    a.inv_leaf = 1.0f; a.r2 = 1.0f; a.inv_cell = 1.0;
+    a.min_cluster = 1u; a.max_cluster = 0xFFFFFFFFu;
+    a.out_layout = (uint32_t)PCOP_LAYOUT_AOS12; a.out_soa_stride = sl.n;
+    a.cell_grid = 1u; a.nb_cap = c->nb_cap; a.gbits = c->gbits; a.tile = kBinTile;
+    a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
+    Frame* fr = c->d_frames;
+    hipStream_t s = c->stream;
+    const dim3 tg(stride_grid(sl.n), 1), sg(std::max(1u, div_up(sl.n, kScanTile)), 1);
+    c->ev_used = 0;
+    mark(c, "start");
+    k_frame_init<<<dim3(1, 1), 64, 0, s>>>(fr);
+    k_minmax<<<dim3(kReduceBlocks, 1), kBlock, 0, s>>>(fr, 1u);
+    k_sor_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr, kReduceBlocks, (uint32_t)mean_k);
+    mark(c, "bounds");
+    k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
+    k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
+    k_cell_count<<<tg, kBlock, 0, s>>>(fr);
+    k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
+    k_cell_place<<<tg, kBlock, 0, s>>>(fr);
+    mark(c, "cell_grid");
+    k_knn_mean<<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
+    mark(c, "k_knn_mean");
+    k_emit<<<tg, kBlock, 0, s>>>(fr, 1u);
+    mark(c, "k_emit");
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    collect_times(c);
+    const uint32_t e = sl.h_state->err;
+    if (e & kErrNonFinite) { scrub_flags(c); c->err = "non-finite coordinates"; return PCOP_ERR_NONFINITE; }
+    if (e) { scrub_flags(c); c->err = (e & kErrReplanCpath) ? "no cell grid fits this cloud" : "internal error in the k-NN pass"; return PCOP_ERR_STATE; }
+    const float* dist = sl.h_xyzr;   // pinned: the kernel wrote the n mean distances here
+    const double thr = sor_threshold(dist, n, stddev_mul);
     size_t kept = 0;
     const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
     for (size_t i = 0; i < n; ++i) {
         if ((double)dist[i] > thr) continue;   // the outliers
         if (layout == PCOP_LAYOUT_SOA) {
-            for (int a = 0; a < 3; ++a) out_xyz[(size_t)a * n + kept] = xyz[(size_t)a * n + i];
+            for (int ax = 0; ax < 3; ++ax) out_xyz[(size_t)ax * n + kept] = xyz[(size_t)ax * n + i];
         } else {
-            for (size_t a = 0; a < fl; ++a) out_xyz[fl * kept + a] = xyz[fl * i + a];
+            for (size_t ax = 0; ax < fl; ++ax) out_xyz[fl * kept + ax] = xyz[fl * i + ax];
         }
         ++kept;
     }
     *n_out = kept;
-    if (distances) std::memcpy(distances, dist.data(), n * sizeof(float));
+    if (distances) std::memcpy(distances, dist, n * sizeof(float));
     if (threshold) *threshold = thr;
+    return PCOP_OK;
+}
+
+static double sor_threshold(const float* dist, size_t n, float stddev_mul) {
+    double sum = 0.0, sq_sum = 0.0;
+    for (size_t i = 0; i < n; ++i) { sum += dist[i]; sq_sum += dist[i] * dist[i]; }
+    const double valid = (double)n;
+    const double mean = sum / valid;
+    const double variance = (sq_sum - sum * sum / valid) / (valid - 1.0);
+    return mean + (double)stddev_mul * std::sqrt(variance);
+}
+
+int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem, const pcop_occ_params* occ,
+                      int64_t* counts, int64_t* row_avg, int8_t* grid, int mean_k, float stddev_mul, pcop_result* out,
+                      pcop_node_stats* stats) {
+    if (!c || !out) return PCOP_ERR_ARG;
+    int rc = busy(c);
+    if (rc) return rc;
+    if ((rc = check_params(c, true, true))) return rc;
+    if (mem != PCOP_MEM_HOST && mem != PCOP_MEM_DEVICE) return PCOP_ERR_ARG;
+    if (occ && (rc = occ_check(c, occ))) return rc;
+    const bool sor = mean_k != 0;
+    if (sor) {
+        if (mean_k < 1 || mean_k + 1 > kKnnMax) { c->err = "mean_k must be 1..31"; return PCOP_ERR_PARAM; }
+        if (!std::isfinite(stddev_mul)) { c->err = "stddev multiplier must be finite"; return PCOP_ERR_PARAM; }
+        if (!c->cell_grid) { c->err = "statistical outlier removal needs the dense cell grid (context created with PCOP_CELL_PATH=hash)"; return PCOP_ERR_STATE; }
+        const double radius = (double)c->params.tol;
+        if (!((float)(radius * radius) > 0.0f)) { c->err = "the node chain with outlier removal needs a tolerance > 0"; return PCOP_ERR_PARAM; }
+    }
+    if ((rc = set_device(c))) return rc;
+    Slot& sl = c->slots[0];
+    sl.have_result = false;
+    if ((rc = stage_input(c, sl, xyz, layout, n, mem))) return rc;
+    c->occ_valid = false;
+    const uint32_t* n_dev = nullptr;
+    if (occ) {   // the kept cloud and its point count stay on the device
+        if ((rc = occ_launch(c, sl, n, occ))) return rc;
+        const size_t cells = (size_t)occ->grid_width * occ->grid_height, rows = (size_t)occ->grid_height;
+        if (counts) HIPCHK(c, hipMemcpyAsync(counts, c->occ_counts, cells * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        if (row_avg) HIPCHK(c, hipMemcpyAsync(row_avg, c->occ_rowavg, rows * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        if (grid) HIPCHK(c, hipMemcpyAsync(grid, c->occ_grid, cells, hipMemcpyDeviceToHost, c->stream));
+        sl.src_x = c->occ_xyz; sl.src_y = c->occ_xyz + c->cap; sl.src_z = c->occ_xyz + 2 * c->cap;
+        n_dev = c->occ_totals;
+        is_dense = 1;   // the cloud build_initial_occupancy_grid_dataset fills keeps PointCloud's default is_dense = true (od.cpp:214)
+    }
+    c->nframes = 1;
+    c->is_dense = is_dense; c->kind = kFrameChain; c->emit_cloud = c->params.publish_clouds != 0; c->out_layout = c->cloud_layout;
+    c->cur_n_dev = n_dev;
+    double thr = 0.0;
+    uint32_t n_vox = 0;
+    for (int attempt = 0;; ++attempt) {
+        if (attempt >= 8) { c->cur_n_dev = nullptr; c->retry_to_caller = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
+        if (!sor) {   // the plain chain on the kept cloud; finish_batch re-plans by itself (the mailbox keeps the device count)
+            c->retry_to_caller = false;
+            if ((rc = enqueue_batch(c))) break;
+            rc = finish_batch(c, out, 1);
+            n_vox = sl.h_state->m;
+            break;
+        }
+        c->retry_to_caller = true;
+        const uint32_t nb = fill_frame_args(c);
+        Frame* fr = c->d_frames;
+        hipStream_t s = c->stream;
+        c->ev_used = 0;
+        mark(c, "start");
+        enqueue_launches(c, kFrameChain, nb, 1, kPartVoxel | kPartOwnGridSetup);
+        // outlier removal, first half: bounds of the voxel cloud, a cell grid sized for it, mean distance to the mean_k nearest neighbours
+        const dim3 tg(stride_grid(nb), 1), sg(std::max(1u, div_up(nb, kScanTile)), 1);
+        k_minmax<<<dim3(kReduceBlocks, 1), kBlock, 0, s>>>(fr, 1u);
+        k_sor_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr, kReduceBlocks, (uint32_t)mean_k);
+        k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
+        k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
+        k_cell_count<<<tg, kBlock, 0, s>>>(fr);
+        k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
+        k_cell_place<<<tg, kBlock, 0, s>>>(fr);
+        mark(c, "sor_grid");
+        k_knn_mean<<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
+        mark(c, "k_knn_mean");
+        k_cells_reset<<<tg, kBlock, 0, s>>>(fr);
+        k_state_out<<<dim3(1, 1), 64, 0, s>>>(fr);
+        HIPCHK(c, hipGetLastError());
+        c->in_flight = true;
+        HIPCHK(c, hipStreamSynchronize(s));
+        const DevState* hs = sl.h_state;
+        if (hs->err) {   // let finish_batch sort the error out: a re-plan comes back as 1, anything else as its status
+            rc = finish_batch(c, nullptr, 0);
+            if (rc == 1) continue;
+            if (rc == PCOP_OK) { c->err = "internal: error bits without a status"; rc = PCOP_ERR_STATE; }
+            break;
+        }
+        n_vox = hs->m;
+        const uint32_t npts = hs->c_n;   // the voxel cloud (or the input after a pass-through)
+        thr = npts ? sor_threshold(sl.h_xyzr, npts, stddev_mul) : 0.0;
+        sl.h_args->sor_thr = thr;
+        // second half: the points within the threshold, then the clusters on what is left
+        k_sor_select<<<sg, kBlock, 0, s>>>(fr);
+        mark(c, "k_sor_select");
+        enqueue_launches(c, kFrameChain, nb, 1, kPartCluster | kPartEmit | kPartOwnGridSetup);
+        HIPCHK(c, hipGetLastError());
+        rc = finish_batch(c, out, 1);
+        if (rc == 1) continue;
+        break;
+    }
+    c->cur_n_dev = nullptr; c->retry_to_caller = false;
+    if (rc) {
+        if (rc == PCOP_ERR_STATE && (sl.h_state->err & kErrSorFew)) { c->err = "fewer voxels than mean_k + 1: the reference reads past its k-NN result"; return PCOP_ERR_PARAM; }
+        return rc;
+    }
+    const DevState* hs = sl.h_state;
+    if (c->emit_cloud) out->num_voxels = (int32_t)(hs->c_from_input && !hs->passthrough ? hs->c_n : hs->m);
+    out->voxel_xyz = (c->emit_cloud && out->num_voxels) ? sl.h_vox : nullptr;
+    if (stats) {
+        uint32_t totals[4] = {0, 0, 0, 0};
+        if (occ) HIPCHK(c, hipMemcpy(totals, c->occ_totals, sizeof(totals), hipMemcpyDeviceToHost));
+        stats->n_in = (int32_t)n; stats->n_filtered = (int32_t)hs->n_in; stats->index_errors = (int32_t)totals[1];
+        stats->n_voxels = (int32_t)n_vox; stats->n_inliers = (int32_t)(sor ? hs->c_n : n_vox); stats->reserved = 0; stats->threshold = thr;
+    }
+    if (occ) { c->occ_n = hs->n_in; c->occ_valid = true; }
     return PCOP_OK;
 }
 

@@ -292,12 +292,12 @@ __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t n
         for (uint32_t i = tid; i <= k; i += nth) out.offsets[i] = d_offsets[i];
         for (uint32_t i = tid; i < np; i += nth) out.indices[i] = d_indices[i];
     }
-    if (st->emit_cloud) {
-        const bool pt = st->passthrough != 0;
+    if (st->emit_cloud) {   // the cloud the cluster indices refer to: the voxel centroids, or the input planes (pass-through; the cloud a filter kept)
+        const bool pt = st->c_from_input != 0 && st->kind != kFrameClusterOnly;
         const float* __restrict__ px = pt ? st->src_x : cen_x;
         const float* __restrict__ py = pt ? st->src_y : cen_y;
         const float* __restrict__ pz = pt ? st->src_z : cen_z;
-        const uint32_t m = st->m, layout = st->out_layout, stride = st->out_soa_stride;
+        const uint32_t m = pt ? st->c_n : st->m, layout = st->out_layout, stride = st->out_soa_stride;
         for (uint32_t i = tid; i < m; i += nth) {
             const float x = px[i], y = py[i], z = pz[i];
             if (layout == 0) {

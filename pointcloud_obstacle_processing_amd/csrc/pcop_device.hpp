@@ -87,9 +87,9 @@ struct DevPtr {
     __host__ __device__ T* get() const { return (T*)p; }
 #else
     T* p;
-    DevPtr& operator=(T* q) { p = q; return *this; }
-    operator T*() const { return p; }
-    T* get() const { return p; }
+    __host__ __device__ DevPtr& operator=(T* q) { p = q; return *this; }   // (the host pass checks kernel bodies too)
+    __host__ __device__ operator T*() const { return p; }
+    __host__ __device__ T* get() const { return p; }
 #endif
 };
 static_assert(sizeof(DevPtr<float>) == sizeof(float*), "DevPtr is layout-compatible with a pointer");
@@ -103,6 +103,7 @@ enum ErrBits : uint32_t {
     kErrReplanPath = 64u,  // the streaming voxel path does not apply to this frame (too many buckets)
     kErrReplanVcap = 128u, // the streaming voxel path needs more buckets than the launch provided LDS for
     kErrReplanBins = 1024u,  // a coarse key bin holds more points than a bucket (or spans more cells): finer bins needed
+    kErrSorFew = 2048u,      // statistical outlier removal on fewer than mean_k + 1 points (the reference reads past its search result)
     kErrReplanCpath = 256u,  // the dense cell grid does not apply to this frame (grid too large)
     kErrReplanCtiles = 512u, // the occupancy scan of the dense cell grid was launched with too few tiles
 };
@@ -127,6 +128,8 @@ struct FrameArgs {
     uint32_t cell_grid, gbits;                // dense cell grid requested (else: the hash table of cells); log2 of the coarse bins wanted
     uint32_t tile, pad0;                      // streaming voxel path: points per tile (kBinTile or kBinTileSmall)
     DevPtr<const float> src_x, src_y, src_z;
+    DevPtr<const uint32_t> n_dev;             // when set: the point count lives on the device (at most n): the cloud a previous kernel kept
+    double sor_thr;                           // statistical outlier removal: mean + stddev_mul * sigma, formed by the host between the two halves of the node chain
 };
 
 // Device-resident frame state; k_emit copies it to pinned host memory at the end of a frame.
@@ -206,7 +209,8 @@ struct Frame {
     DevPtr<uint32_t> binsum;          // [coarse bin]: points of the frame in the bin
     DevPtr<uint16_t> tcnt;            // [bucket][tstride]: points of the tile in the bucket
     DevPtr<uint32_t> tbase;           // [bucket][tstride]: points of the lower tiles in the bucket
-    uint32_t tstride, pad_f;          // tiles a context provides for, rounded up to a multiple of 8
+    uint32_t tstride, cap;            // tiles a context provides for, rounded up to a multiple of 8; points a slot provides for
+    DevPtr<float> h_aux;              // pinned host: per-point values a call hands to the host (mean neighbour distances)
     DevPtr<uint32_t> bucket_pub;      // [bucket]: its voxel count + 1 once known (0 = not yet)
     // dense cell grid (null when the context was created without it)
     DevPtr<uint8_t> cflag;            // one byte per grid cell: occupied?  all zero between frames

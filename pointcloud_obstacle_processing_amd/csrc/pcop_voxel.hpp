@@ -67,7 +67,7 @@ __device__ __forceinline__ void frame_init(Frame& F) {   // one thread: the mail
         const FrameArgs a = *F.args;
         DevState s;
         memset(&s, 0, sizeof(s));
-        s.n_in = a.n; s.is_dense = a.is_dense; s.kind = a.kind; s.trivial = a.trivial;
+        s.n_in = a.n_dev.get() ? min(*a.n_dev, a.n) : a.n; s.is_dense = a.is_dense; s.kind = a.kind; s.trivial = a.trivial;
         s.emit_cloud = a.emit_cloud; s.out_layout = a.out_layout; s.out_soa_stride = a.out_soa_stride;
         s.inv_leaf = a.inv_leaf; s.r2 = a.r2; s.inv_cell = a.inv_cell;
         s.min_cluster = a.min_cluster; s.max_cluster = a.max_cluster;
@@ -75,9 +75,9 @@ __device__ __forceinline__ void frame_init(Frame& F) {   // one thread: the mail
         s.debug_skip_union = a.debug_skip_union;
         s.nb_cap = a.nb_cap; s.gbits = a.gbits; s.tile = a.tile ? a.tile : kBinTile; s.cgrid_req = a.cell_grid;
         if (a.kind == kFrameClusterOnly) {   // no voxel stage: cluster the input cloud as it is
-            s.c_from_input = 1; s.c_n = a.n; s.n_valid = a.n;
+            s.c_from_input = 1; s.c_n = s.n_in; s.n_valid = s.n_in;
             uint32_t cap = 1024;
-            while (cap < 2u * a.n && cap < 0x80000000u) cap <<= 1;
+            while (cap < 2u * s.n_in && cap < 0x80000000u) cap <<= 1;
             s.hash_mask = cap - 1u;
         }
         *st = s;
@@ -179,7 +179,9 @@ __device__ __forceinline__ void reduce_partials_lds(MinMaxPartial* s_p) {   // k
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_minmax(Frame* frames) {
+// from_cen = 0: the input cloud, straight from the mailbox; 1: the cloud the cell stage will see (voxel centroids or, after a
+// pass-through, the input), from DevState - the bounds pass of the statistical outlier removal inside the node chain.
+__global__ __launch_bounds__(kBlock) void k_minmax(Frame* frames, uint32_t from_cen) {
     __shared__ MinMaxPartial s_p[kBlock];
     Frame& F = frames[blockIdx.y];
     MinMaxPartial* partials = F.partials;
@@ -188,11 +190,13 @@ __global__ __launch_bounds__(kBlock) void k_minmax(Frame* frames) {
     __shared__ FrameArgs s_args;
     if (threadIdx.x == 0) s_args = *F.args;
     __syncthreads();
-    if (s_args.kind == kFrameClusterOnly && !s_args.cell_grid) return;   // bounds of a cluster-only frame: for the dense cell grid
-    const float* __restrict__ x = s_args.src_x;
-    const float* __restrict__ y = s_args.src_y;
-    const float* __restrict__ z = s_args.src_z;
-    const uint32_t n = s_args.n;
+    if (!from_cen && s_args.kind == kFrameClusterOnly && !s_args.cell_grid) return;   // bounds of a cluster-only frame: for the dense cell grid
+    const DevState* st = &F.st;
+    const bool cen = from_cen && !st->c_from_input;
+    const float* __restrict__ x = from_cen ? (cen ? F.cen_x.get() : st->src_x.get()) : s_args.src_x.get();
+    const float* __restrict__ y = from_cen ? (cen ? F.cen_y.get() : st->src_y.get()) : s_args.src_y.get();
+    const float* __restrict__ z = from_cen ? (cen ? F.cen_z.get() : st->src_z.get()) : s_args.src_z.get();
+    const uint32_t n = from_cen ? (st->err ? 0u : st->c_n) : (s_args.n_dev.get() ? min(*s_args.n_dev, s_args.n) : s_args.n);
     const float fmax = 3.402823466e+38f;
     float mn0 = fmax, mn1 = fmax, mn2 = fmax, mx0 = -fmax, mx1 = -fmax, mx2 = -fmax;
     uint32_t valid = 0, bad = 0;

@@ -1,5 +1,6 @@
 #include "obstacle_path.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -164,8 +165,24 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
     rc = pcop_set_cloud_layout(ctx_, PCOP_LAYOUT_AOS16);
     if (rc) { error_ = pcop_last_error(ctx_); return rc; }
     pcop_result r{};
-    rc = pcop_process_pointcloud2(ctx_, cloud_msg.data.data(), cloud_msg.width, cloud_msg.height, cloud_msg.point_step,
-                                  cloud_msg.row_step, ox, oy, oz, cloud_msg.is_bigendian ? 1 : 0, cloud_msg.is_dense ? 1 : 0, &r);
+    if (node_order) {
+        PointCloudXYZ in;                                   // pcl::fromPCLPointCloud2 (od.cpp:688-689), on the host as there
+        if (!from_pointcloud2(cloud_msg, &in, &error_)) return PCOP_ERR_ARG;
+        pcop_occ_params occ{};
+        occ.x_min = params.x_min; occ.x_max = params.x_max; occ.y_min = params.y_min; occ.y_max = params.y_max;
+        occ.z_min = params.z_min; occ.z_max = params.z_max; occ.block_size = params.block_size; occ.dev_percent = params.dev_percent;
+        pcop_occupancy_grid_dims(occ.x_min, occ.x_max, occ.y_min, occ.y_max, occ.block_size, &occ.grid_width, &occ.grid_height);   // od.cpp:958-959
+        const size_t cells = (size_t)std::max(occ.grid_width, 0) * (size_t)std::max(occ.grid_height, 0);
+        occupancy_grid.assign(cells, 0); occupancy_counts.assign(cells, 0); occupancy_row_averages.assign((size_t)std::max(occ.grid_height, 0), 0);
+        static_assert(sizeof(long long) == sizeof(int64_t), "counts are 64-bit");
+        rc = pcop_process_node(ctx_, in.points.empty() ? nullptr : &in.points[0].x, PCOP_LAYOUT_AOS16, in.points.size(), 1, PCOP_MEM_HOST,
+                               &occ, reinterpret_cast<int64_t*>(occupancy_counts.data()), reinterpret_cast<int64_t*>(occupancy_row_averages.data()),
+                               reinterpret_cast<int8_t*>(occupancy_grid.data()), params.statistical_outlier_meanK,
+                               params.statistical_outlier_stdDevThres, &r, &stats);
+    } else {
+        rc = pcop_process_pointcloud2(ctx_, cloud_msg.data.data(), cloud_msg.width, cloud_msg.height, cloud_msg.point_step,
+                                      cloud_msg.row_step, ox, oy, oz, cloud_msg.is_bigendian ? 1 : 0, cloud_msg.is_dense ? 1 : 0, &r);
+    }
     if (rc) { error_ = pcop_last_error(ctx_); return rc; }
     passthrough = r.passthrough;
     // the downsampled cloud (statistical_outlier_input_cloud, od.cpp:740-741)

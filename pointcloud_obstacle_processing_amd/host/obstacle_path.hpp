@@ -65,6 +65,15 @@ public:
     const std::string& last_error() const { return error_; }
 
     NodeParams params;
+    // false (default): the chain BASELINE.json's north star names, voxel grid -> clusters.  true: the node's own order,
+    // build_initial_occupancy_grid_dataset (limits, block_size, dev_percent of `params`) -> voxel grid ->
+    // remove_statistical_outliers (statistical_outlier_meanK / _stdDevThres) -> clusters (od.cpp:727-797, without the
+    // plane removal of od.cpp:778-781), one pcop_process_node call; voxel_cloud is then the cloud the cluster indices
+    // refer to (the inliers), occupancy_grid / _counts / _row_averages the grid outputs.
+    bool node_order = false;
+    std::vector<signed char> occupancy_grid;            // occupancy_grid_data (od.cpp:725)
+    std::vector<long long> occupancy_counts, occupancy_row_averages;
+    pcop_node_stats stats{};
     Publisher<PointCloud2> downsample_publisher;        // "voxel_grid",   queue 1   (od.cpp:1004)
     Publisher<PointIndicesArray> centroid_publisher;    // "centroids",    queue 1   (od.cpp:1009)
     Publisher<PointCloud2> euc_cluster_publisher;       // "euc_clusters", queue 5   (od.cpp:1010)

@@ -120,3 +120,39 @@ def test_node_harness_sor_between_voxel_grid_and_clusters(oracle, tmp_path):
     assert len(clusters) == len(want_off) - 1
     for c, idx in enumerate(clusters):
         assert np.array_equal(idx, want_idx[want_off[c]:want_off[c + 1]])
+
+
+def test_node_harness_node_order(oracle, tmp_path):
+    """--node-order: the node's own order (od.cpp:727-797 without the plane removal) through one pcop_process_node call:
+    bounds filter + occupancy binning -> voxel grid -> statistical outlier removal -> clusters, parameters from the yaml."""
+    exe = os.path.join(HOST, "pcop_node")
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    pts = synth.make_cloud("C3", n=90_000, seed=31)
+    pts[::91] = np.nan                      # a depth camera's holes
+    cloud = str(tmp_path / "c3.pc2")
+    pc2io.write_pointcloud2(cloud, pts, point_step=32, offsets=(0, 4, 8), width=300, height=300)
+    yaml_path = str(tmp_path / "params.yaml")
+    with open(yaml_path, "w") as f:
+        f.write("pointcloud_obstacle_processing:\n        x_min: 0.2\n        x_max: 4.3\n        y_min: 0.2\n        y_max: 4.3\n"
+                "        z_min: -0.4\n        z_max: 0.7\n        obstacle_detection:\n                block_size: 0.2\n"
+                "                dev_percent: 0.4\n                downsample_size: 0.04\n                statistical_outlier_meanK: 12\n"
+                "                statistical_outlier_stdDevThres: 1.5\n                euc_cluster_tolerance: 0.1\n"
+                "                euc_min_cluster_size: 5\n                euc_max_cluster_size: 20000\n")
+    out = subprocess.run([exe, "--params", yaml_path, "--cloud", cloud, "--out", str(tmp_path), "--node-order"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    f32 = np.float32
+    p = oracle.occ_params(f32(0.2), f32(4.3), f32(0.2), f32(4.3), f32(-0.4), f32(0.7), f32(0.2), f32(0.4))
+    kept = oracle.occupancy(pts, p)
+    vox, _ = oracle.voxel_downsample(kept["xyz"], 0.04)
+    s = oracle.sor(vox, 12, 1.5)
+    off, idx = oracle.euclidean_clusters(s["xyz"], 0.1, 5, 20000)
+    assert "inside the box %d, voxels %d, inliers %d" % (kept["n_out"], len(vox), len(s["xyz"])) in out.stdout
+    got = pc2io.read_pointcloud2(str(tmp_path / "voxel_grid.pc2"))
+    assert got["xyz"].tobytes() == s["xyz"].tobytes()
+    clusters = read_indices(str(tmp_path / "cluster_indices.txt"))
+    assert len(clusters) == len(off) - 1 and len(clusters) > 0
+    for c, ci in enumerate(clusters):
+        assert np.array_equal(ci, idx[off[c]:off[c + 1]])
+    ec = pc2io.read_pointcloud2(str(tmp_path / "euc_clusters.pc2"))
+    assert ec["xyz"].tobytes() == s["xyz"][idx].tobytes()

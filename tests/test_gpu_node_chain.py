@@ -1,0 +1,130 @@
+"""The node's own order on the device (od.cpp:727-797): build_initial_occupancy_grid_dataset -> downsample_cloud ->
+remove_statistical_outliers -> kd-tree + extract_euclidian_clusters, one C-ABI call (pcop_process_node), the cloud of
+every step staying in HBM.  Checked against the stage-by-stage chain of the CPU restatements: kept points, voxel
+centroids, inliers, cluster offsets and indices all bit-exact."""
+import numpy as np
+import pytest
+
+from pointcloud_obstacle_processing_amd import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pointcloud_obstacle_processing_amd import capi as m
+    m.load_library()
+    return m
+
+
+def field_cloud(n, seed):
+    """C3-like scene (ground plane + hovering boxes on a 4.5 m field) with a margin of points outside the node's box and
+    a few NaNs, as a depth camera delivers them."""
+    pts = synth.make_cloud("C3", n=n, seed=seed).copy()
+    rng = np.random.default_rng(seed + 1000)
+    k = n // 20
+    pts[rng.choice(n, k, replace=False)] += rng.uniform(-1.5, 1.5, (k, 3)).astype(f32)      # strays, some outside the box
+    pts[rng.choice(n, n // 500, replace=False)] = np.nan      # a depth camera's holes: x, y and z all NaN (the reference's
+    return pts                                                 # filter tests x only, od.cpp:199)
+
+
+def oracle_chain(oracle, pts, occ, leaf, mean_k, mul, tol, mn, mx):
+    cloud = pts
+    ref = {}
+    if occ is not None:
+        r = oracle.occupancy(pts, occ)
+        cloud = r["xyz"]
+        ref.update(n_filtered=r["n_out"], counts=r["counts"], row_avg=r["row_avg"], grid=r["grid"], index_errors=r["index_errors"])
+    vox, pt = oracle.voxel_downsample(cloud, leaf)
+    ref["n_voxels"] = len(vox)
+    if mean_k:
+        s = oracle.sor(vox, mean_k, mul)
+        ref["threshold"] = s["threshold"]
+        vox = s["xyz"]
+    ref["cloud"] = vox
+    ref["offsets"], ref["indices"] = oracle.euclidean_clusters(vox, tol, mn, mx)
+    return ref
+
+
+def occ_of(capi, oracle):
+    # the yaml's field box (params.yaml:2-7) with a usable z range
+    p = oracle.occ_params(0.0, 4.5, 0.0, 3.78, -0.5, 0.6, 0.15, 0.5)
+    return p, capi.OccParams(p.x_min, p.x_max, p.y_min, p.y_max, p.z_min, p.z_max, p.block_size, p.dev_percent, p.grid_width, p.grid_height)
+
+
+@pytest.mark.parametrize("use_occ,mean_k", [(True, 15), (True, 0), (False, 15), (False, 0)])
+@pytest.mark.parametrize("paths", ["stream+grid", "sort+hash"])
+def test_node_chain_matches_stage_by_stage_oracle(capi, oracle, monkeypatch, use_occ, mean_k, paths):
+    vox_path, cell_path = paths.split("+")
+    if cell_path == "hash" and mean_k:
+        pytest.skip("the k-NN pass needs the dense cell grid")
+    monkeypatch.setenv("PCOP_VOXEL_PATH", vox_path)
+    monkeypatch.setenv("PCOP_CELL_PATH", cell_path)
+    leaf, tol, mn, mx, mul = 0.05, 0.12, 5, 20000, 1.0
+    pts = field_cloud(300_000, 21)
+    if not use_occ:
+        pts = pts[np.isfinite(pts).all(axis=1)]
+    po, pc = occ_of(capi, oracle)
+    ref = oracle_chain(oracle, pts, po if use_occ else None, leaf, mean_k, mul, tol, mn, mx)
+    c = capi.Context(len(pts))
+    c.set_params(leaf=leaf, tol=tol, min_cluster=mn, max_cluster=mx, publish_clouds=1)
+    for rep in range(2):
+        got = c.process_node(pts, occ=pc if use_occ else None, mean_k=mean_k, stddev_mul=mul, want_grid=True)
+        assert got["voxel_xyz"].tobytes() == ref["cloud"].tobytes()
+        assert np.array_equal(got["offsets"], ref["offsets"]) and np.array_equal(got["indices"], ref["indices"])
+        assert got["n_voxels"] == ref["n_voxels"] and got["n_inliers"] == len(ref["cloud"])
+        if use_occ:
+            assert got["n_filtered"] == ref["n_filtered"] and got["index_errors"] == ref["index_errors"]
+            assert np.array_equal(got["counts"], ref["counts"]) and np.array_equal(got["row_avg"], ref["row_avg"])
+            assert np.array_equal(got["grid"], ref["grid"])
+        if mean_k:
+            assert got["threshold"] == ref["threshold"]
+    # the clouds of the topics come off the GPU as well
+    clu = c.cluster_cloud()
+    assert clu[:, :3].tobytes() == ref["cloud"][ref["indices"]].tobytes()
+    k = len(ref["offsets"]) - 1
+    if k:
+        assert np.max(np.abs(c.cluster_summaries(k) - oracle.cluster_summaries(ref["cloud"], ref["offsets"], ref["indices"]))) <= 1e-5
+    # the context goes back to plain frames afterwards
+    p1 = synth.params_of("C1")
+    c.set_params(publish_clouds=1, **p1)
+    small = synth.make_cloud("C1")
+    r1, g1 = oracle.process_xyz(small, **p1), c.process_xyz(small)
+    assert g1["voxel_xyz"].tobytes() == r1["voxel_xyz"].tobytes() and np.array_equal(g1["indices"], r1["indices"])
+    c.close()
+
+
+def test_node_chain_on_a_cloud_resident_in_hbm(capi, oracle):
+    leaf, tol, mn, mx = 0.04, 0.1, 5, 20000
+    pts = field_cloud(500_000, 22)
+    po, pc = occ_of(capi, oracle)
+    ref = oracle_chain(oracle, pts, po, leaf, 15, 2.0, tol, mn, mx)
+    c = capi.Context(len(pts))
+    c.set_params(leaf=leaf, tol=tol, min_cluster=mn, max_cluster=mx, publish_clouds=1)
+    ptr, n = c.upload_soa(pts)
+    got = c.process_node(None, occ=pc, mean_k=15, stddev_mul=2.0, dev_ptr=ptr, n=n)
+    assert got["voxel_xyz"].tobytes() == ref["cloud"].tobytes()
+    assert np.array_equal(got["offsets"], ref["offsets"]) and np.array_equal(got["indices"], ref["indices"])
+    c.close()
+
+
+def test_node_chain_edge_cases(capi, oracle):
+    c = capi.Context(50_000)
+    c.set_params(leaf=0.05, tol=0.12, min_cluster=5, max_cluster=20000, publish_clouds=1)
+    po, pc = occ_of(capi, oracle)
+    # nothing inside the box: empty all the way down (sor2.filter on an empty cloud gives an empty cloud)
+    far = synth.uniform_field(5000, 3) + f32(100.0)
+    got = c.process_node(far, occ=pc, mean_k=15, stddev_mul=1.0)
+    assert got["n_filtered"] == 0 and got["n_voxels"] == 0 and got["n_inliers"] == 0 and len(got["offsets"]) == 1
+    # fewer voxels than mean_k + 1: refused, as pcop_statistical_outlier_removal refuses it
+    few = synth.uniform_field(8, 4)
+    with pytest.raises(capi.PcopError) as e:
+        c.process_node(few, mean_k=15, stddev_mul=1.0)
+    assert e.value.status == -2
+    # and the context still works
+    pts = field_cloud(40_000, 5)
+    ref = oracle_chain(oracle, pts, po, 0.05, 15, 1.0, 0.12, 5, 20000)
+    got = c.process_node(pts, occ=pc, mean_k=15, stddev_mul=1.0)
+    assert got["voxel_xyz"].tobytes() == ref["cloud"].tobytes() and np.array_equal(got["indices"], ref["indices"])
+    c.close()
