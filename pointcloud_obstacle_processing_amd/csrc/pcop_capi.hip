@@ -274,9 +274,13 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
                 else k_bin_scatter<8, false><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr);
             }
             mark(c, "k_bin_scatter");
-            if (c->lds_ordered) k_bucket_reduce<true><<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
-            else k_bucket_reduce<false><<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
+            if (c->lds_ordered) k_bucket_reduce<true><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
+            else k_bucket_reduce<false><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_bucket_reduce");
+            k_bucket_scan<<<dim3(1, nf), kBinThreads, 0, s>>>(fr);
+            mark(c, "k_bucket_scan");
+            k_voxel_gather<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);   // (also marks the grid cells of a chain frame: see marks_cells below)
+            mark(c, "k_voxel_gather");
         } else {
             for (uint32_t p = 0; p < c->npass_voxel; ++p) {
                 k_radix_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
@@ -303,8 +307,13 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
                 k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, 2u | 4u);
                 mark(c, "k_voxel_setup");
             }
-            k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
-            mark(c, "k_cell_mark");
+            // a chain frame on the streaming voxel path has its cells marked by k_voxel_gather (same launch sequence, grid
+            // set up before the voxel stage)
+            const bool marks_cells = kind == kFrameChain && (parts & kPartVoxel) && stream_on(c) && !(parts & kPartOwnGridSetup);
+            if (!marks_cells) {
+                k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
+                mark(c, "k_cell_mark");
+            }
             k_occ_scan<<<dim3(c->ctiles, nf), kBlock, 0, s>>>(fr);
             mark(c, "k_cmap_scan");
             k_cell_count<<<tg, kBlock, 0, s>>>(fr);
@@ -676,6 +685,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         TRY(dev_alloc(c, &f.tcnt, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.tbase, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.bucket_pub, (size_t)kNbMax));
+        TRY(dev_alloc(c, &f.vbase, (size_t)kNbMax + 1));
     }
     TRY(host_alloc(c, &sl.h_args, 1));
     TRY(host_alloc(c, &sl.h_state, 1));

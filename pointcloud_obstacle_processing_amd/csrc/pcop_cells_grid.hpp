@@ -62,6 +62,35 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_setup(Frame* frames) {
     cgrid_setup_block(F, F.st.c_n, F.st.c_n == 0u);
 }
 
+// Grid position of a point of the cell stage; its cell's flag byte set.  0 (and an error bit) for a point the grid cannot take.
+struct CellMarker {
+    double ig;
+    long long c0x, c0y, c0z, d0, d1, d2;
+    uint32_t rowbits, plane;
+    __device__ __forceinline__ void init(const DevState* st) {
+        ig = st->inv_cell;
+        c0x = st->c0[0]; c0y = st->c0[1]; c0z = st->c0[2];
+        d0 = st->c_dim[0]; d1 = st->c_dim[1]; d2 = st->c_dim[2];
+        rowbits = st->c_rowbits; plane = st->c_plane;
+    }
+    __device__ __forceinline__ uint32_t operator()(DevState* st, uint8_t* __restrict__ cflag, float px, float py, float pz) const {
+        if (!finite3(px, py, pz)) {   // radiusSearch on a non-finite point is undefined in PCL
+            atomicOr(&st->err, (uint32_t)kErrNonFinite);
+            return 0u;
+        }
+        const long long gx = (long long)floor((double)px * ig) - c0x, gy = (long long)floor((double)py * ig) - c0y,
+                        gz = (long long)floor((double)pz * ig) - c0z;
+        // two free cells on every side keep the whole 5x5x5 stencil inside the array
+        if (gx < 2 || gy < 2 || gz < 2 || gx > d0 - 3 || gy > d1 - 3 || gz > d2 - 3) {
+            atomicOr(&st->err, (uint32_t)kErrReplanCpath);
+            return 0u;
+        }
+        const uint32_t pos = (uint32_t)gz * plane + (uint32_t)gy * rowbits + (uint32_t)gx;
+        cflag[pos] = 1;
+        return pos;
+    }
+};
+
 __global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
@@ -73,27 +102,41 @@ __global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
     const float* __restrict__ y = from_in ? st->src_y.get() : cen_y;
     const float* __restrict__ z = from_in ? st->src_z.get() : cen_z;
     const uint32_t n = st->c_n;
-    const double ig = st->inv_cell;
-    const long long c0x = st->c0[0], c0y = st->c0[1], c0z = st->c0[2];
-    const long long d0 = st->c_dim[0], d1 = st->c_dim[1], d2 = st->c_dim[2];
-    const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float px = x[i], py = y[i], pz = z[i];
-        uint32_t pos = 0;
-        if (!finite3(px, py, pz)) {   // radiusSearch on a non-finite point is undefined in PCL
-            atomicOr(&st->err, (uint32_t)kErrNonFinite);
-        } else {
-            const long long gx = (long long)floor((double)px * ig) - c0x, gy = (long long)floor((double)py * ig) - c0y,
-                            gz = (long long)floor((double)pz * ig) - c0z;
-            // two free cells on every side keep the whole 5x5x5 stencil inside the array
-            if (gx < 2 || gy < 2 || gz < 2 || gx > d0 - 3 || gy > d1 - 3 || gz > d2 - 3) {
-                atomicOr(&st->err, (uint32_t)kErrReplanCpath);
-            } else {
-                pos = (uint32_t)gz * plane + (uint32_t)gy * rowbits + (uint32_t)gx;
-                cflag[pos] = 1;
-            }
+    CellMarker mark; mark.init(st);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
+}
+
+// End of the streaming voxel path and start of the cell stage in one pass over the voxels: the centroids k_bucket_reduce left
+// at their buckets' places go to their ranks (output order = voxel key order), and each marks its grid cell on the way,
+// so the chain has no k_cell_mark launch.  One block per bucket.  A frame the voxel grid passed through (or gave no voxels)
+// has no buckets: its cell stage sees the input cloud, marked here by all blocks together.
+__global__ __launch_bounds__(kBlock) void k_voxel_gather(Frame* frames) {
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
+    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
+    if (st->err || st->kind == kFrameClusterOnly) return;
+    const bool cells = !cgrid_off(st);
+    CellMarker mark;
+    if (cells) mark.init(st);
+    if (st->vpath && st->n_valid && !st->passthrough) {
+        const uint32_t b = blockIdx.x;
+        if (b >= st->nbuckets) return;
+        const float4* __restrict__ scratch = F.rec_b;
+        const uint32_t first = F.binfo[b].x, nvox = F.bucket_pub[b], base = F.vbase[b];
+        for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
+            const float4 p = scratch[first + v];
+            const uint32_t i = base + v;
+            cx[i] = p.x; cy[i] = p.y; cz[i] = p.z;
+            if (cells) pt_pos[i] = mark(st, cflag, p.x, p.y, p.z);
         }
-        pt_pos[i] = pos;
+    } else if (cells) {
+        const bool from_in = st->c_from_input != 0;
+        const float* __restrict__ x = from_in ? st->src_x.get() : cx;
+        const float* __restrict__ y = from_in ? st->src_y.get() : cy;
+        const float* __restrict__ z = from_in ? st->src_z.get() : cz;
+        const uint32_t n = st->c_n;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
     }
 }
 

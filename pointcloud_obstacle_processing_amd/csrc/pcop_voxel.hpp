@@ -566,6 +566,7 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 // after its sums are done; a lower tile never waits for a higher one and blocks are dispatched in
 // index order, so the lower tiles are always running or finished (the wait is bounded anyway).
 constexpr uint32_t kSpinLimit = 1u << 24;
+constexpr uint32_t kReduceBucketsPerBlock = 2u;   // k_bucket_reduce: consecutive buckets per block
 
 __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t npass) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
@@ -1255,6 +1256,7 @@ template <bool ORDERED>   // as in k_bin_scatter
 __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     constexpr uint32_t NW = kBlock / kWave;                    // 4 waves; a wave ranks 512 consecutive points of the bucket
     constexpr uint32_t kItemsB = kBucketCap / kBlock;          // 8
+    constexpr uint32_t kBucketsPerBlock = kReduceBucketsPerBlock;
     constexpr uint32_t kMapWords = kBucketCells / 32u;         // 4096
     constexpr uint32_t kPerW = kMapWords / kBlock;             // at most 16 occupancy words per thread
     constexpr uint32_t kPlane = kBucketCap + kBucketCap / 32u + 8u;   // a staged coordinate plane: slot s lives at s + (s >> 5)
@@ -1270,33 +1272,47 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     const uint4* __restrict__ binfo = F.binfo;
     const Rec3* __restrict__ recs = reinterpret_cast<const Rec3*>(F.rec_a.get());
     uint32_t* __restrict__ bucket_pub = F.bucket_pub;
-    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
+    float4* __restrict__ scratch = F.rec_b;
     if (stream_off(st)) return;
-    const uint32_t b = blockIdx.x, nb = st->nbuckets;
-    if (b >= nb) return;
-    const uint4 info = binfo[b];   // {first record, records, first key, keys spanned}
-    const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
+    const uint32_t nb = st->nbuckets;
+    if (blockIdx.x * kBucketsPerBlock >= nb) return;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(s_mem);
     uint16_t* wpre = reinterpret_cast<uint16_t*>(s_mem + kMapWords * 4u);
     float* stage_x = reinterpret_cast<float*>(s_mem); float* stage_y = stage_x + kPlane; float* stage_z = stage_y + kPlane;
+    const uint32_t w = threadIdx.x / kWave, lane = lane_id();
+    VoxelKey key; key.init(st);
+    const uint32_t pbase = w * (kItemsB * kWave) + lane;   // position in the bucket = index order
+    // A block takes kBucketsPerBlock consecutive buckets, one after the other; the records of the next one are requested
+    // before the current one is worked on, so only the first bucket's load latency is exposed.
+    Rec3 rec[kItemsB], recn[kItemsB];
+    uint4 info_n = binfo[blockIdx.x * kBucketsPerBlock];
+    auto request = [&](Rec3* r, const uint4& inf) {
+        const uint32_t lastr = inf.y ? min(inf.y, kBucketCap) - 1u : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < kItemsB; ++j) r[j] = recs[inf.x + min(pbase + j * kWave, lastr)];   // clamped, unconditional
+    };
+    request(recn, info_n);
+    for (uint32_t it = 0; it < kBucketsPerBlock; ++it) {
+    const uint32_t b = blockIdx.x * kBucketsPerBlock + it;
+    if (b >= nb) break;
+    const uint4 info = info_n;   // {first record, records, first key, keys spanned}
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) rec[j] = recn[j];
+    if (it + 1u < kBucketsPerBlock && b + 1u < nb) { info_n = binfo[b + 1u]; request(recn, info_n); }
+    const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
     // A bucket that spans at most kBucketCap cells sorts by the cell itself (ids of empty cells get empty runs);
     // a wider one first ranks its occupied cells through an occupancy map, so that ids stay below the point count.
     const bool direct = span <= kBucketCap;
     const uint32_t words = (span + 31u) / 32u;
     bool bad = cnt == 0u || cnt > kBucketCap || span > kBucketCells;   // never: k_bin_plan keeps both limits
-    const uint32_t w = threadIdx.x / kWave, lane = lane_id();
-    VoxelKey key; key.init(st);
-    Rec3 rec[kItemsB];
     uint32_t lk[kItemsB], id[kItemsB], rank[kItemsB];
     bool act[kItemsB];
-    const uint32_t pbase = w * (kItemsB * kWave) + lane;   // position in the bucket = index order
-    PCOP_STAMP(F, 2, 0, 300);
-    const uint32_t last = bad ? 0u : cnt - 1u;
-#pragma unroll
-    for (uint32_t j = 0; j < kItemsB; ++j) rec[j] = recs[info.x + min(pbase + j * kWave, last)];
+    PCOP_STAMP(F, 2, 0, 150);
     // (the LDS is cleared while the records are on their way)
     if (!direct) for (uint32_t i = threadIdx.x; i < min(words, kMapWords); i += kBlock) bitmap[i] = 0u;
-    for (uint32_t i = threadIdx.x; i < 2u * kBucketCap / 4u; i += kBlock) reinterpret_cast<uint4*>(s_wc)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // ids stay below nidr (the cells spanned, or the points, rounded up to a multiple of the block): the per-id steps stop there
+    const uint32_t nidr = min(kBucketCap, ((direct ? span : cnt) + kBlock - 1u) / kBlock * kBlock);
+    for (uint32_t v = threadIdx.x; v < nidr; v += kBlock) { s_wc[v] = 0u; s_wc[kBucketCap + v] = 0u; }
     if (!ORDERED) for (uint32_t i = threadIdx.x; i < NW * 96u; i += kBlock) s_match[i] = 0ull;
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
@@ -1306,17 +1322,17 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
         id[j] = act[j] ? lk[j] : 0u;
     }
     bad = __syncthreads_or(bad ? 1 : 0) != 0;
-    PCOP_STAMP(F, 2, 1, 300);
+    PCOP_STAMP(F, 2, 1, 150);
     if (bad) {   // publish "present, no voxels", so that the higher buckets do not wait
-        if (threadIdx.x == 0) { atomicOr(&st->err, (uint32_t)kErrInternal); st_agent(bucket_pub + b, 1u); }
-        return;
+        if (threadIdx.x == 0) { atomicOr(&st->err, (uint32_t)kErrInternal); bucket_pub[b] = 0u; }
+        continue;
     }
     if (!direct) {
 #pragma unroll
         for (uint32_t j = 0; j < kItemsB; ++j)
             if (act[j]) atomicOr(&bitmap[lk[j] >> 5], 1u << (lk[j] & 31u));
         __syncthreads();
-    PCOP_STAMP(F, 2, 2, 300);
+    PCOP_STAMP(F, 2, 2, 150);
         // running count of the occupied cells: thread t owns the perw consecutive words from t * perw
         const uint32_t perw = (words + kBlock - 1u) / kBlock;   // 1 .. 16
         uint32_t wv[kPerW];
@@ -1336,14 +1352,14 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
             run += __popc(wv[k]);
         }
         __syncthreads();
-    PCOP_STAMP(F, 2, 3, 300);
+    PCOP_STAMP(F, 2, 3, 150);
 #pragma unroll
         for (uint32_t j = 0; j < kItemsB; ++j) {   // id = occupied cells of the bucket before this one
             const uint32_t wi = act[j] ? lk[j] >> 5 : 0u;
             id[j] = (uint32_t)wpre[wi] + __popc(bitmap[wi] & ((1u << (lk[j] & 31u)) - 1u));
         }
         __syncthreads();   // the occupancy words are done with: the staging area may be written from here on
-    PCOP_STAMP(F, 2, 4, 300);
+    PCOP_STAMP(F, 2, 4, 150);
     }
     // ranks inside (wave, id)
     const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
@@ -1370,20 +1386,21 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     }
     }
     __syncthreads();
-    PCOP_STAMP(F, 2, 5, 300);
+    PCOP_STAMP(F, 2, 5, 150);
     // points per id (a thread takes ids t, t + 256, ...: neighbouring words), then run starts and ranks of the occupied ids
     // (thread t owns ids t * 8 .. t * 8 + 7: one 16-byte access each way)
 #pragma unroll
     for (uint32_t k = 0; k < kItemsB; ++k) {
+        if (k * kBlock >= nidr) break;
         const uint32_t v = k * kBlock + threadIdx.x;
         const uint32_t a = s_wc[v], q = s_wc[kBucketCap + v];
         s_run[v] = (uint16_t)((a & 0xFFFFu) + (a >> 16) + (q & 0xFFFFu) + (q >> 16));
     }
     __syncthreads();
-    PCOP_STAMP(F, 2, 6, 300);
+    PCOP_STAMP(F, 2, 6, 150);
     uint4* run4 = reinterpret_cast<uint4*>(s_run) + threadIdx.x;
     uint4* vr4 = reinterpret_cast<uint4*>(s_vr) + threadIdx.x;
-    const uint4 t4 = *run4;
+    const uint4 t4 = threadIdx.x * kItemsB < nidr ? *run4 : make_uint4(0u, 0u, 0u, 0u);   // (beyond nidr: no ids, stale words)
     const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
     uint32_t tsum = 0u;   // low half: points, high half: occupied ids
 #pragma unroll
@@ -1394,7 +1411,7 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     uint32_t ttot;
     uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
     const uint32_t nvox = ttot >> 16;
-    if (threadIdx.x == 0) st_agent(bucket_pub + b, nvox + 1u);   // publish: the higher buckets add this up
+    if (threadIdx.x == 0) bucket_pub[b] = nvox;   // k_bucket_scan turns the counts into output ranks
     {
         uint32_t ro[4], vo[4];
 #pragma unroll
@@ -1409,7 +1426,7 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     }
     if (threadIdx.x == 0) s_run[kBucketCap] = (uint16_t)(ttot & 0xFFFFu);
     __syncthreads();
-    PCOP_STAMP(F, 2, 7, 300);
+    PCOP_STAMP(F, 2, 7, 150);
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
         if (act[j]) {
@@ -1425,14 +1442,14 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
         }
     }
     __syncthreads();
-    PCOP_STAMP(F, 2, 8, 300);
-    // one lane per id: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count)
-    float ox[kItemsB], oy[kItemsB], oz[kItemsB];
-    uint32_t ov[kItemsB];
+    PCOP_STAMP(F, 2, 8, 150);
+    // one lane per id: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count).  The centroid
+    // of the bucket's v-th voxel goes to place (first record of the bucket + v) of the scratch records: a bucket has at
+    // least as many records as voxels, so the places of different buckets do not meet; k_voxel_gather moves them to their ranks.
 #pragma unroll
     for (uint32_t k = 0; k < kItemsB; ++k) {
+        if (k * kBlock >= nidr) break;
         const uint32_t v = k * kBlock + threadIdx.x;
-        ox[k] = oy[k] = oz[k] = 0.0f; ov[k] = 0xFFFFFFFFu;
         const uint32_t s0 = s_run[v], e0 = s_run[v + 1u];
         if (e0 > s0) {
             float sx = 0.0f, sy = 0.0f, sz = 0.0f;
@@ -1444,30 +1461,33 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
                 for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
             }
             const float fc = (float)(e0 - s0);
-            ox[k] = sx / fc; oy[k] = sy / fc; oz[k] = sz / fc;
-            ov[k] = s_vr[v];
+            scratch[info.x + s_vr[v]] = make_float4(sx / fc, sy / fc, sz / fc, 0.0f);
         }
     }
-    PCOP_STAMP(F, 2, 20, 300);
-    // voxels of the lower buckets (published before their sums, so they are usually there by now; the wait is bounded)
-    uint32_t lower = 0u;
-    for (uint32_t t = threadIdx.x; t < b; t += kBlock) {
-        uint32_t v = ld_agent(bucket_pub + t), spins = 0u;
-        while (v == 0u) {
-            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
-            __builtin_amdgcn_s_sleep(2);
-            v = ld_agent(bucket_pub + t);
-        }
-        lower += v - 1u;
+    PCOP_STAMP(F, 2, 20, 150);
+    __syncthreads();   // the next bucket clears and fills the same LDS
     }
-    __syncthreads();   // s_w is reused
-    PCOP_STAMP(F, 2, 9, 300);
-    const uint32_t before = block_sum(lower, s_w);
-    if (threadIdx.x == 0 && b + 1u == nb) finish_voxel(st, before + nvox);   // the last bucket knows M
+}
+
+// Output rank of every bucket's first voxel (exclusive scan of the buckets' voxel counts), and M.  One block per frame.
+__global__ __launch_bounds__(kBinThreads) void k_bucket_scan(Frame* frames) {
+    constexpr int NW = kBinThreads / kWave;
+    constexpr uint32_t kPer = kNbMax / kBinThreads;   // 4 consecutive buckets per thread
+    __shared__ uint32_t s_w[NW];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    const uint32_t* __restrict__ bucket_pub = F.bucket_pub;
+    uint32_t* __restrict__ vbase = F.vbase;
+    if (stream_off(st)) return;
+    const uint32_t nb = st->nbuckets;
+    uint32_t v[kPer], sum = 0u;
 #pragma unroll
-    for (uint32_t k = 0; k < kItemsB; ++k)
-        if (ov[k] != 0xFFFFFFFFu) { cx[before + ov[k]] = ox[k]; cy[before + ov[k]] = oy[k]; cz[before + ov[k]] = oz[k]; }
-    PCOP_STAMP(F, 2, 21, 300);
+    for (uint32_t k = 0; k < kPer; ++k) { const uint32_t b = threadIdx.x * kPer + k; v[k] = b < nb ? bucket_pub[min(b, kNbMax - 1u)] : 0u; sum += v[k]; }
+    uint32_t m;
+    uint32_t run = block_excl_scan_n<NW>(sum, s_w, &m);
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) { const uint32_t b = threadIdx.x * kPer + k; if (b < nb) vbase[b] = run; run += v[k]; }
+    if (threadIdx.x == 0) finish_voxel(st, m);
 }
 
 // ------------------------------------------------------------------------------------------
