@@ -212,30 +212,57 @@ int pcop_process_filtered(pcop_ctx* ctx, pcop_result* out);
 int pcop_statistical_outlier_removal(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int mean_k, float stddev_mul,
                                      float* out_xyz, size_t* n_out, float* distances, double* threshold);
 
+/* ---- RANSAC plane removal --------------------------------------------------------------------
+ * Replaces segment_plane_and_extract_indices (od.cpp:342-428, called at od.cpp:778-781): pcl::SACSegmentation with
+ * SACMODEL_PERPENDICULAR_PLANE, SAC_RANSAC, optimised coefficients, PCL's defaults (50 iterations, probability 0.99, the
+ * fixed seed of a non-random model) inside "while more than 30 % of the cloud is left: find a plane, stop if none, keep the
+ * points outside it" with pcl::ExtractIndices.  The GPU counts the inliers of all candidate planes of a round in one pass
+ * and splits the cloud; the sampling, the plane through three points and the least-squares refit are sequential by nature
+ * and run on the host, in the reference's order of float operations.
+ *   dist_thresh  plane_segment_dist_thres (od.cpp:110, 969)   axis  (0, 0, 1) in the node (od.cpp:768)
+ *   eps_angle    plane_segment_angle as the node passes it: an int that PCL reads as radians (od.cpp:111, 371, 970) */
+typedef struct pcop_plane_params {
+    float  dist_thresh;
+    float  axis[3];
+    double eps_angle;
+} pcop_plane_params;
+/* Stage form (host memory in and out, like the reference's function): out_xyz receives what is left (layout of the input,
+ * room for n points), last_plane_xyz (may be NULL; same layout, room for n points) the points of the last plane removed
+ * ("indices_cloud" in the reference), coeffs (may be NULL, room for 4 * cap_planes floats) the refined coefficients of
+ * every plane removed, *n_planes their number, *found_all 0 when a round found no plane (the node prints "Couldn't
+ * estimate a planar model" and leaves the loop). */
+int pcop_segment_planes(pcop_ctx* ctx, const float* xyz, int layout, size_t n, const pcop_plane_params* p,
+                        float* out_xyz, size_t* n_out, float* last_plane_xyz, size_t* n_last_plane,
+                        float* coeffs, int32_t cap_planes, int32_t* n_planes, int32_t* found_all);
+
 /* ---- the node's chain in one call, nothing but results leaving HBM (od.cpp:727-797) -----------------------------
  * build_initial_occupancy_grid_dataset (od.cpp:727-731) -> downsample_cloud (740-741) -> remove_statistical_outliers
- * (751-754) -> kd-tree + extract_euclidian_clusters (791-797), in the node's order.  (The plane removal of od.cpp:778-781
- * sits between the last two in the node; it is not part of this call.)
+ * (751-754) -> segment_plane_and_extract_indices (778-781) -> kd-tree + extract_euclidian_clusters (791-797), in the
+ * node's order.
  *   occ      NULL: no bounds filter / occupancy binning, the chain starts at the voxel grid.  Otherwise as in
  *            pcop_occupancy_filter; counts / row_avg / grid (each may be NULL) receive its grid outputs.
  *   mean_k   0: no outlier removal.  Otherwise as in pcop_statistical_outlier_removal, applied to the voxel cloud.
+ *   plane    NULL: no plane removal.  Otherwise as in pcop_segment_planes, applied to what the outlier removal kept.
  * The kept cloud of every step stays on the device; the point counts flow through device memory.  With outlier removal
  * the call synchronises once in the middle: the n mean neighbour distances go to the host, which forms the two
- * sequential double sums of the reference (a parallel sum would round differently) and hands back the threshold.
- * out->voxel_xyz / num_voxels describe the cloud the cluster indices refer to (the voxel cloud, or what the outlier
- * removal kept of it); stats (may be NULL) reports the point counts after every step. */
+ * sequential double sums of the reference (a parallel sum would round differently) and hands back the threshold; the
+ * plane removal synchronises once per candidate-plane count (its sampling and refit are the host's).
+ * out->voxel_xyz / num_voxels describe the cloud the cluster indices refer to (the voxel cloud, or what the later steps
+ * kept of it); stats (may be NULL) reports the point counts after every step. */
 typedef struct pcop_node_stats {
     int32_t n_in;          /* points handed in                                   */
     int32_t n_filtered;    /* points inside the box (== n_in without occ)         */
     int32_t index_errors;  /* as in pcop_occupancy_filter                         */
     int32_t n_voxels;      /* voxel grid output                                   */
     int32_t n_inliers;     /* after the outlier removal (== n_voxels without it)  */
-    int32_t reserved;
+    int32_t n_planes;      /* planes removed                                      */
+    int32_t n_clustered;   /* points that entered the clustering                  */
+    int32_t planes_found_all; /* 0: a round of the plane removal found no plane   */
     double  threshold;     /* mean + stddev_mul * sigma (0 without outlier removal) */
 } pcop_node_stats;
 int pcop_process_node(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int is_dense, int mem,
                       const pcop_occ_params* occ, int64_t* counts, int64_t* row_avg, int8_t* grid,
-                      int mean_k, float stddev_mul, pcop_result* out, pcop_node_stats* stats);
+                      int mean_k, float stddev_mul, const pcop_plane_params* plane, pcop_result* out, pcop_node_stats* stats);
 
 /* Device-side allocation helpers so a host program without its own HIP code
  * (e.g. a ctypes caller) can keep clouds resident in HBM. */

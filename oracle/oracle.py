@@ -1,5 +1,6 @@
 """ctypes front-end of the CPU oracle (oracle/pcl_restatement.cpp: voxel grid, radius graph, clusters;
-oracle/occupancy_restatement.cpp: bounds filter + occupancy binning; oracle/sor_restatement.cpp: statistical outlier removal).
+oracle/occupancy_restatement.cpp: bounds filter + occupancy binning; oracle/sor_restatement.cpp: statistical outlier removal;
+oracle/plane_restatement.cpp: RANSAC plane removal).
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg.  The product package never imports this module.
@@ -20,7 +21,7 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle with g++ (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pcl_restatement.cpp", "occupancy_restatement.cpp", "sor_restatement.cpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("pcl_restatement.cpp", "occupancy_restatement.cpp", "sor_restatement.cpp", "plane_restatement.cpp")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpcop_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -67,6 +68,11 @@ def lib():
         L.pcop_oracle_sor.restype = C.c_int
         L.pcop_oracle_sor.argtypes = [fp, C.c_size_t, C.c_int, C.c_float, fp, C.POINTER(C.c_double), C.POINTER(C.c_uint8),
                                       C.POINTER(C.c_size_t)]
+        L.pcop_oracle_segment_planes.restype = C.c_int
+        L.pcop_oracle_segment_planes.argtypes = [fp, C.c_size_t, C.c_float, fp, C.c_double, fp, C.POINTER(C.c_size_t), fp,
+                                                 C.POINTER(C.c_size_t), fp, C.c_int, ip, ip]
+        L.pcop_oracle_plane_rnd.restype = None
+        L.pcop_oracle_plane_rnd.argtypes = [ip, C.c_int]
         _lib = L
     return _lib
 
@@ -232,6 +238,30 @@ def process_xyz(xyz, leaf, tol, min_cluster, max_cluster, is_dense=True, layout=
         raise ValueError("oracle process_xyz rc=%d" % rc)
     return dict(voxel_xyz=vox[: 3 * m.value].reshape(-1, 3).copy(), passthrough=bool(pt.value),
                 offsets=offsets[: k.value + 1].copy(), indices=indices[: offsets[k.value]].copy())
+
+
+def segment_planes(xyz, dist_thresh, axis=(0.0, 0.0, 1.0), eps_angle=20.0, max_planes=64):
+    """segment_plane_and_extract_indices (od.cpp:342-428) -> dict(xyz what is left, last_plane its last plane's points,
+    coeffs (planes, 4) refined coefficients, iterations RANSAC iterations per plane, found_all False when a round found no plane)."""
+    pts = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    n = len(pts)
+    out = np.zeros(max(3 * n, 3), dtype=np.float32)
+    last = np.zeros(max(3 * n, 3), dtype=np.float32)
+    coeffs = np.zeros((max_planes, 4), dtype=np.float32)
+    its = np.zeros(max_planes, dtype=np.int32)
+    ax = np.asarray(axis, dtype=np.float32)
+    n_out, n_last, n_planes = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+    rc = lib().pcop_oracle_segment_planes(_f(pts), n, np.float32(dist_thresh), _f(ax), float(eps_angle), _f(out), C.byref(n_out),
+                                          _f(last), C.byref(n_last), _f(coeffs), max_planes, C.byref(n_planes), _i(its))
+    k = min(n_planes.value, max_planes)
+    return dict(xyz=out[:3 * n_out.value].reshape(-1, 3).copy(), last_plane=last[:3 * n_last.value].reshape(-1, 3).copy(),
+                coeffs=coeffs[:k].copy(), iterations=its[:k].copy(), n_planes=n_planes.value, found_all=rc == 0)
+
+
+def plane_rnd(count):
+    out = np.zeros(count, dtype=np.int32)
+    lib().pcop_oracle_plane_rnd(_i(out), count)
+    return out
 
 
 def sor(xyz, mean_k, stddev_mul):

@@ -20,7 +20,7 @@ EXPORTS = [
     "pcop_set_profiling", "pcop_get_stage_times", "pcop_stream", "pcop_voxel_downsample", "pcop_euclidean_clusters",
     "pcop_process_pointcloud2", "pcop_process_xyz", "pcop_submit_xyz", "pcop_wait", "pcop_cluster_summaries",
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
-    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
+    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_segment_planes", "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
     "pcop_cluster_summaries_frame", "pcop_occupancy_grid_dims", "pcop_occupancy_filter", "pcop_process_filtered",
     "pcop_statistical_outlier_removal",
 ]
@@ -52,7 +52,17 @@ class Result(C.Structure):
 
 class NodeStats(C.Structure):
     _fields_ = [("n_in", C.c_int32), ("n_filtered", C.c_int32), ("index_errors", C.c_int32), ("n_voxels", C.c_int32),
-                ("n_inliers", C.c_int32), ("reserved", C.c_int32), ("threshold", C.c_double)]
+                ("n_inliers", C.c_int32), ("n_planes", C.c_int32), ("n_clustered", C.c_int32), ("planes_found_all", C.c_int32),
+                ("threshold", C.c_double)]
+
+
+class PlaneParams(C.Structure):
+    """pcop_plane_params: distance threshold, axis and angle of the RANSAC plane removal (od.cpp:110-111, 768)."""
+    _fields_ = [("dist_thresh", C.c_float), ("axis", C.c_float * 3), ("eps_angle", C.c_double)]
+
+
+def plane_params(dist_thresh, axis=(0.0, 0.0, 1.0), eps_angle=20.0):
+    return PlaneParams(np.float32(dist_thresh), (C.c_float * 3)(*[float(a) for a in axis]), float(eps_angle))
 
 
 class StageTimes(C.Structure):
@@ -114,7 +124,10 @@ def load_library():
     L.pcop_cluster_cloud.argtypes = [vp, C.c_int, C.POINTER(fp), ip]
     L.pcop_process_node.restype = C.c_int
     L.pcop_process_node.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_int, C.c_float, C.POINTER(Result), C.POINTER(NodeStats)]
+                                    C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.POINTER(Result), C.POINTER(NodeStats)]
+    L.pcop_segment_planes.restype = C.c_int
+    L.pcop_segment_planes.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(PlaneParams), C.c_void_p, C.POINTER(C.c_size_t),
+                                      C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_int32, ip, ip]
     L.pcop_occupancy_grid_dims.restype = None
     L.pcop_occupancy_grid_dims.argtypes = [C.c_float] * 5 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.pcop_occupancy_filter.restype = C.c_int
@@ -323,10 +336,23 @@ class Context:
                                                             out.ctypes.data, C.byref(n_out), dist.ctypes.data, C.byref(thr)))
         return dict(xyz=unpack_points(out, layout, n_out.value, n), distances=dist[:n], threshold=thr.value)
 
-    def process_node(self, xyz, occ=None, mean_k=0, stddev_mul=1.0, is_dense=True, layout=LAYOUT_AOS12, dev_ptr=None, n=None,
-                     want_grid=False):
+    def segment_planes(self, xyz, plane, layout=LAYOUT_AOS12, cap_planes=64):
+        """segment_plane_and_extract_indices -> dict(xyz what is left, coeffs (planes, 4), n_planes, found_all)."""
+        flat, n = pack_points(xyz, layout)
+        out = np.zeros_like(flat) if n else np.zeros(3, dtype=np.float32)
+        last = np.zeros_like(out)
+        coeffs = np.zeros((cap_planes, 4), dtype=np.float32)
+        n_out, n_last, n_planes, found = C.c_size_t(0), C.c_size_t(0), C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.pcop_segment_planes(self.h, flat.ctypes.data, layout, n, C.byref(plane), out.ctypes.data, C.byref(n_out),
+                                               last.ctypes.data, C.byref(n_last), coeffs.ctypes.data, cap_planes, C.byref(n_planes),
+                                               C.byref(found)))
+        return dict(xyz=unpack_points(out, layout, n_out.value, n), last_plane=unpack_points(last, layout, n_last.value, n),
+                    coeffs=coeffs[:min(n_planes.value, cap_planes)].copy(), n_planes=n_planes.value, found_all=bool(found.value))
+
+    def process_node(self, xyz, occ=None, mean_k=0, stddev_mul=1.0, plane=None, is_dense=True, layout=LAYOUT_AOS12, dev_ptr=None,
+                     n=None, want_grid=False):
         """The node's chain in one call (od.cpp:727-797): [bounds filter + occupancy binning] -> voxel grid ->
-        [statistical outlier removal] -> clusters.  xyz: (n,3) host array, or dev_ptr/n for SoA planes already in HBM.
+        [statistical outlier removal] -> [RANSAC plane removal] -> clusters.  xyz: (n,3) host array, or dev_ptr/n for SoA planes already in HBM.
         -> dict of the frame result + stats (+ counts, row_avg, grid with want_grid)."""
         if dev_ptr is None:
             flat, n = pack_points(xyz, layout)
@@ -345,10 +371,11 @@ class Context:
                                              counts.ctypes.data if counts is not None else None,
                                              row_avg.ctypes.data if row_avg is not None else None,
                                              grid.ctypes.data if grid is not None else None,
-                                             int(mean_k), C.c_float(stddev_mul), C.byref(r), C.byref(st)))
+                                             int(mean_k), C.c_float(stddev_mul),
+                                             C.cast(C.byref(plane), C.c_void_p) if plane is not None else None, C.byref(r), C.byref(st)))
         out = self._result(r)
         out.update(n_filtered=st.n_filtered, index_errors=st.index_errors, n_voxels=st.n_voxels, n_inliers=st.n_inliers,
-                   threshold=st.threshold)
+                   n_planes=st.n_planes, n_clustered=st.n_clustered, planes_found_all=bool(st.planes_found_all), threshold=st.threshold)
         if counts is not None:
             out.update(counts=counts[:occ.grid_width * occ.grid_height], row_avg=row_avg[:occ.grid_height],
                        grid=grid[:occ.grid_width * occ.grid_height])

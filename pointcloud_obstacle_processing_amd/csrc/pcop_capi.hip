@@ -10,7 +10,9 @@
 #include "pcop_device.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -262,7 +264,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             mark(c, "k_bin_plan");
             k_bin_tilecnt<<<bt, kBlock, (bins + 8u) * 2u, s>>>(fr);
             mark(c, "k_bin_tilecnt");
-            k_bin_colscan<<<dim3(div_up(c->nb_cap, kBlock), nf), kBlock, 0, s>>>(fr);
+            k_bin_colscan<<<dim3(div_up(c->nb_cap, kWavesPerBlock), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_bin_colscan");
             if (c->lds_ordered) {
                 if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, true><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr);
@@ -591,6 +593,271 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         }
     }
     for (uint32_t f = 0; f < c->nframes; ++f) order_frame(c, c->slots[f], (out && f < nout) ? out + f : nullptr);
+    return PCOP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RANSAC plane removal, host side (the GPU passes are in pcop_planes.hpp).  What pcl::SACSegmentation does around its two
+// passes over the cloud is sequential and tiny: a fixed-seed generator picks three points, a plane goes through them, the
+// inliers of the best plane are refitted by least squares.  Same float operations, in the same order, as the reference's
+// libraries perform them (the open choices are listed with the CPU restatement, oracle/plane_restatement.cpp).
+// ---------------------------------------------------------------------------------------------------------------------
+struct PlaneRng {   // boost::mt19937 seeded with 12345u (SampleConsensusModel with random = false); rnd() = uniform_int<>(0, INT_MAX) = word / 2
+    uint32_t s[624];
+    int idx;
+    PlaneRng() {
+        s[0] = 12345u;
+        for (int i = 1; i < 624; ++i) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    int rnd() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; ++i) {
+                const uint32_t y = (s[i] & 0x80000000u) | (s[(i + 1) % 624] & 0x7FFFFFFFu);
+                s[i] = s[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = s[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
+        return (int)(y >> 1);
+    }
+};
+
+struct HostCloud {   // the cloud of the current round on the host: three planes of `n` floats
+    const float *x, *y, *z;
+    size_t n;
+};
+
+inline bool host_plane_within(const float c[4], float x, float y, float z, double thr) {
+    const float d = ((c[0] * x + c[1] * y) + c[2] * z) + c[3];
+    return std::fabs((double)d) < thr;
+}
+
+// SampleConsensusModelPlane::computeModelCoefficients (false: the three points are collinear by its test)
+bool plane_through(const HostCloud& h, const int smp[3], float c[4]) {
+    const float p0[3] = {h.x[smp[0]], h.y[smp[0]], h.z[smp[0]]}, p1[3] = {h.x[smp[1]], h.y[smp[1]], h.z[smp[1]]}, p2[3] = {h.x[smp[2]], h.y[smp[2]], h.z[smp[2]]};
+    const float ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2], bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
+    const float r0 = ax / bx, r1 = ay / by, r2 = az / bz;
+    if (r0 == r1 && r2 == r1) return false;
+    c[0] = ay * bz - az * by;
+    c[1] = az * bx - ax * bz;
+    c[2] = ax * by - ay * bx;
+    c[3] = 0.0f;
+    const float nrm = std::sqrt(((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]) + c[3] * c[3]);
+    c[0] /= nrm; c[1] /= nrm; c[2] /= nrm; c[3] /= nrm;
+    c[3] = -1.0f * (((c[0] * p0[0] + c[1] * p0[1]) + c[2] * p0[2]) + c[3] * 1.0f);
+    return true;
+}
+
+// SampleConsensusModelPerpendicularPlane::isModelValid
+bool plane_valid(const float c[4], const pcop_plane_params& p) {
+    if (!(p.eps_angle > 0.0)) return true;
+    const double d = (double)((c[0] * p.axis[0] + c[1] * p.axis[1]) + c[2] * p.axis[2]);
+    const double n1 = std::sqrt((double)((p.axis[0] * p.axis[0] + p.axis[1] * p.axis[1]) + p.axis[2] * p.axis[2]));
+    const double n2 = std::sqrt((double)((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]));
+    double rad = d / (n1 * n2);
+    if (rad < -1.0) rad = -1.0; else if (rad > 1.0) rad = 1.0;
+    double ang = std::fabs(std::acos(rad));
+    ang = std::min(ang, M_PI - ang);
+    return !(ang > p.eps_angle);
+}
+
+void plane_roots2(float b, float c, float r[3]) {   // pcl::computeRoots2
+    r[0] = 0.0f;
+    float d = b * b - 4.0f * c;
+    if (d < 0.0f) d = 0.0f;
+    const float sd = std::sqrt(d);
+    r[2] = 0.5f * (b + sd);
+    r[1] = 0.5f * (b - sd);
+}
+
+void plane_roots3(const float m[3][3], float r[3]) {   // pcl::computeRoots
+    const float c0 = m[0][0] * m[1][1] * m[2][2] + 2.0f * m[0][1] * m[0][2] * m[1][2] - m[0][0] * m[1][2] * m[1][2] -
+                     m[1][1] * m[0][2] * m[0][2] - m[2][2] * m[0][1] * m[0][1];
+    const float c1 = m[0][0] * m[1][1] - m[0][1] * m[0][1] + m[0][0] * m[2][2] - m[0][2] * m[0][2] + m[1][1] * m[2][2] - m[1][2] * m[1][2];
+    const float c2 = m[0][0] + m[1][1] + m[2][2];
+    if (std::fabs(c0) < std::numeric_limits<float>::epsilon()) { plane_roots2(c2, c1, r); return; }
+    const float inv3 = 1.0f / 3.0f, sqrt3 = std::sqrt(3.0f);
+    const float c2_3 = c2 * inv3;
+    float a_3 = (c1 - c2 * c2_3) * inv3;
+    if (a_3 > 0.0f) a_3 = 0.0f;
+    const float half_b = 0.5f * (c0 + c2_3 * (2.0f * c2_3 * c2_3 - c1));
+    float q = half_b * half_b + a_3 * a_3 * a_3;
+    if (q > 0.0f) q = 0.0f;
+    const float rho = std::sqrt(-a_3);
+    const float theta = std::atan2(std::sqrt(-q), half_b) * inv3;
+    const float ct = std::cos(theta), st = std::sin(theta);
+    r[0] = c2_3 + 2.0f * rho * ct;
+    r[1] = c2_3 - rho * (ct + sqrt3 * st);
+    r[2] = c2_3 - rho * (ct - sqrt3 * st);
+    if (r[0] >= r[1]) std::swap(r[0], r[1]);
+    if (r[1] >= r[2]) { std::swap(r[1], r[2]); if (r[0] >= r[1]) std::swap(r[0], r[1]); }
+    if (r[0] <= 0.0f) plane_roots2(c2, c1, r);
+}
+
+// SampleConsensusModelPlane::optimizeModelCoefficients over the inliers of `c_in` (in index order): nine sequential float
+// sums (computeMeanAndCovarianceMatrix), the eigenvector of the smallest eigenvalue (pcl::eigen33), d through the centroid.
+void plane_refit(const HostCloud& h, const float c_in[4], const pcop_plane_params& p, double thr, float c_out[4]) {
+    std::memcpy(c_out, c_in, 16);
+    if (!plane_valid(c_in, p)) return;
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t cnt = 0;
+    for (size_t i = 0; i < h.n; ++i) {
+        const float x = h.x[i], y = h.y[i], z = h.z[i];
+        if (!host_plane_within(c_in, x, y, z, thr)) continue;
+        acc[0] += x * x; acc[1] += x * y; acc[2] += x * z; acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
+        acc[6] += x; acc[7] += y; acc[8] += z;
+        ++cnt;
+    }
+    if (cnt <= 3) return;
+    const float fc = (float)cnt;
+    for (float& a : acc) a /= fc;
+    float m[3][3];
+    m[0][0] = acc[0] - acc[6] * acc[6]; m[0][1] = acc[1] - acc[6] * acc[7]; m[0][2] = acc[2] - acc[6] * acc[8];
+    m[1][1] = acc[3] - acc[7] * acc[7]; m[1][2] = acc[4] - acc[7] * acc[8]; m[2][2] = acc[5] - acc[8] * acc[8];
+    m[1][0] = m[0][1]; m[2][0] = m[0][2]; m[2][1] = m[1][2];
+    float scale = 0.0f;
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) scale = std::max(scale, std::fabs(m[a][b]));
+    if (scale <= std::numeric_limits<float>::min()) scale = 1.0f;
+    float sm[3][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) sm[a][b] = m[a][b] / scale;
+    float ev[3];
+    plane_roots3(sm, ev);
+    for (int a = 0; a < 3; ++a) sm[a][a] -= ev[0];
+    auto cross = [](const float u[3], const float v[3], float o[3]) { o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0]; };
+    float v1[3], v2[3], v3[3];
+    cross(sm[0], sm[1], v1); cross(sm[0], sm[2], v2); cross(sm[1], sm[2], v3);
+    auto sq = [](const float v[3]) { return (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]; };
+    const float l1 = sq(v1), l2 = sq(v2), l3 = sq(v3);
+    const float* best; float len;
+    if (l1 >= l2 && l1 >= l3) { best = v1; len = l1; } else if (l2 >= l1 && l2 >= l3) { best = v2; len = l2; } else { best = v3; len = l3; }
+    const float rl = std::sqrt(len);
+    float c[4] = {best[0] / rl, best[1] / rl, best[2] / rl, 0.0f};
+    c[3] = -1.0f * (((c[0] * acc[6] + c[1] * acc[7]) + c[2] * acc[8]) + 0.0f * 1.0f);
+    if (plane_valid(c, p)) std::memcpy(c_out, c, 16);
+}
+
+// The loop of segment_plane_and_extract_indices on a cloud that lives on the device (planes d[0..2], n points) with a copy on
+// the host (h: three planes in `hbuf`, compacted in place round by round).  Output planes alternate between the two scratch
+// plane sets `sa` and `sb` (each three device pointers; neither may be the input).  On return *dx.. point to the planes
+// that hold what is left and *n_left is its size.
+struct PlaneScratch { float* p[3]; };
+int plane_removal_loop(pcop_ctx* c, Slot& sl, const float* in_x, const float* in_y, const float* in_z, uint32_t n, float* hbuf,
+                       const pcop_plane_params& prm, PlaneScratch sa, PlaneScratch sb, const float** ox, const float** oy, const float** oz,
+                       uint32_t* n_left, std::vector<float>* coeffs, int32_t* found_all, std::vector<float>* last_plane = nullptr) {
+    const double thr = (double)prm.dist_thresh;   // setDistanceThreshold(double) from the node's float
+    const uint32_t nr_points = n;
+    const float *dx = in_x, *dy = in_y, *dz = in_z;
+    float *hx = hbuf, *hy = hbuf + n, *hz = hbuf + 2 * (size_t)n;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(hx, dx, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hy, dy, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hz, dz, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *found_all = 1;
+    uint32_t* d_counts = sl.f.bin_total.get();           // free outside a frame's partition passes: kPlaneModelsMax + 2 words used
+    uint32_t* d_tiles = sl.f.tile_a.get();
+    int round = 0;
+    while ((double)n > 0.3 * (double)nr_points) {
+        const HostCloud h{hx, hy, hz, n};
+        // the candidate planes of RandomSampleConsensus::computeModel, in the order the generator yields them
+        struct Event { bool model; float c[4]; };
+        std::vector<Event> events;
+        PlaneModels pm;
+        std::memset(&pm, 0, sizeof(pm));
+        if (n >= 3) {
+            PlaneRng gen;
+            std::vector<int> shuffled(n);
+            for (uint32_t i = 0; i < n; ++i) shuffled[i] = (int)i;
+            unsigned skipped = 0;
+            while (pm.count < 51u && skipped < 500u) {
+                int smp[3];
+                bool good = false;
+                for (unsigned it = 0; it < 1000 && !good; ++it) {   // getSamples: drawIndexSample until isSampleGood
+                    for (uint32_t i = 0; i < 3; ++i) std::swap(shuffled[i], shuffled[i + (uint32_t)(gen.rnd() % (int)(n - i))]);
+                    smp[0] = shuffled[0]; smp[1] = shuffled[1]; smp[2] = shuffled[2];
+                    const float r0 = (hx[smp[1]] - hx[smp[0]]) / (hx[smp[2]] - hx[smp[0]]), r1 = (hy[smp[1]] - hy[smp[0]]) / (hy[smp[2]] - hy[smp[0]]),
+                                r2 = (hz[smp[1]] - hz[smp[0]]) / (hz[smp[2]] - hz[smp[0]]);
+                    good = (r0 != r1) || (r2 != r1);
+                }
+                if (!good) break;
+                Event e;
+                e.model = plane_through(h, smp, e.c);
+                if (e.model) {
+                    std::memcpy(pm.c[pm.count], e.c, 16);
+                    pm.valid[pm.count] = plane_valid(e.c, prm) ? 1u : 0u;
+                    ++pm.count;
+                } else {
+                    ++skipped;
+                }
+                events.push_back(e);
+            }
+        }
+        // inlier counts of all of them in one pass over the cloud
+        std::vector<uint32_t> counts(kPlaneModelsMax, 0u);
+        if (pm.count) {
+            HIPCHK(c, hipMemsetAsync(d_counts, 0, kPlaneModelsMax * 4, c->stream));
+            k_plane_count<<<std::min(2048u, std::max(1u, div_up(n, kBlock))), kBlock, 0, c->stream>>>(dx, dy, dz, n, pm, thr, d_counts);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(counts.data(), d_counts, kPlaneModelsMax * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        // the loop itself, replayed: while (iterations_ < k && skipped_count < max_skip)
+        int iterations = 0, best_count = -INT_MAX;
+        double k = 1.0;
+        const double log_probability = std::log(1.0 - 0.99), one_over = 1.0 / (double)n;
+        unsigned skipped = 0;
+        bool have = false;
+        float best[4] = {0, 0, 0, 0};
+        uint32_t mi = 0;
+        for (size_t ei = 0; ei < events.size() && iterations < k && skipped < 500u; ++ei) {
+            if (!events[ei].model) { ++skipped; continue; }
+            const int cnt = (int)counts[mi++];
+            if (cnt > best_count) {
+                best_count = cnt; have = true; std::memcpy(best, events[ei].c, 16);
+                const double w = (double)cnt * one_over;
+                double p_no = 1.0 - std::pow(w, 3.0);
+                p_no = std::max(std::numeric_limits<double>::epsilon(), p_no); p_no = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no);
+                k = log_probability / std::log(p_no);
+            }
+            ++iterations;
+            if (iterations > 50) break;
+        }
+        if (!have) { *found_all = 0; break; }   // "Couldn't estimate a planar model for the given dataset."
+        float refined[4];
+        plane_refit(h, best, prm, thr, refined);
+        if (!plane_valid(refined, prm)) { *found_all = 0; break; }   // selectWithinDistance of an invalid model: no inliers
+        // ExtractIndices (negative) on the device; the same selection on the host copy
+        PlaneScratch& dst = (round & 1) ? sb : sa;
+        HIPCHK(c, hipMemsetAsync(d_tiles, 0, (size_t)div_up(n, kScanTile) * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d_counts, 0, 8, c->stream));
+        k_plane_split<<<div_up(n, kScanTile), kBlock, 0, c->stream>>>(dx, dy, dz, n, refined[0], refined[1], refined[2], refined[3], thr,
+                                                                      dst.p[0], dst.p[1], dst.p[2], d_tiles, d_counts, d_counts + 1);
+        HIPCHK(c, hipGetLastError());
+        uint32_t kept = 0;
+        if (last_plane) last_plane->clear();
+        for (uint32_t i = 0; i < n; ++i) {
+            if (host_plane_within(refined, hx[i], hy[i], hz[i], thr)) {
+                if (last_plane) { last_plane->push_back(hx[i]); last_plane->push_back(hy[i]); last_plane->push_back(hz[i]); }
+                continue;
+            }
+            hx[kept] = hx[i]; hy[kept] = hy[i]; hz[kept] = hz[i];   // (in place: kept <= i)
+            ++kept;
+        }
+        uint32_t dev[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(dev, d_counts, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (dev[1] || dev[0] != kept) { c->err = "internal: the plane split disagrees with the host's selection"; return PCOP_ERR_STATE; }
+        if (kept == n) { *found_all = 0; if (last_plane) last_plane->clear(); break; }   // inliers->indices.size() == 0
+        if (coeffs) coeffs->insert(coeffs->end(), refined, refined + 4);
+        dx = dst.p[0]; dy = dst.p[1]; dz = dst.p[2];
+        n = kept;
+        ++round;
+    }
+    *ox = dx; *oy = dy; *oz = dz; *n_left = n;
     return PCOP_OK;
 }
 
@@ -1174,9 +1441,50 @@ static double sor_threshold(const float* dist, size_t n, float stddev_mul) {
     return mean + (double)stddev_mul * std::sqrt(variance);
 }
 
+int pcop_segment_planes(pcop_ctx* c, const float* xyz, int layout, size_t n, const pcop_plane_params* p, float* out_xyz, size_t* n_out,
+                        float* last_plane_xyz, size_t* n_last_plane, float* coeffs, int32_t cap_planes, int32_t* n_planes, int32_t* found_all) {
+    if (!c || !p || !n_out || !n_planes || !found_all || (!out_xyz && n) || (!xyz && n) || cap_planes < 0) return PCOP_ERR_ARG;
+    int rc = busy(c);
+    if (rc) return rc;
+    if (!(p->dist_thresh >= 0.0f) || !std::isfinite(p->dist_thresh) || !std::isfinite(p->eps_angle)) { c->err = "plane removal: the distance threshold must be finite and >= 0"; return PCOP_ERR_PARAM; }
+    if ((rc = set_device(c))) return rc;
+    Slot& sl = c->slots[0];
+    sl.have_result = false;
+    if ((rc = stage_input(c, sl, xyz, layout, n, PCOP_MEM_HOST))) return rc;   // the cloud as SoA planes in HBM
+    float* rb = reinterpret_cast<float*>(sl.f.rec_b.get());
+    float* ra = reinterpret_cast<float*>(sl.f.rec_a.get());
+    const PlaneScratch sa{{rb, rb + c->cap, rb + 2 * c->cap}}, sb{{ra, ra + c->cap, ra + 2 * c->cap}};   // rec_a / rec_b: 16 bytes per point each
+    const float *ox, *oy, *oz;
+    uint32_t left = 0;
+    std::vector<float> cf, lastp;
+    if ((rc = plane_removal_loop(c, sl, sl.src_x, sl.src_y, sl.src_z, (uint32_t)n, sl.h_vox, *p, sa, sb, &ox, &oy, &oz, &left, &cf, found_all,
+                                 last_plane_xyz ? &lastp : nullptr))) return rc;
+    // what is left is on the host already (the loop keeps its copy in step): three planes in h_vox
+    const float *hx = sl.h_vox, *hy = hx + n, *hz = hy + n;
+    const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
+    for (size_t i = 0; i < left; ++i) {
+        if (layout == PCOP_LAYOUT_SOA) { out_xyz[i] = hx[i]; out_xyz[n + i] = hy[i]; out_xyz[2 * n + i] = hz[i]; }
+        else { out_xyz[fl * i] = hx[i]; out_xyz[fl * i + 1] = hy[i]; out_xyz[fl * i + 2] = hz[i]; if (fl == 4) out_xyz[fl * i + 3] = 1.0f; }
+    }
+    *n_out = left;
+    if (last_plane_xyz) {
+        const size_t nl = lastp.size() / 3;
+        for (size_t i = 0; i < nl; ++i) {
+            if (layout == PCOP_LAYOUT_SOA) { last_plane_xyz[i] = lastp[3 * i]; last_plane_xyz[n + i] = lastp[3 * i + 1]; last_plane_xyz[2 * n + i] = lastp[3 * i + 2]; }
+            else { last_plane_xyz[fl * i] = lastp[3 * i]; last_plane_xyz[fl * i + 1] = lastp[3 * i + 1]; last_plane_xyz[fl * i + 2] = lastp[3 * i + 2]; if (fl == 4) last_plane_xyz[fl * i + 3] = 1.0f; }
+        }
+        if (n_last_plane) *n_last_plane = nl;
+    } else if (n_last_plane) {
+        *n_last_plane = 0;
+    }
+    *n_planes = (int32_t)(cf.size() / 4);
+    if (coeffs) std::memcpy(coeffs, cf.data(), std::min<size_t>(cf.size(), (size_t)cap_planes * 4) * sizeof(float));
+    return PCOP_OK;
+}
+
 int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem, const pcop_occ_params* occ,
-                      int64_t* counts, int64_t* row_avg, int8_t* grid, int mean_k, float stddev_mul, pcop_result* out,
-                      pcop_node_stats* stats) {
+                      int64_t* counts, int64_t* row_avg, int8_t* grid, int mean_k, float stddev_mul, const pcop_plane_params* plane,
+                      pcop_result* out, pcop_node_stats* stats) {
     if (!c || !out) return PCOP_ERR_ARG;
     int rc = busy(c);
     if (rc) return rc;
@@ -1188,8 +1496,13 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
         if (mean_k < 1 || mean_k + 1 > kKnnMax) { c->err = "mean_k must be 1..31"; return PCOP_ERR_PARAM; }
         if (!std::isfinite(stddev_mul)) { c->err = "stddev multiplier must be finite"; return PCOP_ERR_PARAM; }
         if (!c->cell_grid) { c->err = "statistical outlier removal needs the dense cell grid (context created with PCOP_CELL_PATH=hash)"; return PCOP_ERR_STATE; }
+    }
+    if (plane && (!(plane->dist_thresh >= 0.0f) || !std::isfinite(plane->dist_thresh) || !std::isfinite(plane->eps_angle))) {
+        c->err = "plane removal: the distance threshold must be finite and >= 0"; return PCOP_ERR_PARAM;
+    }
+    if (sor || plane) {
         const double radius = (double)c->params.tol;
-        if (!((float)(radius * radius) > 0.0f)) { c->err = "the node chain with outlier removal needs a tolerance > 0"; return PCOP_ERR_PARAM; }
+        if (!((float)(radius * radius) > 0.0f)) { c->err = "the node chain with outlier or plane removal needs a tolerance > 0"; return PCOP_ERR_PARAM; }
     }
     if ((rc = set_device(c))) return rc;
     Slot& sl = c->slots[0];
@@ -1211,14 +1524,23 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
     c->is_dense = is_dense; c->kind = kFrameChain; c->emit_cloud = c->params.publish_clouds != 0; c->out_layout = c->cloud_layout;
     c->cur_n_dev = n_dev;
     double thr = 0.0;
-    uint32_t n_vox = 0;
+    uint32_t n_vox = 0, n_inl = 0, n_clu = 0;
+    int32_t found_all = 1;
+    std::vector<float> plane_coeffs;
+    auto mid_state = [&](Frame* fr) -> int {   // DevState to the host in the middle of the call
+        k_state_out<<<dim3(1, 1), 64, 0, c->stream>>>(fr);
+        HIPCHK(c, hipGetLastError());
+        c->in_flight = true;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return PCOP_OK;
+    };
     for (int attempt = 0;; ++attempt) {
         if (attempt >= 8) { c->cur_n_dev = nullptr; c->retry_to_caller = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
-        if (!sor) {   // the plain chain on the kept cloud; finish_batch re-plans by itself (the mailbox keeps the device count)
+        if (!sor && !plane) {   // the plain chain on the kept cloud; finish_batch re-plans by itself (the mailbox keeps the device count)
             c->retry_to_caller = false;
             if ((rc = enqueue_batch(c))) break;
             rc = finish_batch(c, out, 1);
-            n_vox = sl.h_state->m;
+            n_vox = n_inl = n_clu = sl.h_state->m;
             break;
         }
         c->retry_to_caller = true;
@@ -1228,23 +1550,21 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
         c->ev_used = 0;
         mark(c, "start");
         enqueue_launches(c, kFrameChain, nb, 1, kPartVoxel | kPartOwnGridSetup);
-        // outlier removal, first half: bounds of the voxel cloud, a cell grid sized for it, mean distance to the mean_k nearest neighbours
         const dim3 tg(stride_grid(nb), 1), sg(std::max(1u, div_up(nb, kScanTile)), 1);
-        k_minmax<<<dim3(kReduceBlocks, 1), kBlock, 0, s>>>(fr, 1u);
-        k_sor_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr, kReduceBlocks, (uint32_t)mean_k);
-        k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
-        k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
-        k_cell_count<<<tg, kBlock, 0, s>>>(fr);
-        k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
-        k_cell_place<<<tg, kBlock, 0, s>>>(fr);
-        mark(c, "sor_grid");
-        k_knn_mean<<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
-        mark(c, "k_knn_mean");
-        k_cells_reset<<<tg, kBlock, 0, s>>>(fr);
-        k_state_out<<<dim3(1, 1), 64, 0, s>>>(fr);
-        HIPCHK(c, hipGetLastError());
-        c->in_flight = true;
-        HIPCHK(c, hipStreamSynchronize(s));
+        if (sor) {   // outlier removal, first half: bounds of the voxel cloud, a cell grid sized for it, mean distance to the mean_k nearest neighbours
+            k_minmax<<<dim3(kReduceBlocks, 1), kBlock, 0, s>>>(fr, 1u);
+            k_sor_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr, kReduceBlocks, (uint32_t)mean_k);
+            k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
+            k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
+            k_cell_count<<<tg, kBlock, 0, s>>>(fr);
+            k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
+            k_cell_place<<<tg, kBlock, 0, s>>>(fr);
+            mark(c, "sor_grid");
+            k_knn_mean<<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
+            mark(c, "k_knn_mean");
+            k_cells_reset<<<tg, kBlock, 0, s>>>(fr);
+        }
+        if ((rc = mid_state(fr))) break;
         const DevState* hs = sl.h_state;
         if (hs->err) {   // let finish_batch sort the error out: a re-plan comes back as 1, anything else as its status
             rc = finish_batch(c, nullptr, 0);
@@ -1253,16 +1573,47 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
             break;
         }
         n_vox = hs->m;
-        const uint32_t npts = hs->c_n;   // the voxel cloud (or the input after a pass-through)
-        thr = npts ? sor_threshold(sl.h_xyzr, npts, stddev_mul) : 0.0;
-        sl.h_args->sor_thr = thr;
-        // second half: the points within the threshold, then the clusters on what is left
-        k_sor_select<<<sg, kBlock, 0, s>>>(fr);
-        mark(c, "k_sor_select");
+        uint32_t npts = hs->c_n;   // the voxel cloud (or the input after a pass-through)
+        n_inl = npts;
+        if (sor) {   // second half: the points within the threshold
+            thr = npts ? sor_threshold(sl.h_xyzr, npts, stddev_mul) : 0.0;
+            sl.h_args->sor_thr = thr;
+            k_sor_select<<<sg, kBlock, 0, s>>>(fr);
+            mark(c, "k_sor_select");
+            if (plane) {
+                if ((rc = mid_state(fr))) break;
+                npts = hs->c_n;
+            }
+            n_inl = plane ? npts : 0u;   // (without plane removal: read from the final state below)
+        }
+        if (plane) {   // the cloud lives where the previous step left it; what is left alternates between two scratch plane sets
+            const bool from_in = hs->c_from_input != 0;
+            const float* px = from_in ? hs->src_x.get() : sl.f.cen_x.get();
+            const float* py = from_in ? hs->src_y.get() : sl.f.cen_y.get();
+            const float* pz = from_in ? hs->src_z.get() : sl.f.cen_z.get();
+            float* rb = reinterpret_cast<float*>(sl.f.rec_b.get());
+            PlaneScratch s0{{sl.in_x, sl.in_y, sl.in_z}}, s1{{rb, rb + c->cap, rb + 2 * c->cap}};
+            // neither scratch set may be the cloud of the first round: after the outlier removal it sits in rec_b's planes,
+            // after a pass-through possibly in the staging planes
+            PlaneScratch first = s0, second = s1;
+            if (px == sl.in_x) { first = s1; second = s0; }
+            if (px == sl.in_x && sor) { c->err = "internal: plane removal scratch"; rc = PCOP_ERR_STATE; break; }
+            const float *ox, *oy, *oz;
+            uint32_t left = 0;
+            plane_coeffs.clear();
+            c->in_flight = false;
+            rc = plane_removal_loop(c, sl, px, py, pz, npts, sl.h_vox, *plane, first, second, &ox, &oy, &oz, &left, &plane_coeffs, &found_all);
+            if (rc) break;
+            k_set_cloud<<<1, 64, 0, s>>>(fr, ox, oy, oz, left);
+            mark(c, "plane_removal");
+        }
         enqueue_launches(c, kFrameChain, nb, 1, kPartCluster | kPartEmit | kPartOwnGridSetup);
         HIPCHK(c, hipGetLastError());
+        c->in_flight = true;
         rc = finish_batch(c, out, 1);
         if (rc == 1) continue;
+        n_clu = sl.h_state->c_n;
+        if (sor && !plane) n_inl = n_clu;
         break;
     }
     c->cur_n_dev = nullptr; c->retry_to_caller = false;
@@ -1277,7 +1628,8 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
         uint32_t totals[4] = {0, 0, 0, 0};
         if (occ) HIPCHK(c, hipMemcpy(totals, c->occ_totals, sizeof(totals), hipMemcpyDeviceToHost));
         stats->n_in = (int32_t)n; stats->n_filtered = (int32_t)hs->n_in; stats->index_errors = (int32_t)totals[1];
-        stats->n_voxels = (int32_t)n_vox; stats->n_inliers = (int32_t)(sor ? hs->c_n : n_vox); stats->reserved = 0; stats->threshold = thr;
+        stats->n_voxels = (int32_t)n_vox; stats->n_inliers = (int32_t)n_inl; stats->n_planes = (int32_t)(plane_coeffs.size() / 4);
+        stats->n_clustered = (int32_t)n_clu; stats->planes_found_all = found_all; stats->threshold = thr;
     }
     if (occ) { c->occ_n = hs->n_in; c->occ_valid = true; }
     return PCOP_OK;

@@ -366,3 +366,4 @@ __device__ __forceinline__ bool make_plan(RadixPlan* pl, uint32_t key_bits, uint
 #include "pcop_clusters.hpp"
 #include "pcop_neighbours.hpp"
 #include "pcop_occupancy.hpp"
+#include "pcop_planes.hpp"

@@ -218,11 +218,18 @@ __global__ __launch_bounds__(kBlock) void k_minmax(Frame* frames, uint32_t from_
     const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
     const float4* __restrict__ y4 = reinterpret_cast<const float4*>(y);
     const float4* __restrict__ z4 = reinterpret_cast<const float4*>(z);
-    for (uint32_t i = gtid; i < n4; i += gsz) {
+    uint32_t i = gtid;
+    for (; i + gsz < n4; i += 2u * gsz) {   // two trips' worth of loads in flight
+        const float4 a = x4[i], b = y4[i], c = z4[i];
+        const float4 d = x4[i + gsz], e = y4[i + gsz], f = z4[i + gsz];
+        take(a.x, b.x, c.x); take(a.y, b.y, c.y); take(a.z, b.z, c.z); take(a.w, b.w, c.w);
+        take(d.x, e.x, f.x); take(d.y, e.y, f.y); take(d.z, e.z, f.z); take(d.w, e.w, f.w);
+    }
+    for (; i < n4; i += gsz) {
         const float4 a = x4[i], b = y4[i], c = z4[i];
         take(a.x, b.x, c.x); take(a.y, b.y, c.y); take(a.z, b.z, c.z); take(a.w, b.w, c.w);
     }
-    for (uint32_t i = n4 * 4 + gtid; i < n; i += gsz) take(x[i], y[i], z[i]);
+    for (uint32_t j = n4 * 4 + gtid; j < n; j += gsz) take(x[j], y[j], z[j]);
     MinMaxPartial p;
     p.mn[0] = mn0; p.mn[1] = mn1; p.mn[2] = mn2; p.mx[0] = mx0; p.mx[1] = mx1; p.mx[2] = mx2;
     p.valid = valid; p.nonfinite = bad;
@@ -1015,34 +1022,39 @@ __global__ __launch_bounds__(kBlock) void k_bin_tilecnt(const Frame* frames) {
     }
 }
 
-// tbase[bucket][tile] = points of the lower tiles in the bucket: one thread per bucket, eight tiles per step.
+// tbase[bucket][tile] = points of the lower tiles in the bucket: one wave per bucket, a lane takes eight tiles (one 16-byte
+// load), a wave scan joins the lanes; 512 tiles per round.
 __global__ __launch_bounds__(kBlock) void k_bin_colscan(const Frame* frames) {
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const uint16_t* __restrict__ tcnt = F.tcnt;
     uint32_t* __restrict__ tbase = F.tbase;
     if (stream_off(st)) return;
-    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t b = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
     if (b >= st->nbuckets) return;
     const uint32_t ntiles = (st->n_in + st->tile - 1u) / st->tile, ts = F.tstride;   // ts: a multiple of 8
+    const uint32_t ngroups = (ntiles + 7u) / 8u;
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(tcnt + (size_t)b * ts);
     uint4* __restrict__ dst = reinterpret_cast<uint4*>(tbase + (size_t)b * ts);
-    uint32_t run = 0u;
-    for (uint32_t g0 = 0; g0 * 8u < ntiles; g0 += 4u) {   // four 16-byte loads in flight (entries past ntiles are never read by anyone)
-        uint4 v[4];
+    uint32_t carry = 0u;
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += kWave) {
+        const uint32_t g = g0 + lane_id();
+        const uint4 v = src[min(g, ngroups - 1u)];   // (entries past ntiles are never read by anyone: whatever they hold)
+        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+        uint32_t sum = 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) v[k] = src[min(g0 + k, (ntiles - 1u) / 8u)];
+        for (int j = 0; j < 4; ++j) sum += (wv[j] & 0xFFFFu) + (wv[j] >> 16);
+        if (g >= ngroups) sum = 0u;
+        const uint32_t incl = wave_incl_scan(sum);
+        uint32_t run = carry + incl - sum;
+        if (g < ngroups) {
+            uint32_t o[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            if ((g0 + k) * 8u < ntiles) {
-                const uint32_t wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-                uint32_t o[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { o[2 * j] = run; run += wv[j] & 0xFFFFu; o[2 * j + 1] = run; run += wv[j] >> 16; }
-                dst[2u * (g0 + k)] = make_uint4(o[0], o[1], o[2], o[3]);
-                dst[2u * (g0 + k) + 1u] = make_uint4(o[4], o[5], o[6], o[7]);
-            }
+            for (int j = 0; j < 4; ++j) { o[2 * j] = run; run += wv[j] & 0xFFFFu; o[2 * j + 1] = run; run += wv[j] >> 16; }
+            dst[2u * g] = make_uint4(o[0], o[1], o[2], o[3]);
+            dst[2u * g + 1u] = make_uint4(o[4], o[5], o[6], o[7]);
         }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
     }
 }
 

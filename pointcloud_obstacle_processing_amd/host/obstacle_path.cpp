@@ -139,6 +139,48 @@ void remove_statistical_outliers(PointCloudXYZ::Ptr& input_cloud, PointCloudXYZ&
     }
 }
 
+bool segment_plane_and_extract_indices(PointCloudXYZ::Ptr& planar_cloud, PointCloudXYZ::Ptr& indices_cloud, PointCloudXYZ::Ptr& cloud_f,
+                                       ModelCoefficients::Ptr& coefficients, PointIndices::Ptr& inliers, PointIndices::Ptr& outliers,
+                                       const float axis[3], float dist_thresh, int eps_angle, Publisher<PointCloud2>& pub1,
+                                       Publisher<PointCloud2>& pub2, Publisher<PointCloud2>& pub3, bool publish_planar, bool publish_indices,
+                                       bool publish_filtered) {
+    const size_t n = planar_cloud->points.size();
+    pcop_ctx* c = default_context(n);
+    pcop_plane_params p{};
+    p.dist_thresh = dist_thresh; p.axis[0] = axis[0]; p.axis[1] = axis[1]; p.axis[2] = axis[2];
+    p.eps_angle = (double)eps_angle;                     // seg.setEpsAngle(eps_angle): the int goes in as radians (od.cpp:371)
+    std::vector<PointXYZ> rest(n ? n : 1), last(n ? n : 1);
+    std::vector<float> coeffs(4 * 64);
+    size_t n_rest = 0, n_last = 0;
+    int32_t n_planes = 0, found_all = 0;
+    check(c, pcop_segment_planes(c, n ? &planar_cloud->points[0].x : nullptr, PCOP_LAYOUT_AOS16, n, &p, &rest[0].x, &n_rest, &last[0].x, &n_last,
+                                 coeffs.data(), 64, &n_planes, &found_all), "pcop_segment_planes");
+    rest.resize(n_rest); last.resize(n_last);
+    const Header hdr = planar_cloud->header;
+    auto fill = [&](PointCloudXYZ::Ptr& dst, const std::vector<PointXYZ>& pts) {
+        if (!dst) dst.reset(new PointCloudXYZ);
+        dst->points = pts; dst->header = hdr; dst->width = (uint32_t)pts.size(); dst->height = 1; dst->is_dense = true;
+    };
+    if (n_planes) {                                      // (with no plane found the reference leaves all three clouds as they were)
+        fill(planar_cloud, rest);
+        fill(indices_cloud, last);
+        fill(cloud_f, rest);
+        if (coefficients) coefficients->values.assign(coeffs.begin() + 4 * (std::min(n_planes, 64) - 1), coeffs.begin() + 4 * std::min(n_planes, 64));
+    }
+    if (inliers) inliers->indices.clear();
+    if (outliers) outliers->indices.clear();
+    auto pub = [&](Publisher<PointCloud2>& pb, const PointCloudXYZ::Ptr& cl) {   // od.cpp:400-426
+        PointCloud2 msg;
+        to_pointcloud2(*cl, &msg);
+        msg.header.frame_id = "world";
+        pb.publish(msg);
+    };
+    if (publish_planar && planar_cloud) pub(pub1, planar_cloud);
+    if (publish_indices && indices_cloud) pub(pub2, indices_cloud);
+    if (publish_filtered && cloud_f) pub(pub3, cloud_f);
+    return found_all != 0;
+}
+
 ObstacleNode::ObstacleNode(const NodeParams& prm, size_t max_points, int device) : params(prm) {
     downsample_publisher.topic = "voxel_grid"; downsample_publisher.queue_size = 1;
     centroid_publisher.topic = "centroids"; centroid_publisher.queue_size = 1;
@@ -172,13 +214,16 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
         occ.x_min = params.x_min; occ.x_max = params.x_max; occ.y_min = params.y_min; occ.y_max = params.y_max;
         occ.z_min = params.z_min; occ.z_max = params.z_max; occ.block_size = params.block_size; occ.dev_percent = params.dev_percent;
         pcop_occupancy_grid_dims(occ.x_min, occ.x_max, occ.y_min, occ.y_max, occ.block_size, &occ.grid_width, &occ.grid_height);   // od.cpp:958-959
+        pcop_plane_params plane{};                           // od.cpp:768, 778-781: axis (0, 0, 1), the yaml's threshold and "angle"
+        plane.dist_thresh = params.plane_segment_dist_thres; plane.axis[0] = 0.0f; plane.axis[1] = 0.0f; plane.axis[2] = 1.0f;
+        plane.eps_angle = (double)params.plane_segment_angle;
         const size_t cells = (size_t)std::max(occ.grid_width, 0) * (size_t)std::max(occ.grid_height, 0);
         occupancy_grid.assign(cells, 0); occupancy_counts.assign(cells, 0); occupancy_row_averages.assign((size_t)std::max(occ.grid_height, 0), 0);
         static_assert(sizeof(long long) == sizeof(int64_t), "counts are 64-bit");
         rc = pcop_process_node(ctx_, in.points.empty() ? nullptr : &in.points[0].x, PCOP_LAYOUT_AOS16, in.points.size(), 1, PCOP_MEM_HOST,
                                &occ, reinterpret_cast<int64_t*>(occupancy_counts.data()), reinterpret_cast<int64_t*>(occupancy_row_averages.data()),
                                reinterpret_cast<int8_t*>(occupancy_grid.data()), params.statistical_outlier_meanK,
-                               params.statistical_outlier_stdDevThres, &r, &stats);
+                               params.statistical_outlier_stdDevThres, remove_planes ? &plane : nullptr, &r, &stats);
     } else {
         rc = pcop_process_pointcloud2(ctx_, cloud_msg.data.data(), cloud_msg.width, cloud_msg.height, cloud_msg.point_step,
                                       cloud_msg.row_step, ox, oy, oz, cloud_msg.is_bigendian ? 1 : 0, cloud_msg.is_dense ? 1 : 0, &r);

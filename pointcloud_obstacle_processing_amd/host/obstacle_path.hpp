@@ -7,6 +7,7 @@
 //   extract_euclidian_clusters  od.cpp:430-455     EuclideanClusterExtraction
 //   build_initial_occupancy_grid_dataset  od.cpp:175-269   bounds filter + occupancy binning (the step before)
 //   remove_statistical_outliers  od.cpp:316-340    StatisticalOutlierRemoval + optional publish (between the two)
+//   segment_plane_and_extract_indices  od.cpp:342-428   RANSAC plane removal + optional publishes (after it)
 //   ObstacleNode::cloud_cb      od.cpp:674-928     the part of the callback the north star names:
 //                                                  PointCloud2 in -> voxel grid -> clusters ->
 //                                                  "voxel_grid", "centroids", "euc_clusters" out
@@ -51,6 +52,18 @@ void build_initial_occupancy_grid_dataset(int grid_size, int grid_height, int gr
 void remove_statistical_outliers(PointCloudXYZ::Ptr& input_cloud, PointCloudXYZ& output_cloud, float meanK, float stdDevThres,
                                  Publisher<PointCloud2>& pub, bool publish);
 
+// od.cpp:342-428.  Same argument list with the stand-in types: planar_cloud is the input and ends up as the points outside
+// every plane found, indices_cloud as the points of the last plane removed, cloud_f as planar_cloud; coefficients holds the
+// refined coefficients of the last plane.  inliers / outliers keep the call shape (the reference's ExtractIndices consumes
+// them internally; here the selection happens on the GPU).  axis, dist_thresh, eps_angle as the node passes them (od.cpp:768,
+// 110-111: the angle is an int that PCL reads as radians).  Returns false when a round found no plane (the reference prints
+// "Couldn't estimate a planar model for the given dataset." and leaves the loop).
+bool segment_plane_and_extract_indices(PointCloudXYZ::Ptr& planar_cloud, PointCloudXYZ::Ptr& indices_cloud, PointCloudXYZ::Ptr& cloud_f,
+                                       ModelCoefficients::Ptr& coefficients, PointIndices::Ptr& inliers, PointIndices::Ptr& outliers,
+                                       const float axis[3], float dist_thresh, int eps_angle, Publisher<PointCloud2>& pub1,
+                                       Publisher<PointCloud2>& pub2, Publisher<PointCloud2>& pub3, bool publish_planar, bool publish_indices,
+                                       bool publish_filtered);
+
 // The node surface of the path: same topic names, queue sizes and parameter keys as od.cpp:930-1015.
 class ObstacleNode {
 public:
@@ -67,10 +80,11 @@ public:
     NodeParams params;
     // false (default): the chain BASELINE.json's north star names, voxel grid -> clusters.  true: the node's own order,
     // build_initial_occupancy_grid_dataset (limits, block_size, dev_percent of `params`) -> voxel grid ->
-    // remove_statistical_outliers (statistical_outlier_meanK / _stdDevThres) -> clusters (od.cpp:727-797, without the
-    // plane removal of od.cpp:778-781), one pcop_process_node call; voxel_cloud is then the cloud the cluster indices
+    // remove_statistical_outliers (statistical_outlier_meanK / _stdDevThres) -> segment_plane_and_extract_indices
+    // (plane_segment_dist_thres, plane_segment_angle, axis z) -> clusters (od.cpp:727-797), one pcop_process_node call; voxel_cloud is then the cloud the cluster indices
     // refer to (the inliers), occupancy_grid / _counts / _row_averages the grid outputs.
     bool node_order = false;
+    bool remove_planes = true;                          // node order only: segment_plane_and_extract_indices between the outlier removal and the clustering (od.cpp:778-781)
     std::vector<signed char> occupancy_grid;            // occupancy_grid_data (od.cpp:725)
     std::vector<long long> occupancy_counts, occupancy_row_averages;
     pcop_node_stats stats{};

@@ -5,8 +5,8 @@
 //   pcop_node --params params.yaml --cloud in.pc2 --out outdir [--device 0] [--stage-api] [--occupancy] [--sor] [--node-order]
 //
 // --node-order (frame mode) runs the node's own order in one call that keeps every intermediate cloud on the GPU:
-// bounds filter + occupancy binning -> voxel grid -> statistical outlier removal -> clusters (od.cpp:727-797 without the
-// plane removal), parameters from the yaml tree; voxel_grid.pc2 is then the cloud the cluster indices refer to.
+// bounds filter + occupancy binning -> voxel grid -> statistical outlier removal -> RANSAC plane removal -> clusters
+// (od.cpp:727-797), parameters from the yaml tree (--no-planes leaves the plane removal out); voxel_grid.pc2 is then the cloud the cluster indices refer to.
 //
 // --stage-api runs the two free functions (downsample_cloud, extract_euclidian_clusters) the way
 // cloud_cb calls them (od.cpp:740, od.cpp:791-797) instead of the fused frame entry.
@@ -39,7 +39,7 @@ static void write_indices(const std::string& path, const std::vector<PointIndice
 int main(int argc, char** argv) {
     std::string params_path, cloud_path, out_dir = ".";
     int device = 0;
-    bool stage_api = false, occupancy = false, sor = false, node_order = false;
+    bool stage_api = false, occupancy = false, sor = false, node_order = false, planes = true;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--params" && i + 1 < argc) params_path = argv[++i];
@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
         else if (a == "--occupancy") occupancy = true;
         else if (a == "--sor") sor = true;
         else if (a == "--node-order") node_order = true;
+        else if (a == "--no-planes") planes = false;
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (params_path.empty() || cloud_path.empty()) {
@@ -112,6 +113,7 @@ int main(int argc, char** argv) {
         }
         ObstacleNode node(prm, std::max<size_t>((size_t)msg.width * msg.height, 1024), device);
         node.node_order = node_order;
+        node.remove_planes = planes;
         const int rc = node.cloud_cb(msg);
         if (rc) { std::fprintf(stderr, "cloud_cb failed: %s (%s)\n", pcop_status_string(rc), node.last_error().c_str()); return 1; }
         if (node.downsample_publisher.published &&
@@ -125,8 +127,8 @@ int main(int argc, char** argv) {
         write_indices(out_dir + "/cluster_indices.txt", node.euc_cluster_indices);
         std::printf("frame: N=%u M=%zu K=%zu passthrough=%d\n", msg.width * msg.height, node.voxel_cloud.size(),
                     node.euc_cluster_indices.size(), node.passthrough);
-        if (node_order) std::printf("node order: inside the box %d, voxels %d, inliers %d, threshold %.17g\n", node.stats.n_filtered,
-                                    node.stats.n_voxels, node.stats.n_inliers, node.stats.threshold);
+        if (node_order) std::printf("node order: inside the box %d, voxels %d, inliers %d, planes %d, clustered %d, threshold %.17g\n", node.stats.n_filtered,
+                                    node.stats.n_voxels, node.stats.n_inliers, node.stats.n_planes, node.stats.n_clustered, node.stats.threshold);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -54,8 +54,15 @@ struct PointCloudXYZ {   // pcl::PointCloud<pcl::PointXYZ>
 };
 
 struct PointIndices {   // pcl::PointIndices
+    typedef std::shared_ptr<PointIndices> Ptr;
     Header header;
     std::vector<int> indices;
+};
+
+struct ModelCoefficients {   // pcl::ModelCoefficients
+    typedef std::shared_ptr<ModelCoefficients> Ptr;
+    Header header;
+    std::vector<float> values;
 };
 
 struct PointWithRad {   // msg/PointWithRad.msg:1-4

@@ -136,7 +136,8 @@ def test_node_harness_node_order(oracle, tmp_path):
         f.write("pointcloud_obstacle_processing:\n        x_min: 0.2\n        x_max: 4.3\n        y_min: 0.2\n        y_max: 4.3\n"
                 "        z_min: -0.4\n        z_max: 0.7\n        obstacle_detection:\n                block_size: 0.2\n"
                 "                dev_percent: 0.4\n                downsample_size: 0.04\n                statistical_outlier_meanK: 12\n"
-                "                statistical_outlier_stdDevThres: 1.5\n                euc_cluster_tolerance: 0.1\n"
+                "                statistical_outlier_stdDevThres: 1.5\n                plane_segment_dist_thres: 0.04\n"
+                "                plane_segment_angle: 20\n                euc_cluster_tolerance: 0.1\n"
                 "                euc_min_cluster_size: 5\n                euc_max_cluster_size: 20000\n")
     out = subprocess.run([exe, "--params", yaml_path, "--cloud", cloud, "--out", str(tmp_path), "--node-order"],
                          capture_output=True, text=True, timeout=300)
@@ -146,8 +147,11 @@ def test_node_harness_node_order(oracle, tmp_path):
     kept = oracle.occupancy(pts, p)
     vox, _ = oracle.voxel_downsample(kept["xyz"], 0.04)
     s = oracle.sor(vox, 12, 1.5)
+    pl = oracle.segment_planes(s["xyz"], 0.04)
+    assert pl["n_planes"] >= 1
+    s = dict(xyz=pl["xyz"], n_inl=len(s["xyz"]))
     off, idx = oracle.euclidean_clusters(s["xyz"], 0.1, 5, 20000)
-    assert "inside the box %d, voxels %d, inliers %d" % (kept["n_out"], len(vox), len(s["xyz"])) in out.stdout
+    assert "inside the box %d, voxels %d, inliers %d, planes %d, clustered %d" % (kept["n_out"], len(vox), s["n_inl"], pl["n_planes"], len(pl["xyz"])) in out.stdout
     got = pc2io.read_pointcloud2(str(tmp_path / "voxel_grid.pc2"))
     assert got["xyz"].tobytes() == s["xyz"].tobytes()
     clusters = read_indices(str(tmp_path / "cluster_indices.txt"))

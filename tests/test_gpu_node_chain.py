@@ -29,7 +29,7 @@ def field_cloud(n, seed):
     return pts                                                 # filter tests x only, od.cpp:199)
 
 
-def oracle_chain(oracle, pts, occ, leaf, mean_k, mul, tol, mn, mx):
+def oracle_chain(oracle, pts, occ, leaf, mean_k, mul, tol, mn, mx, plane_thr=None):
     cloud = pts
     ref = {}
     if occ is not None:
@@ -42,6 +42,11 @@ def oracle_chain(oracle, pts, occ, leaf, mean_k, mul, tol, mn, mx):
         s = oracle.sor(vox, mean_k, mul)
         ref["threshold"] = s["threshold"]
         vox = s["xyz"]
+    ref["n_inliers"] = len(vox)
+    if plane_thr is not None:
+        pl = oracle.segment_planes(vox, plane_thr)
+        ref["n_planes"], ref["coeffs"] = pl["n_planes"], pl["coeffs"]
+        vox = pl["xyz"]
     ref["cloud"] = vox
     ref["offsets"], ref["indices"] = oracle.euclidean_clusters(vox, tol, mn, mx)
     return ref
@@ -92,6 +97,28 @@ def test_node_chain_matches_stage_by_stage_oracle(capi, oracle, monkeypatch, use
     small = synth.make_cloud("C1")
     r1, g1 = oracle.process_xyz(small, **p1), c.process_xyz(small)
     assert g1["voxel_xyz"].tobytes() == r1["voxel_xyz"].tobytes() and np.array_equal(g1["indices"], r1["indices"])
+    c.close()
+
+
+@pytest.mark.parametrize("use_occ,mean_k", [(True, 15), (False, 0), (False, 15)])
+def test_node_chain_with_plane_removal(capi, oracle, use_occ, mean_k):
+    """All five steps of od.cpp:727-797: bounds filter -> voxel grid -> outlier removal -> RANSAC plane removal -> clusters."""
+    leaf, tol, mn, mx, mul, pthr = 0.04, 0.12, 5, 20000, 1.0, 0.04
+    pts = field_cloud(300_000, 23)
+    if not use_occ:
+        pts = pts[np.isfinite(pts).all(axis=1)]
+    po, pc = occ_of(capi, oracle)
+    ref = oracle_chain(oracle, pts, po if use_occ else None, leaf, mean_k, mul, tol, mn, mx, plane_thr=pthr)
+    assert ref["n_planes"] >= 1 and len(ref["offsets"]) > 1
+    c = capi.Context(len(pts))
+    c.set_params(leaf=leaf, tol=tol, min_cluster=mn, max_cluster=mx, publish_clouds=1)
+    for rep in range(2):
+        got = c.process_node(pts, occ=pc if use_occ else None, mean_k=mean_k, stddev_mul=mul, plane=capi.plane_params(pthr))
+        assert got["voxel_xyz"].tobytes() == ref["cloud"].tobytes()
+        assert np.array_equal(got["offsets"], ref["offsets"]) and np.array_equal(got["indices"], ref["indices"])
+        assert got["n_voxels"] == ref["n_voxels"] and got["n_inliers"] == ref["n_inliers"]
+        assert got["n_planes"] == ref["n_planes"] and got["n_clustered"] == len(ref["cloud"]) and got["planes_found_all"]
+    assert c.cluster_cloud()[:, :3].tobytes() == ref["cloud"][ref["indices"]].tobytes()
     c.close()
 
 

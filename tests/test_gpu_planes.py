@@ -1,0 +1,79 @@
+"""RANSAC plane removal on the GPU (pcop_segment_planes, through the C ABI) against the CPU restatement of od.cpp:342-428:
+the planes' refined coefficients, what is left, the last plane's points - all bit-exact (the candidate planes come from a
+fixed-seed generator, the counts are integers, the refit is the same sequence of float operations on the host)."""
+import numpy as np
+import pytest
+
+from pointcloud_obstacle_processing_amd import synth
+from test_oracle_planes import plane_cloud
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pointcloud_obstacle_processing_amd import capi as m
+    m.load_library()
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(400_000)
+    yield c
+    c.close()
+
+
+def check(ctx, capi, oracle, pts, thr, axis=(0, 0, 1), eps=20.0, layout=2):
+    got = ctx.segment_planes(pts, capi.plane_params(thr, axis, eps), layout=layout)
+    ref = oracle.segment_planes(pts, thr, axis=axis, eps_angle=eps)
+    assert got["n_planes"] == ref["n_planes"] and got["found_all"] == ref["found_all"]
+    assert got["coeffs"].tobytes() == ref["coeffs"].tobytes()
+    assert got["xyz"].tobytes() == ref["xyz"].tobytes()
+    assert got["last_plane"].tobytes() == ref["last_plane"].tobytes()
+    return got
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_voxel_cloud_of_the_benchmark_scene(ctx, capi, oracle, layout):
+    """The node's case: a ground plane with boxes on it; the ground goes, the boxes stay (od.cpp:778-781, threshold of params.yaml)."""
+    vox, _ = oracle.voxel_downsample(synth.make_cloud("C3", n=400_000, seed=41), 0.03)
+    got = check(ctx, capi, oracle, vox, 0.04, layout=layout)
+    assert got["n_planes"] >= 1 and len(got["xyz"]) <= 0.3 * len(vox)
+
+
+def test_two_planes_and_scatter(ctx, capi, oracle):
+    ground = plane_cloud(60_000, (0, 0, 1), 0.0, 0.003, 2)
+    wall = plane_cloud(25_000, (1, 0.2, 0.1), 1.0, 0.003, 3)
+    rng = np.random.default_rng(4)
+    blob = rng.uniform(-2, 2, (15_000, 3)).astype(f32) + f32([0, 0, 3])
+    pts = np.concatenate([ground, wall, blob])[rng.permutation(100_000)]
+    got = check(ctx, capi, oracle, pts, 0.02)
+    assert got["n_planes"] == 2
+
+
+def test_many_small_planes(ctx, capi, oracle):
+    """Eight parallel sheets of equal size: the loop runs six times (each round takes one sheet, 30 % = 2.4 sheets stay)."""
+    sheets = [plane_cloud(3000, (0, 0, 1), -0.2 * k, 0.001, 10 + k) for k in range(8)]
+    pts = np.concatenate(sheets)[np.random.default_rng(5).permutation(24_000)]
+    got = check(ctx, capi, oracle, pts, 0.02)
+    assert got["n_planes"] == 6
+
+
+def test_edge_cases(ctx, capi, oracle):
+    check(ctx, capi, oracle, np.zeros((0, 3), dtype=f32), 0.02)
+    check(ctx, capi, oracle, np.array([[0, 0, 0], [1, 0, 0]], dtype=f32), 0.02)                 # fewer than three points: no plane
+    check(ctx, capi, oracle, np.repeat(np.array([[1, 2, 3]], dtype=f32), 100, axis=0), 0.02)     # every sample degenerate
+    wall = plane_cloud(4000, (1, 0, 0), 0.5, 0.002, 5)
+    got = check(ctx, capi, oracle, wall, 0.02, eps=0.1)                                          # the angle rejects every candidate
+    assert got["n_planes"] == 0 and not got["found_all"]
+    check(ctx, capi, oracle, wall, 0.02, axis=(1, 0, 0), eps=0.1)
+    check(ctx, capi, oracle, np.random.default_rng(6).uniform(-1, 1, (5000, 3)).astype(f32), 0.01)   # no plane worth the name: slabs get cut out all the same
+    with pytest.raises(capi.PcopError):
+        ctx.segment_planes(wall, capi.plane_params(float("nan")))
+    # the context still runs frames afterwards
+    p = synth.params_of("C1")
+    ctx.set_params(publish_clouds=1, **p)
+    pts = synth.make_cloud("C1")
+    assert ctx.process_xyz(pts)["voxel_xyz"].tobytes() == oracle.process_xyz(pts, **p)["voxel_xyz"].tobytes()

@@ -6,6 +6,7 @@ acc = collections.defaultdict(list)
 for r in rows:
     if r["Grid_Size_Y"] == str(batch):
         acc[r["Kernel_Name"][:64]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+acc = {k: v for k, v in acc.items() if "pcop::k_" in k and "probe" not in k and "unpack" not in k}
 nb = min(len(v) for v in acc.values())
 items = sorted(((k, sum(v) / len(v), len(v) // nb) for k, v in acc.items()), key=lambda t: -t[1] * t[2])
 tot = 0.0

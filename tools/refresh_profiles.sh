@@ -1,28 +1,34 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the bench line, the rocprofv3 kernel trace and the two PMC passes of the
-# same command, reduced to the files kept under profiles/.  usage: tools/refresh_profiles.sh <round tag, e.g. r01>
+# same command, reduced to the files kept under profiles/.  usage: tools/refresh_profiles.sh <round tag, e.g. r02> [batch]
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
+B=${2:-16}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh_$tag
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/trace.log 2>&1
 echo "trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --contexts 1 > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --rounds 3 --no-cpu-baseline --no-end-to-end --contexts 1 > $O/pmc_$c.log 2>&1
 done
 echo "pmc done"
+# single-frame latency: the kernel trace of one-frame calls
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -o trace -- python3 $R/tools/single_frame.py > $O/trace1.log 2>&1
+echo "single-frame trace done"
 cd $R
 T=$(dirname $(find $O/trace -name trace_kernel_trace.csv | head -1))
-python3 tools/prof_summary.py $T 8 > $O/kernel_summary_batch8.txt
+python3 tools/prof_summary.py $T $B > $O/kernel_summary_batch$B.txt
 cp $(find $O/trace -name trace_kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats.csv
+T1=$(dirname $(find $O/trace1 -name trace_kernel_trace.csv | head -1))
+python3 tools/prof_summary.py $T1 1 > $O/kernel_summary_single_frame.txt
 F=$(dirname $(find $O/pmc_FETCH_SIZE -name pmc_counter_collection.csv | head -1))
 W=$(dirname $(find $O/pmc_WRITE_SIZE -name pmc_counter_collection.csv | head -1))
-python3 tools/pmc_summary.py $F $W 8 $O/pmc_traffic.json > $O/pmc_summary.txt
-head -12 $O/kernel_summary_batch8.txt; head -8 $O/pmc_summary.txt
+python3 tools/pmc_summary.py $F $W $B $O/pmc_traffic.json > $O/pmc_summary.txt
+head -14 $O/kernel_summary_batch$B.txt; head -10 $O/pmc_summary.txt; tail -3 $O/kernel_summary_single_frame.txt
 python3 - <<PY
-import json; d=json.load(open("$O/bench.json")); print(d["value"], d["latency_ms_single_frame"], d["roofline"], d.get("cpu_baseline"))
+import json; d=json.load(open("$O/bench.json")); print(d["value"], d["latency_ms_single_frame"], d["roofline"], d.get("cpu_baseline"), d.get("end_to_end"), d.get("parity"))
 PY
