@@ -117,6 +117,7 @@ struct pcop_ctx {
     // LDS atomic adds of one wave instruction return their old values in lane order on this device (checked by
     // k_lds_order_probe when the context is made; PCOP_LDS_ORDER=0 skips the check and keeps the peer-mask ranks)
     bool lds_ordered = false;
+    std::vector<float> sor_sq;               // outlier removal: the squares of the mean distances
     const uint32_t* cur_n_dev = nullptr;     // the batch in flight takes frame 0's point count from the device (the cloud a filter kept)
     bool retry_to_caller = false;            // finish_batch hands a re-plan back to its caller instead of re-running the plain chain
     // dense cell grid: on unless PCOP_CELL_PATH=hash; a frame whose grid exceeds kCmapCells is re-run on the hash
@@ -941,6 +942,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         HIPCHK(c, hipMemset(f.cflag.get(), 0, (size_t)kCmapCells));   // the kernels keep it all zero between frames
         TRY(dev_alloc(c, &f.cmap, (size_t)kCmapCells / 32u + 1u));
         TRY(dev_alloc(c, &f.ctile, (size_t)kCmapCells / 32u / kVmapTile));
+        TRY(dev_alloc(c, &f.ccoarse, (size_t)kCoarseBits / 32u));
     }
     if (c->voxel_stream) {
         const size_t tiles = (n + kBinTileSmall - 1) / kBinTileSmall + 1;
@@ -1358,7 +1360,7 @@ int pcop_process_filtered(pcop_ctx* c, pcop_result* out) {
 }
 
 // StatisticalOutlierRemoval::applyFilterIndices, second half: sequential double sums in index order, then the threshold.
-static double sor_threshold(const float* dist, size_t n, float stddev_mul);
+static double sor_threshold(const float* dist, size_t n, float stddev_mul, std::vector<float>& sq);
 
 int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, size_t n, int mean_k, float stddev_mul,
                                      float* out_xyz, size_t* n_out, float* distances, double* threshold) {
@@ -1399,11 +1401,13 @@ int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, 
     mark(c, "bounds");
     k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
     k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
+    k_cmap_coarse<<<dim3(256, 1), kBlock, 0, s>>>(fr);
     k_cell_count<<<tg, kBlock, 0, s>>>(fr);
     k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
     k_cell_place<<<tg, kBlock, 0, s>>>(fr);
     mark(c, "cell_grid");
-    k_knn_mean<<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
+    if (mean_k + 1 <= 16) k_knn_mean<16><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
+    else k_knn_mean<32><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
     mark(c, "k_knn_mean");
     k_emit<<<tg, kBlock, 0, s>>>(fr, 1u);
     mark(c, "k_emit");
@@ -1414,17 +1418,19 @@ int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, 
     if (e & kErrNonFinite) { scrub_flags(c); c->err = "non-finite coordinates"; return PCOP_ERR_NONFINITE; }
     if (e) { scrub_flags(c); c->err = (e & kErrReplanCpath) ? "no cell grid fits this cloud" : "internal error in the k-NN pass"; return PCOP_ERR_STATE; }
     const float* dist = sl.h_xyzr;   // pinned: the kernel wrote the n mean distances here
-    const double thr = sor_threshold(dist, n, stddev_mul);
+    const double thr = sor_threshold(dist, n, stddev_mul, c->sor_sq);
     size_t kept = 0;
     const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
-    for (size_t i = 0; i < n; ++i) {
-        if ((double)dist[i] > thr) continue;   // the outliers
-        if (layout == PCOP_LAYOUT_SOA) {
+    // every point is written where the next kept one goes and the place advances only past an inlier: no branch on the data
+    if (layout == PCOP_LAYOUT_SOA) {
+        for (size_t i = 0; i < n; ++i) {
             for (int ax = 0; ax < 3; ++ax) out_xyz[(size_t)ax * n + kept] = xyz[(size_t)ax * n + i];
-        } else {
-            for (size_t ax = 0; ax < fl; ++ax) out_xyz[fl * kept + ax] = xyz[fl * i + ax];
+            kept += !((double)dist[i] > thr);
         }
-        ++kept;
+    } else if (fl == 4) {
+        for (size_t i = 0; i < n; ++i) { std::memmove(out_xyz + 4 * kept, xyz + 4 * i, 16); kept += !((double)dist[i] > thr); }
+    } else {
+        for (size_t i = 0; i < n; ++i) { std::memmove(out_xyz + 3 * kept, xyz + 3 * i, 12); kept += !((double)dist[i] > thr); }
     }
     *n_out = kept;
     if (distances) std::memcpy(distances, dist, n * sizeof(float));
@@ -1432,9 +1438,42 @@ int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, 
     return PCOP_OK;
 }
 
-static double sor_threshold(const float* dist, size_t n, float stddev_mul) {
-    double sum = 0.0, sq_sum = 0.0;
-    for (size_t i = 0; i < n; ++i) { sum += dist[i]; sq_sum += dist[i] * dist[i]; }
+// sum of v[0..n) in double, bit for bit what `for (i) s += v[i]` gives.  The values are floats >= 0: each is a whole
+// multiple of g = 2^(smallest biased exponent - 150), so every partial sum is one too; when n * largest / g stays
+// below 2^53 every partial sum is representable, no addition rounds, and the order of the additions cannot matter -
+// the sum is then taken with eight accumulators instead of one chain of dependent additions.  Otherwise: in order.
+static double seq_sum_floats(const float* v, size_t n) {
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t b; std::memcpy(&b, v + i, 4);
+        const uint32_t m = b - 1u;            // a zero adds nothing and must not drag the smallest value down
+        lo = m < lo ? m : lo;
+        hi = b > hi ? b : hi;
+    }
+    bool exact = false;
+    if (hi == 0u) return 0.0;
+    if (!(hi >> 31) && hi < 0x7F800000u) {     // all finite and non-negative (as non-negative floats order like their bit patterns)
+        const uint32_t elo = std::max(1u, (lo + 1u) >> 23), ehi = std::max(1u, hi >> 23);
+        uint32_t L = 0; while ((1ull << L) < n) ++L;
+        exact = L + 24u + (ehi - elo) <= 53u;
+    }
+    if (!exact) {
+        double s = 0.0;
+        for (size_t i = 0; i < n; ++i) s += v[i];
+        return s;
+    }
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int k = 0; k < 8; ++k) a[k] += v[i + k];
+    for (; i < n; ++i) a[0] += v[i];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+static double sor_threshold(const float* dist, size_t n, float stddev_mul, std::vector<float>& sq) {
+    sq.resize(n);
+    for (size_t i = 0; i < n; ++i) sq[i] = dist[i] * dist[i];   // a float product, as the reference forms it
+    const double sum = seq_sum_floats(dist, n), sq_sum = seq_sum_floats(sq.data(), n);
     const double valid = (double)n;
     const double mean = sum / valid;
     const double variance = (sq_sum - sum * sum / valid) / (valid - 1.0);
@@ -1556,11 +1595,13 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
             k_sor_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr, kReduceBlocks, (uint32_t)mean_k);
             k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
             k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
+            k_cmap_coarse<<<dim3(256, 1), kBlock, 0, s>>>(fr);
             k_cell_count<<<tg, kBlock, 0, s>>>(fr);
             k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
             k_cell_place<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "sor_grid");
-            k_knn_mean<<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
+            if (mean_k + 1 <= 16) k_knn_mean<16><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
+            else k_knn_mean<32><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
             mark(c, "k_knn_mean");
             k_cells_reset<<<tg, kBlock, 0, s>>>(fr);
         }
@@ -1576,7 +1617,7 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
         uint32_t npts = hs->c_n;   // the voxel cloud (or the input after a pass-through)
         n_inl = npts;
         if (sor) {   // second half: the points within the threshold
-            thr = npts ? sor_threshold(sl.h_xyzr, npts, stddev_mul) : 0.0;
+            thr = npts ? sor_threshold(sl.h_xyzr, npts, stddev_mul, c->sor_sq) : 0.0;
             sl.h_args->sor_thr = thr;
             k_sor_select<<<sg, kBlock, 0, s>>>(fr);
             mark(c, "k_sor_select");

@@ -71,6 +71,7 @@ constexpr uint32_t kBucketCells = 1u << 17;     // grid cells a bucket may span 
 constexpr uint32_t kNbMin = 1024, kNbMax = 4096;   // buckets per frame a launch provides LDS for (grows on demand)
 constexpr uint32_t kScatThreads = 512, kScatItems = 8, kScatChunk = kScatThreads * kScatItems;   // k_bin_scatter: a tile in chunks of 4096
 constexpr uint32_t kCmapCells = 1u << 24;       // dense cell grid: largest grid (cells, margins included) with an occupancy map
+constexpr uint32_t kCoarseBits = 1u << 20;      // room for the blocks of 4x4x4 cells of the largest grid (partial blocks at the ends of y and z included)
 constexpr int kCellMargin = 3;                  // empty cells around the grid: 2 for the 5x5x5 stencil + 1 of slack (a centroid
                                                 // may round a hair outside the bounding box of its points)        // voxel key / id of a dropped (non-finite) point
 
@@ -219,6 +220,7 @@ struct Frame {
     DevPtr<uint8_t> cflag;            // one byte per grid cell: occupied?  all zero between frames
     DevPtr<uint2> cmap;               // per 32 cells: {occupancy bits, occupied cells before this word}
     DevPtr<uint32_t> ctile;           // scan tiles: popcount + 1 once known
+    DevPtr<uint32_t> ccoarse;         // one bit per block of 4x4x4 cells: any of them occupied?  (k-NN pass: far neighbours)
     // pinned host outputs
     DevPtr<DevState> h_state;
     DevPtr<uint32_t> h_offsets;       // n_kept + 1, discovery order

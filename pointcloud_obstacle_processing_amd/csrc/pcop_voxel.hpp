@@ -692,7 +692,9 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 //                     per-wave counts, chunks of kScatChunk points staged in LDS so that stores are contiguous)
 //   k_bucket_reduce : a bucket lives in LDS: occupancy bits of its key range -> local voxel ids (rank of the key),
 //                     stable counting sort by id, one lane per voxel sums its run in order from 0.0f and divides
-//                     by float(count); buckets publish their voxel counts and add up the lower ones -> output rank.
+//                     by float(count); the centroids stay at the bucket's place, the bucket publishes its voxel count
+//   k_bucket_scan   : exclusive scan of the buckets' voxel counts -> output rank of every bucket's first voxel, M
+//   k_voxel_gather  : (pcop_cells_grid.hpp) centroids to their ranks = voxel key order, grid cells marked on the way
 // Same float operations in the same order as the sort path.  No global atomics, no scattered global access: the
 // cloud is read three times (bounds, histogram, partition), written once and read once as 12-byte records.
 // Any bucket plan that respects the two limits gives the same result, so the host may tune gbits freely.

@@ -64,6 +64,17 @@ def test_degenerate_shapes_and_duplicates(ctx, oracle):
     check(ctx, oracle, tiny, 15, 1.0)
 
 
+@pytest.mark.parametrize("mean_k", [1, 2, 7, 14, 15, 16, 23, 31])
+def test_every_neighbour_count(ctx, oracle, mean_k):
+    """mean_k + 1 <= 16 and > 16 run different instances of the k-NN kernel (16 / 32 values in registers, the unused
+    places pre-filled); a dense blob is settled by the 27 cells around a point, the stragglers and the sparse shell
+    around it walk outwards shell by shell."""
+    rng = np.random.default_rng(40 + mean_k)
+    pts = np.concatenate([rng.normal(0, 0.05, (6000, 3)), rng.uniform(-2, 2, (300, 3)),
+                          np.array([[9.0, 9.0, 9.0], [-9.0, 9.0, -9.0]])]).astype(f32)
+    check(ctx, oracle, pts[rng.permutation(len(pts))], mean_k, 1.0)
+
+
 def test_empty_cloud_gives_empty_cloud(ctx):
     """sor2.filter on an empty input returns an empty cloud (od.cpp:316-340 after a bounds filter that kept nothing)."""
     got = ctx.statistical_outlier_removal(np.zeros((0, 3), dtype=f32), 15, 4.0)
