@@ -29,6 +29,11 @@ F=$(dirname $(find $O/pmc_FETCH_SIZE -name pmc_counter_collection.csv | head -1)
 W=$(dirname $(find $O/pmc_WRITE_SIZE -name pmc_counter_collection.csv | head -1))
 python3 tools/pmc_summary.py $F $W $B $O/pmc_traffic.json > $O/pmc_summary.txt
 head -14 $O/kernel_summary_batch$B.txt; head -10 $O/pmc_summary.txt; tail -3 $O/kernel_summary_single_frame.txt
+python3 tests/tools/config_report.py > $O/configs.txt 2> $O/configs.err
+python3 tests/tools/occ_bench.py > $O/occupancy.json
+python3 tests/tools/sor_bench.py > $O/sor.json
+python3 tests/tools/node_bench.py > $O/node_chain.json
+echo "configs / occupancy / sor / node chain done"
 python3 - <<PY
 import json; d=json.load(open("$O/bench.json")); print(d["value"], d["latency_ms_single_frame"], d["roofline"], d.get("cpu_baseline"), d.get("end_to_end"), d.get("parity"))
 PY
