@@ -337,6 +337,9 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames) {
     const float r2 = st->r2;
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+#ifdef PCOP_STAMPS
+        const unsigned long long t_0 = wall_clock64();
+#endif
         const uint4 ma = slot_meta[c];
         const uint32_t pa = ld_agent(parent + c);
         // round 1: the windows of all rows.  Every load is issued before any is used and none sits under a
@@ -385,7 +388,14 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames) {
                 }
             }
         }
+#ifdef PCOP_STAMPS
+        const unsigned long long t_1 = wall_clock64();
+        const uint32_t n_slow = (uint32_t)__popcll(__ballot(differs));
+        uint32_t n_pairs = 0, n_unions = 0, n_root = pa == c ? 1u : 0u;
+        if (differs && !scan_only) {
+#else
         if (!differs || scan_only) continue;
+#endif
         // some neighbour may be in another set: walk the rows again and look properly at those whose parent
         // word differs from the cell's (roots, pair test, union by CAS)
         uint32_t ra = uf_find(parent, c);
@@ -400,9 +410,29 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames) {
                 ra = uf_find(parent, ra);   // the cell's root may have been hung under another one meanwhile
                 if (rb == ra) continue;
                 const uint4 mb = slot_meta[id];
-                if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) { uf_union(parent, prio, ra, rb); ra = uf_find(parent, ra); }
+#ifdef PCOP_STAMPS
+                ++n_pairs;
+#endif
+                if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) { uf_union(parent, prio, ra, rb); ra = uf_find(parent, ra);
+#ifdef PCOP_STAMPS
+                    ++n_unions;
+#endif
+                }
             }
         }
+#ifdef PCOP_STAMPS
+        }
+        {   // diagnostic build (tools/union_stamps.py): per wave {fast part, slow part} in 10 ns ticks, lanes in the slow part,
+            // pair tests, unions, roots among the wave's cells; into rec_b, which a cluster-only frame does not use
+            const unsigned long long t_2 = wall_clock64();
+            uint32_t tp = n_pairs, tu = n_unions, tr = n_root;
+            for (int d = 32; d >= 1; d >>= 1) { tp += __shfl_down(tp, d, kWave); tu += __shfl_down(tu, d, kWave); tr += __shfl_down(tr, d, kWave); }
+            if (lane_id() == 0) {
+                uint32_t* dbg = reinterpret_cast<uint32_t*>(F.rec_b.get()) + 8u * (c >> 6);
+                dbg[0] = (uint32_t)(t_1 - t_0); dbg[1] = (uint32_t)(t_2 - t_1); dbg[2] = n_slow; dbg[3] = tp; dbg[4] = tu; dbg[5] = 0u; dbg[6] = tr;
+            }
+        }
+#endif
     }
 }
 
