@@ -200,6 +200,7 @@ void mark(pcop_ctx* c, const char* name) {
 
 uint32_t pow2_at_least(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
+constexpr uint32_t kFarBlocks = 1024;   // k_knn_far: 4096 waves share the points the first k-NN pass left over
 uint32_t stride_grid(uint32_t n) { return std::min(2048u, std::max(1u, div_up(n, kBlock))); }
 
 uint32_t bucket_of(const pcop_ctx* c, uint32_t n) {   // launch-size bucket: next power of two, at most cap
@@ -1406,9 +1407,9 @@ int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, 
     k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
     k_cell_place<<<tg, kBlock, 0, s>>>(fr);
     mark(c, "cell_grid");
-    if (mean_k + 1 <= 16) k_knn_mean<16><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
-    else k_knn_mean<32><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
-    mark(c, "k_knn_mean");
+    if (mean_k + 1 <= 16) { k_knn_mean<16><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); mark(c, "k_knn_mean"); k_knn_far<16><<<dim3(kFarBlocks, 1), kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); }
+    else { k_knn_mean<32><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); mark(c, "k_knn_mean"); k_knn_far<32><<<dim3(kFarBlocks, 1), kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); }
+    mark(c, "k_knn_far");
     k_emit<<<tg, kBlock, 0, s>>>(fr, 1u);
     mark(c, "k_emit");
     HIPCHK(c, hipGetLastError());
@@ -1600,9 +1601,9 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
             k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
             k_cell_place<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "sor_grid");
-            if (mean_k + 1 <= 16) k_knn_mean<16><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
-            else k_knn_mean<32><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u);
-            mark(c, "k_knn_mean");
+            if (mean_k + 1 <= 16) { k_knn_mean<16><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); mark(c, "k_knn_mean"); k_knn_far<16><<<dim3(kFarBlocks, 1), kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); }
+            else { k_knn_mean<32><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); mark(c, "k_knn_mean"); k_knn_far<32><<<dim3(kFarBlocks, 1), kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); }
+            mark(c, "k_knn_far");
             k_cells_reset<<<tg, kBlock, 0, s>>>(fr);
         }
         if ((rc = mid_state(fr))) break;

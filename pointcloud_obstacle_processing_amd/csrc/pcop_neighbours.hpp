@@ -16,9 +16,7 @@ namespace pcop {
 // ------------------------------------------------------------------------------------------
 constexpr int kKnnMax = 32;   // mean_k + 1 <= 32
 constexpr uint32_t kKnnBatch = 8;   // candidate records requested together
-constexpr int kKnnFineMax = 15;     // widest shell walked row by row (31 cells: at most two occupancy words per row)
-constexpr int kKnnRows = 8;         // rows of a shell whose occupancy words are requested together
-constexpr int kKnnQueue = 32;       // records a lane can hold back for the wave's common scan
+constexpr int kKnnFineMax = 15;     // k_knn_far: shells below this radius are walked cell row by cell row, the space beyond by blocks
 
 // best[] ascending; keeps the KCAP smallest of what it has seen (a compare-exchange chain, no indexing).  A search for
 // K < KCAP values starts with KCAP - K places at -inf, which nothing displaces: the K smallest then sit in the last K
@@ -85,8 +83,6 @@ __global__ __launch_bounds__(kBlock) void k_cmap_coarse(const Frame* frames) {
 // batched loads.  The grid's edge is sized so that these shells settle nearly every point.
 template <int KCAP>
 __global__ __launch_bounds__(kBlock) void k_knn_mean(const Frame* frames, uint32_t mean_k, double edge_arg, uint32_t out_sel) {
-    __shared__ uint32_t s_bits[2 * kKnnRows][kBlock], s_word[2 * kKnnRows][kBlock], s_before[2 * kKnnRows][kBlock];   // 48 KB: a batch of rows
-    __shared__ uint32_t s_queue[kKnnQueue][kBlock];   // 32 KB: per lane, the records of the occupied cells the batch turned up
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const float4* __restrict__ rec = F.rec_a;
@@ -95,17 +91,15 @@ __global__ __launch_bounds__(kBlock) void k_knn_mean(const Frame* frames, uint32
     const uint32_t* __restrict__ pt_slot = F.pt_slot;
     float* __restrict__ mean_out = out_sel ? reinterpret_cast<float*>(F.pt_root.get()) : F.cen_x.get();
     float* __restrict__ mean_host = out_sel ? F.h_aux.get() : nullptr;
+    uint32_t* __restrict__ far_list = F.idx_a;        // (idle until the clusters' CSR)
+    uint32_t* __restrict__ far_count = F.bin_total;   // zeroed by k_sor_setup
     if (cgrid_off(st)) return;
     const double edge = edge_arg > 0.0 ? edge_arg : 1.0 / st->inv_cell;
     const uint32_t n = st->c_n;
     const uint32_t K = mean_k + 1u;
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
-    const int d1 = (int)st->c_dim[1], d2 = (int)st->c_dim[2];
     const float inf = __uint_as_float(0x7F800000u);
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-#ifdef PCOP_STAMPS
-        const unsigned long long t_0 = wall_clock64();
-#endif
         const float4 q = rec[j];   // records are sorted by cell: neighbouring lanes search neighbouring cells
         const uint32_t idx = f2u(q.w);
         const uint32_t own = pt_slot[idx];
@@ -144,149 +138,15 @@ __global__ __launch_bounds__(kBlock) void k_knn_mean(const Frame* frames, uint32
             const double reach = fmax(edge - 1.0e-6 * edge, 0.0);
             settled = (double)best[KCAP - 1] <= reach * reach;   // inf (fewer than K seen) never is
         }
-#ifdef PCOP_STAMPS
-        const unsigned long long t_1 = wall_clock64();
-        const uint32_t n_unsettled = (uint32_t)__popcll(__ballot(!settled));
-#endif
-        if (!settled) {
-            // The others (outliers, mostly - the points this filter is there for) look further out, shell by shell.  A
-            // shell of radius r is (2r+1)^2 rows of cells along x: whole rows on four of its faces, the two end cells
-            // elsewhere; up to kKnnFineMax a row's window lies in at most two occupancy words.  The words of kKnnRows rows
-            // are requested together: a probe per row instead of one per cell, and eight in flight instead of one.
-            const int gz = (int)(pos / plane), gy = (int)((pos % plane) / rowbits), gx = (int)(pos % rowbits);
-            const double hair = 1.0e-6 * edge;
-            for (int r = 2; r <= kKnnFineMax && !settled; ++r) {
-                const int side = 2 * r + 1, nrows = side * side;
-                const int xlo = max(gx - r, 0), xhi = min(gx + r, (int)rowbits - 1);
-                const uint32_t wa = (uint32_t)xlo >> 5, wb = (uint32_t)xhi >> 5;
-                // window bits inside the two words: a whole row / its two ends
-                const uint32_t hi_a = wa == wb ? (uint32_t)xhi & 31u : 31u;
-                const uint32_t face_a = (0xFFFFFFFFu >> (31u - hi_a)) & (0xFFFFFFFFu << ((uint32_t)xlo & 31u));
-                const uint32_t face_b = wa == wb ? 0u : 0xFFFFFFFFu >> (31u - ((uint32_t)xhi & 31u));
-                const uint32_t bl = gx - r >= 0 ? 1u << ((uint32_t)(gx - r) & 31u) : 0u;
-                const uint32_t bh = gx + r <= (int)rowbits - 1 ? 1u << ((uint32_t)(gx + r) & 31u) : 0u;
-                const uint32_t ends_a = bl | (wa == wb ? bh : 0u), ends_b = wa == wb ? 0u : bh;
-                for (int r0 = 0; r0 < nrows; r0 += kKnnRows) {
-                    uint2 ea[kKnnRows], eb[kKnnRows];
-                    uint32_t ma[kKnnRows], mb[kKnnRows];
-#pragma unroll
-                    for (int u = 0; u < kKnnRows; ++u) {
-                        const int rho = r0 + u;
-                        const int cz = gz - r + rho / side, cy = gy - r + rho % side;
-                        const bool in = rho < nrows && cz >= 0 && cz < d2 && cy >= 0 && cy < d1;
-                        const bool face = abs(cz - gz) == r || abs(cy - gy) == r;
-                        const uint32_t rowword = in ? ((uint32_t)cz * plane + (uint32_t)cy * rowbits) >> 5 : 0u;
-                        ma[u] = in ? (face ? face_a : ends_a) : 0u;
-                        mb[u] = in ? (face ? face_b : ends_b) : 0u;
-                        ea[u] = cmap[rowword + wa];
-                        eb[u] = cmap[rowword + wb];
-                    }
-                    // the words with a cell in them are parked in LDS (a loop over them that is not unrolled needs an index) ...
-#pragma unroll
-                    for (int u = 0; u < kKnnRows; ++u) {
-                        s_bits[2 * u][threadIdx.x] = ea[u].x & ma[u]; s_word[2 * u][threadIdx.x] = ea[u].x; s_before[2 * u][threadIdx.x] = ea[u].y;
-                        s_bits[2 * u + 1][threadIdx.x] = eb[u].x & mb[u]; s_word[2 * u + 1][threadIdx.x] = eb[u].x; s_before[2 * u + 1][threadIdx.x] = eb[u].y;
-                    }
-                    // ... the records of the occupied cells found go on the lane's list (out there a cell holds a point or two) ...
-                    uint32_t queued = 0;
-                    for (int w = 0; w < 2 * kKnnRows; ++w) {
-                        uint32_t bits = s_bits[w][threadIdx.x];
-                        if (!bits) continue;
-                        const uint32_t word = s_word[w][threadIdx.x], before = s_before[w][threadIdx.x];
-                        while (bits) {
-                            const uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
-                            bits &= bits - 1u;
-                            const uint4 mc = slot_meta[before + __popc(word & ((1u << k) - 1u))];
-                            if (queued + mc.y <= (uint32_t)kKnnQueue) {
-                                for (uint32_t i = 0; i < mc.y; ++i) s_queue[queued + i][threadIdx.x] = mc.x + i;
-                                queued += mc.y;
-                            } else knn_scan_range<KCAP>(best, q, rec, mc.x, mc.y);   // (no room on the list: straight away)
-                        }
-                    }
-                    // ... and the lanes of the wave go through their lists side by side: the lanes find their cells at
-                    // different moments, and a scan started by one lane alone would cost the wave as much as one started by all
-                    // (a lane reads back only what it wrote itself: no barrier)
-                    for (uint32_t t = 0; __any(t < queued); t += kKnnBatch) {
-                        if (t < queued) {
-                            float4 c[kKnnBatch];
-#pragma unroll
-                            for (uint32_t u = 0; u < kKnnBatch; ++u) c[u] = rec[s_queue[min(t + u, queued - 1u)][threadIdx.x]];
-#pragma unroll
-                            for (uint32_t u = 0; u < kKnnBatch; ++u) {
-                                const float d = l2_simple(q, c[u]);
-                                if (t + u < queued && d < best[KCAP - 1]) knn_push(best, d);
-                            }
-                        }
-                    }
-                }
-                const double reach = fmax((double)r * edge - hair, 0.0);
-                settled = (double)best[KCAP - 1] <= reach * reach;
-            }
+        if (!settled) {   // for k_knn_far: one wave per such point
+            const uint64_t m = __ballot(true);
+            const uint32_t first = (uint32_t)__ffsll((long long)m) - 1u;
+            uint32_t base = 0;
+            if (lane_id() == first) base = atomicAdd(far_count, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+            far_list[base + (uint32_t)__popcll(m & lanemask_lt())] = j;
+            continue;
         }
-#ifdef PCOP_STAMPS
-        const unsigned long long t_2 = wall_clock64();
-#endif
-        if (!settled) {
-            // Beyond kKnnFineMax cells (a point alone in a large empty space): block by block.  A block is 4x4x4 cells with
-            // one bit in F.ccoarse, so empty space costs a 64th of the probes.  After the blocks within R blocks of the
-            // query's, every cell within 4R cells of the query's has been seen; the blocks within 3 hold nothing new.
-            const uint32_t* __restrict__ ccoarse = F.ccoarse;
-            const int gz = (int)(pos / plane), gy = (int)((pos % plane) / rowbits), gx = (int)(pos % rowbits);
-            const int bxq = gx >> 2, byq = gy >> 2, bzq = gz >> 2;
-            const int cdx = (int)(rowbits >> 2), cdy = (d1 + 3) >> 2, cdz = (d2 + 3) >> 2;
-            const int Rmax = max(cdx, max(cdy, cdz));
-            const double hair = 1.0e-6 * edge;
-            for (int R = (kKnnFineMax + 1) / 4; R <= Rmax; ++R) {
-                const int z0 = max(bzq - R, 0), z1 = min(bzq + R, cdz - 1);
-                const int y0 = max(byq - R, 0), y1 = min(byq + R, cdy - 1);
-                for (int bz = z0; bz <= z1; ++bz) {
-                    for (int by = y0; by <= y1; ++by) {
-                        const bool face = abs(bz - bzq) == R || abs(by - byq) == R;   // whole row on the shell, else its two ends
-                        const int step = face ? 1 : 2 * R;
-                        for (int bx = bxq - R; bx <= bxq + R; bx += step) {
-                            if (bx < 0 || bx >= cdx) continue;
-                            const uint32_t lin = ((uint32_t)bz * (uint32_t)cdy + (uint32_t)by) * (uint32_t)cdx + (uint32_t)bx;
-                            if (!((ccoarse[lin >> 5] >> (lin & 31u)) & 1u)) continue;
-                            for (int dz = 0; dz < 4; ++dz) {
-                                const int z = bz * 4 + dz;
-                                if (z >= d2) break;
-                                for (int dy = 0; dy < 4; ++dy) {
-                                    const int y = by * 4 + dy;
-                                    if (y >= d1) break;
-                                    const int far_yz = max(abs(y - gy), abs(z - gz));
-                                    const uint32_t at = (uint32_t)z * plane + (uint32_t)y * rowbits + (uint32_t)bx * 4u;   // 4 cells, never across words
-                                    const uint2 e = cmap[at >> 5];
-                                    const uint32_t bits = (e.x >> (at & 31u)) & 0xFu;
-                                    if (!bits) continue;
-                                    uint32_t id = e.y + __popc(e.x & ((1u << (at & 31u)) - 1u));
-                                    for (int k = 0; k < 4; ++k) {
-                                        if (!((bits >> k) & 1u)) continue;
-                                        const int far = max(abs(bx * 4 + k - gx), far_yz);   // cells between this one and the query's, the larger count over the axes
-                                        // far <= kKnnFineMax: seen already.  Otherwise nothing in the cell is nearer than
-                                        // (far - 1) edges, which rules it out once the K-th best is no larger.
-                                        const double lb = fmax((double)(far - 1) * edge - hair, 0.0);
-                                        if (far > kKnnFineMax && !((double)best[KCAP - 1] <= lb * lb)) {
-                                            const uint4 mc = slot_meta[id];
-                                            knn_scan_range<KCAP>(best, q, rec, mc.x, mc.y);
-                                        }
-                                        ++id;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                const double reach = fmax(4.0 * (double)R * edge - hair, 0.0);
-                if ((double)best[KCAP - 1] <= reach * reach) break;
-            }
-        }
-#ifdef PCOP_STAMPS
-        if (lane_id() == 0) {   // diagnostic build: per wave {phase 1, shells, blocks} in 10 ns ticks, lanes that went on
-            const unsigned long long t_3 = wall_clock64();
-            uint32_t* dbg = F.idx_b.get() + 4u * (j >> 6);
-            dbg[0] = (uint32_t)(t_1 - t_0); dbg[1] = (uint32_t)(t_2 - t_1); dbg[2] = (uint32_t)(t_3 - t_2); dbg[3] = n_unsettled;
-        }
-#endif
         // ascending order; the first (the query point itself in the reference's k + 1 search) is dropped
         double dist_sum = 0.0;
 #pragma unroll
@@ -294,6 +154,201 @@ __global__ __launch_bounds__(kBlock) void k_knn_mean(const Frame* frames, uint32
         const float mean = (float)(dist_sum / (double)mean_k);
         mean_out[idx] = mean;
         if (mean_host) mean_host[idx] = mean;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The points the 27 cells do not settle - outliers, mostly: the points this filter is there for - one WAVE each
+// (k_knn_mean listed them).  A lane that walks outwards alone pays a memory round trip per probe, and its 63
+// neighbours wait for it; here the lanes share the walk.  Shell r of cells around the point's cell is (2r+1)^2 rows
+// along x - whole rows on four of its faces, the two end cells elsewhere - and a row is one or more occupancy words:
+// the lanes take a (row, word) item each, the occupied cells found are put on a list in LDS, and the lanes take a cell
+// each from the list and scan its records into their own sorted list of the smallest distances (knn_push, as in
+// k_knn_mean).  After shell r every point not seen is farther than r edges, so the point is settled once mean_k + 1 of
+// the values the lanes hold are within that reach: one compare-and-count per shell.  From kKnnFineMax on the walk goes by
+// blocks of 4x4x4 cells with one bit each (k_cmap_coarse): a point alone in a large empty space probes a 64th.
+// At the end the K-th smallest value of the union of the lanes' lists is found by bisection on its bit pattern
+// (non-negative floats order like unsigned integers), the smaller ones are sorted by counting, and lane 0 adds the
+// square roots in ascending order in double, dropping the first - the reference's arithmetic.
+// ------------------------------------------------------------------------------------------
+constexpr int kFarRounds = 1;          // occupancy words a lane requests together (more only add index arithmetic: the shells are small)
+constexpr uint32_t kFarCells = 2048;   // cells a wave can list per round: 64 lanes x the 32 bits of an occupancy word
+
+template <int KCAP>
+__device__ __forceinline__ uint32_t knn_count_le(const float (&best)[KCAP], uint32_t bound_bits) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < KCAP; ++u) c += f2u(best[u]) <= bound_bits ? 1u : 0u;
+    return wave_sum(c);
+}
+
+// the lanes' cells of one round -> the wave's list, behind the `listed` entries it holds (the caller has made room)
+__device__ __forceinline__ void far_list_cells(uint32_t* s_cell, uint32_t listed, uint32_t incl, uint32_t word, uint32_t before, uint32_t bits) {
+    uint32_t at = listed + incl - (uint32_t)__popc(bits);
+    while (bits) {
+        const uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
+        bits &= bits - 1u;
+        s_cell[at++] = before + (uint32_t)__popc(word & ((1u << k) - 1u));
+    }
+}
+
+template <int KCAP>
+__device__ __forceinline__ void far_scan_cells(float (&best)[KCAP], const float4& q, const float4* __restrict__ rec,
+                                               const uint4* __restrict__ slot_meta, const uint32_t* s_cell, uint32_t total) {
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t ci = lane_id(); ci < total; ci += kWave) {
+        const uint4 mc = slot_meta[s_cell[ci]];
+        knn_scan_range<KCAP>(best, q, rec, mc.x, mc.y);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int KCAP>
+__global__ __launch_bounds__(kBlock) void k_knn_far(const Frame* frames, uint32_t mean_k, double edge_arg, uint32_t out_sel) {
+    __shared__ uint32_t s_cells[kWavesPerBlock][kFarCells];
+    __shared__ float s_vals[kWavesPerBlock][kKnnMax];
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = F.rec_a;
+    const uint2* __restrict__ cmap = F.cmap;
+    const uint32_t* __restrict__ ccoarse = F.ccoarse;
+    const uint4* __restrict__ slot_meta = F.slot_meta;
+    const uint32_t* __restrict__ pt_slot = F.pt_slot;
+    float* __restrict__ mean_out = out_sel ? reinterpret_cast<float*>(F.pt_root.get()) : F.cen_x.get();
+    float* __restrict__ mean_host = out_sel ? F.h_aux.get() : nullptr;
+    const uint32_t* __restrict__ far_list = F.idx_a;
+    if (cgrid_off(st)) return;
+    const uint32_t n_far = min(F.bin_total[0], st->c_n);
+    const double edge = edge_arg > 0.0 ? edge_arg : 1.0 / st->inv_cell;
+    const double hair = 1.0e-6 * edge;
+    const uint32_t K = mean_k + 1u;
+    const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
+    const int d1 = (int)st->c_dim[1], d2 = (int)st->c_dim[2];
+    const int cdx = (int)(rowbits >> 2), cdy = (d1 + 3) >> 2, cdz = (d2 + 3) >> 2;
+    const int rlast = max((int)rowbits, max(d1, d2));
+    const float inf = __uint_as_float(0x7F800000u);
+    const uint32_t lane = lane_id(), wv = threadIdx.x / kWave;
+    uint32_t* s_cell = s_cells[wv];
+    for (uint32_t w = blockIdx.x * kWavesPerBlock + wv; w < n_far; w += gridDim.x * kWavesPerBlock) {
+        const float4 q = rec[far_list[w]];
+        const uint32_t idx = f2u(q.w);
+        const uint32_t pos = slot_meta[pt_slot[idx]].w;
+        const int gz = (int)(pos / plane), gy = (int)((pos % plane) / rowbits), gx = (int)(pos % rowbits);
+        float best[KCAP];
+#pragma unroll
+        for (int t = 0; t < KCAP; ++t) best[t] = inf;
+        bool settled = false;
+        int r = 0;
+        // cell row by cell row
+        for (; r < kKnnFineMax && r <= rlast && !settled; ++r) {
+            const int side = 2 * r + 1, nrows = side * side;
+            const int xlo = max(gx - r, 0), xhi = min(gx + r, (int)rowbits - 1);
+            const int wa = xlo >> 5, nw = (xhi >> 5) - wa + 1;
+            const int nitems = nrows * nw;
+            uint32_t listed = 0;   // the cells of a shell are listed round by round and scanned together (when they fit)
+            for (int it0 = 0; it0 < nitems; it0 += kWave * kFarRounds) {   // kFarRounds words per lane requested together
+                uint2 e[kFarRounds];
+                uint32_t mask[kFarRounds];
+#pragma unroll
+                for (int u = 0; u < kFarRounds; ++u) {
+                    const int it = it0 + u * kWave + (int)lane;
+                    const int rho = it / nw, wi = wa + it % nw;
+                    const int cz = gz - r + rho / side, cy = gy - r + rho % side;
+                    const bool in = it < nitems && cz >= 0 && cz < d2 && cy >= 0 && cy < d1;
+                    const bool face = abs(cz - gz) == r || abs(cy - gy) == r;
+                    // the window's bits inside word wi: a whole row, or its two ends
+                    const int lo = max(xlo, wi * 32), hi = min(xhi, wi * 32 + 31);
+                    uint32_t m = 0u;
+                    if (face) m = (0xFFFFFFFFu >> (31 - (hi & 31))) & (0xFFFFFFFFu << (lo & 31));
+                    else {
+                        if (gx - r >= 0 && ((gx - r) >> 5) == wi) m |= 1u << ((gx - r) & 31);
+                        if (gx + r <= (int)rowbits - 1 && ((gx + r) >> 5) == wi) m |= 1u << ((gx + r) & 31);
+                    }
+                    mask[u] = in ? m : 0u;
+                    e[u] = cmap[in ? (((uint32_t)cz * plane + (uint32_t)cy * rowbits) >> 5) + (uint32_t)wi : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < kFarRounds; ++u) {
+                    const uint32_t bits = e[u].x & mask[u];
+                    const uint32_t incl = wave_incl_scan((uint32_t)__popc(bits));
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+                    if (listed + total > kFarCells) { far_scan_cells<KCAP>(best, q, rec, slot_meta, s_cell, listed); listed = 0; }
+                    far_list_cells(s_cell, listed, incl, e[u].x, e[u].y, bits);
+                    listed += total;
+                }
+            }
+            far_scan_cells<KCAP>(best, q, rec, slot_meta, s_cell, listed);
+            const double reach = fmax((double)r * edge - hair, 0.0);
+            settled = knn_count_le<KCAP>(best, f2u(__double2float_rd(reach * reach))) >= K;   // (float v <= double x  <=>  v <= x rounded down)
+        }
+        // block by block: after the blocks within R blocks of the point's, every cell within 4R cells has been seen; the
+        // cells nearer than kKnnFineMax were taken above.  (Rare, so every lane simply scans what its own blocks hold.)
+        for (int R = kKnnFineMax / 4; !settled && R <= max(cdx, max(cdy, cdz)); ++R) {
+            const int side = 2 * R + 1, nblk = side * side * side;
+            const int bxq = gx >> 2, byq = gy >> 2, bzq = gz >> 2;
+            for (int it0 = 0; it0 < nblk; it0 += kWave) {
+                const int it = it0 + (int)lane;
+                const int ox = it % side - R, oy = (it / side) % side - R, oz = it / (side * side) - R;
+                const int bx = bxq + ox, by = byq + oy, bz = bzq + oz;
+                if (!(it < nblk && max(abs(ox), max(abs(oy), abs(oz))) == R && bx >= 0 && bx < cdx && by >= 0 && by < cdy && bz >= 0 && bz < cdz)) continue;
+                const uint32_t lin = ((uint32_t)bz * (uint32_t)cdy + (uint32_t)by) * (uint32_t)cdx + (uint32_t)bx;
+                if (!((ccoarse[lin >> 5] >> (lin & 31u)) & 1u)) continue;
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int z = bz * 4 + rr / 4, y = by * 4 + rr % 4;
+                    if (z >= d2 || y >= d1) continue;
+                    const uint32_t at = (uint32_t)z * plane + (uint32_t)y * rowbits + (uint32_t)bx * 4u;   // 4 cells, never across words
+                    const uint2 e = cmap[at >> 5];
+                    const uint32_t four = (e.x >> (at & 31u)) & 0xFu;
+                    if (!four) continue;
+                    const int far_yz = max(abs(y - gy), abs(z - gz));
+                    uint32_t id = e.y + (uint32_t)__popc(e.x & ((1u << (at & 31u)) - 1u));
+                    for (int k = 0; k < 4; ++k) {
+                        if (!((four >> k) & 1u)) continue;
+                        if (max(abs(bx * 4 + k - gx), far_yz) >= kKnnFineMax) {   // (not seen yet)
+                            const uint4 mc = slot_meta[id];
+                            knn_scan_range<KCAP>(best, q, rec, mc.x, mc.y);
+                        }
+                        ++id;
+                    }
+                }
+            }
+            const double reach = fmax(4.0 * (double)R * edge - hair, 0.0);
+            settled = knn_count_le<KCAP>(best, f2u(__double2float_rd(reach * reach))) >= K;
+        }
+        // the K-th smallest of all the lanes' values: the smallest bit pattern T with at least K values <= T
+        uint32_t lo = 0u, hi = 0x7F800000u;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            if (knn_count_le<KCAP>(best, mid) >= K) hi = mid; else lo = mid + 1u;
+        }
+        const uint32_t T = lo;
+        // the values below T (fewer than K), sorted by counting
+        uint32_t below = 0;
+#pragma unroll
+        for (int u = 0; u < KCAP; ++u) below += f2u(best[u]) < T ? 1u : 0u;
+        const uint32_t incl = wave_incl_scan(below);
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);   // < K <= kKnnMax
+        uint32_t at = incl - below;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < KCAP; ++u) if (f2u(best[u]) < T) s_vals[wv][at++] = best[u];
+        __builtin_amdgcn_wave_barrier();
+        float mine = inf; uint32_t rank = 0;
+        if (lane < m) {
+            mine = s_vals[wv][lane];
+            for (uint32_t o = 0; o < m; ++o) { const float v = s_vals[wv][o]; rank += (v < mine || (v == mine && o < lane)) ? 1u : 0u; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < m) s_vals[wv][rank] = mine;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            double dist_sum = 0.0;
+            for (uint32_t t = 1; t < K; ++t) dist_sum += sqrt((double)(t < m ? s_vals[wv][t] : u2f(T)));
+            const float mean = (float)(dist_sum / (double)mean_k);
+            mean_out[idx] = mean;
+            if (mean_host) mean_host[idx] = mean;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -350,6 +405,7 @@ __global__ __launch_bounds__(kBlock) void k_sor_setup(Frame* frames, uint32_t nb
             st->inv_cell = 1.0 / edge;
         }
         st->cgrid_req = 1u;   // the k-NN pass runs on the dense cell grid whatever the cluster stage uses
+        F.bin_total[0] = 0u;  // k_knn_mean counts the points it leaves to k_knn_far here (the radix tables' totals are idle)
     }
     __syncthreads();
     cgrid_setup_block(F, n, n == 0u);
