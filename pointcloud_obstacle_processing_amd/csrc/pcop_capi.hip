@@ -330,8 +330,12 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             mark(c, "k_cgrid_hook");
             k_cell_compress<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "k_cell_compress");
-            k_cgrid_union<<<cg, kBlock, 0, s>>>(fr);
+            k_cgrid_union<<<cg, kBlock, 0, s>>>(fr, nf == 1 ? 1u : 0u);
             mark(c, "k_cgrid_union");
+            if (nf == 1) {   // one frame: the cells at tree borders get a wave each (a batch leaves them to their lanes)
+                k_cgrid_fix<<<cg, kBlock, 0, s>>>(fr, kFixWaveMax);
+                mark(c, "k_cgrid_fix");
+            }
         } else {
             const uint32_t hcap = hash_cap_for(nb);
             const dim3 hg(std::max(1u, hcap / kScanTile), nf);       // scan tiles over hash slots
@@ -944,6 +948,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         TRY(dev_alloc(c, &f.cmap, (size_t)kCmapCells / 32u + 1u));
         TRY(dev_alloc(c, &f.ctile, (size_t)kCmapCells / 32u / kVmapTile));
         TRY(dev_alloc(c, &f.ccoarse, (size_t)kCoarseBits / 32u));
+        TRY(dev_alloc(c, &f.counters, (size_t)16));
     }
     if (c->voxel_stream) {
         const size_t tiles = (n + kBinTileSmall - 1) / kBinTileSmall + 1;

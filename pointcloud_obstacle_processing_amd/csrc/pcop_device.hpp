@@ -221,6 +221,7 @@ struct Frame {
     DevPtr<uint2> cmap;               // per 32 cells: {occupancy bits, occupied cells before this word}
     DevPtr<uint32_t> ctile;           // scan tiles: popcount + 1 once known
     DevPtr<uint32_t> ccoarse;         // one bit per block of 4x4x4 cells: any of them occupied?  (k-NN pass: far neighbours)
+    DevPtr<uint32_t> counters;        // [0]: cells k_cgrid_union listed for k_cgrid_fix (k_cell_starts zeroes it)
     // pinned host outputs
     DevPtr<DevState> h_state;
     DevPtr<uint32_t> h_offsets;       // n_kept + 1, discovery order
