@@ -332,8 +332,8 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             mark(c, "k_cell_compress");
             k_cgrid_union<<<cg, kBlock, 0, s>>>(fr, nf == 1 ? 1u : 0u);
             mark(c, "k_cgrid_union");
-            if (nf == 1) {   // one frame: the cells at tree borders get a wave each (a batch leaves them to their lanes)
-                k_cgrid_fix<<<cg, kBlock, 0, s>>>(fr, kFixWaveMax);
+            if (nf == 1) {   // one frame: where it pays, the cells at tree borders get a wave each (fix_by_wave)
+                k_cgrid_fix<<<cg, kBlock, 0, s>>>(fr);
                 mark(c, "k_cgrid_fix");
             }
         } else {

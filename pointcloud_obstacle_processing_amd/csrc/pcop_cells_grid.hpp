@@ -324,10 +324,18 @@ __device__ __forceinline__ void union_row(int r, uint32_t at, uint32_t rowbits, 
     else { const int q = r - 3; *pos = at + (uint32_t)(1 + q / 5) * plane + (uint32_t)(q % 5 - 2) * rowbits - 2u; *width = 5u; }
 }
 
-// list: 1 = cells that see a neighbour of another tree go on the list of k_cgrid_fix (a single frame: latency counts);
-// 0 = the lane looks at those neighbours itself, here (a batch of frames: no further launch, and the waves that wait for a
-// walking lane cost nothing the other contexts' kernels could not use).
-__global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames, uint32_t list) {
+constexpr uint32_t kFixWaveMax = 1u << 16;   // cells of a frame up to which k_cgrid_fix may be asked for
+
+// Cells that see a neighbour of another tree: either the lane looks at those neighbours itself, here, or the cell goes on
+// the list of k_cgrid_fix, which gives it a wave.  The wave pays when a cell has many occupied neighbours to look at (a
+// surface sampled several points to the cell: 20 of the 62), not when the cells are sparse (a lane's walk is then short and
+// 62 lanes mostly idle), and only for a single frame, where latency counts: in a batch the waves that wait for a walking
+// lane cost nothing the other contexts' kernels could not use, while a wave per cell takes twenty times the wave-slot time.
+__device__ __forceinline__ bool fix_by_wave(const DevState* st, uint32_t single_frame) {
+    return single_frame && st->n_cells <= kFixWaveMax && st->c_n >= 3u * st->n_cells;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames, uint32_t single_frame) {
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const uint2* __restrict__ cmap = F.cmap;
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames, uin
     uint32_t* __restrict__ fix_count = F.counters;
     if (cgrid_off(st) || st->debug_skip_union == 1u) return;
     const bool scan_only = st->debug_skip_union == 2u;
+    const bool list = fix_by_wave(st, single_frame);
     const uint32_t nc = st->n_cells;
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
@@ -422,20 +431,9 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames, uin
     }
 }
 
-// The cells k_cgrid_union listed: roots, pair tests, unions by CAS.
-//   Up to kFixWaveMax cells a frame: one WAVE per cell, lane = one of the 62 forward neighbours (union_fixup, shared with the
-//   hash-table kernels).  A lane that walks a cell's neighbours alone pays a chain of dependent loads per neighbour while
-//   the other lanes of its wave wait; a clean voxel cloud lists a few hundred cells at cluster borders, a cloud with
-//   strays nearly every cell (each sees some unconnected stray), and in both cases there are far fewer listed cells than
-//   the chip has lanes.
-//   More than that (millions of cells in one tenuous component): a lane per cell, as there are then enough cells to fill
-//   the chip with lanes and a wave per cell would idle 50 of its 62 lanes.  The same holds for a batch of frames, where
-//   throughput counts, not the latency of one frame: a wave per cell takes twenty times the wave-slot time of a lane per
-//   cell, which the kernels of the other contexts in flight would have used.  wave_max: cells a frame may list for the
-//   wave-per-cell form (0: never).
-constexpr uint32_t kFixWaveMax = 1u << 16;
-
-__global__ __launch_bounds__(kBlock) void k_cgrid_fix(const Frame* frames, uint32_t wave_max) {
+// The cells k_cgrid_union listed (fix_by_wave): one WAVE per cell, lane = one of the 62 forward neighbours; roots, pair tests
+// side by side, unions by CAS one at a time (union_fixup, shared with the hash-table kernels).
+__global__ __launch_bounds__(kBlock) void k_cgrid_fix(const Frame* frames) {
     __shared__ float4 s_pa[kWavesPerBlock][kCellPtsCap];
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
@@ -445,54 +443,28 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_fix(const Frame* frames, uint3
     const uint32_t* __restrict__ prio = F.hmin;
     uint32_t* __restrict__ parent = F.parent;
     const uint32_t* __restrict__ fix_list = F.idx_a;
-    if (cgrid_off(st) || st->debug_skip_union) return;
+    if (cgrid_off(st) || st->debug_skip_union || !fix_by_wave(st, 1u)) return;
     const uint32_t count = min(F.counters[0], st->n_cells);
-    if (count == 0u) return;
     const float r2 = st->r2;
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
-    if (count <= wave_max) {
-        const uint32_t lane = lane_id(), wv = threadIdx.x / kWave;
-        int dx = 0, dy = 0, dz = 0;
-        const bool in = lane < (uint32_t)kStencil;
-        if (in) stencil_offset(lane, &dx, &dy, &dz);
-        const uint32_t off = (uint32_t)dz * plane + (uint32_t)dy * rowbits + (uint32_t)dx;   // (wraps like the signed sum)
-        for (uint32_t w = blockIdx.x * kWavesPerBlock + wv; w < count; w += gridDim.x * kWavesPerBlock) {
-            const uint32_t a = fix_list[w];
-            const uint4 ma = slot_meta[a];
-            const uint32_t pa = ld_agent(parent + a);
-            const uint32_t npos = ma.w + off;           // the grid's margins keep the whole stencil inside the array
-            const uint2 e = cmap[npos >> 5];
-            const bool occ = in && ((e.x >> (npos & 31u)) & 1u);
-            const uint32_t b = occ ? e.y + (uint32_t)__popc(e.x & ((1u << (npos & 31u)) - 1u)) : a;
-            bool need = occ && ld_agent(parent + b) != pa;
-            if (!__any(need)) continue;
-            const uint32_t ra = uf_find(parent, a);
-            need = need && uf_find(parent, b) != ra;
-            if (__any(need)) union_fixup(rec, slot_meta, prio, parent, s_pa[wv], a, ma.x, ma.y, b, need, r2);
-        }
-        return;
-    }
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const uint32_t c = fix_list[i];
-        const uint4 ma = slot_meta[c];
-        const uint32_t pa = ld_agent(parent + c);
-        uint32_t ra = uf_find(parent, c);
-#pragma unroll 1
-        for (int r = 0; r < 13; ++r) {
-            uint32_t pos, width, id;
-            union_row(r, ma.w, rowbits, plane, &pos, &width);
-            uint32_t left = (uint32_t)__popc(row_window(cmap, pos, width, &id));
-            for (; left; --left, ++id) {
-                const uint32_t pb = ld_agent(parent + id);
-                if (pb == pa || pb == ra) continue;
-                const uint32_t rb = uf_find(parent, id);
-                if (rb == ra) continue;
-                ra = uf_find(parent, ra);   // the cell's root may have been hung under another one meanwhile
-                if (rb == ra) continue;
-                const uint4 mb = slot_meta[id];
-                if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) { uf_union(parent, prio, ra, rb); ra = uf_find(parent, ra); }
-            }
-        }
+    const uint32_t lane = lane_id(), wv = threadIdx.x / kWave;
+    int dx = 0, dy = 0, dz = 0;
+    const bool in = lane < (uint32_t)kStencil;
+    if (in) stencil_offset(lane, &dx, &dy, &dz);
+    const uint32_t off = (uint32_t)dz * plane + (uint32_t)dy * rowbits + (uint32_t)dx;   // (wraps like the signed sum)
+    for (uint32_t w = blockIdx.x * kWavesPerBlock + wv; w < count; w += gridDim.x * kWavesPerBlock) {
+        const uint32_t a = fix_list[w];
+        const uint4 ma = slot_meta[a];
+        const uint32_t pa = ld_agent(parent + a);
+        const uint32_t npos = ma.w + off;           // the grid's margins keep the whole stencil inside the array
+        const uint2 e = cmap[npos >> 5];
+        const bool occ = in && ((e.x >> (npos & 31u)) & 1u);
+        const uint32_t b = occ ? e.y + (uint32_t)__popc(e.x & ((1u << (npos & 31u)) - 1u)) : a;
+        bool need = occ && ld_agent(parent + b) != pa;
+        if (!__any(need)) continue;
+        const uint32_t ra = uf_find(parent, a);
+        need = need && uf_find(parent, b) != ra;
+        if (__any(need)) union_fixup(rec, slot_meta, prio, parent, s_pa[wv], a, ma.x, ma.y, b, need, r2);
     }
 }
 
