@@ -111,6 +111,7 @@ struct pcop_ctx {
     // kNbMax buckets, or a coarse bin above a bucket's capacity even with the finest bins) is re-run on the sort
     // path and the context stays there until the leaf size changes
     bool voxel_stream = true, stream_ok = true;
+    bool csr_onepass = true;         // PCOP_CSR_ONEPASS=0: the three-kernel form of the CSR partition also for a single pass
     uint32_t nb_cap = kNbMin;                               // buckets the launch provides LDS and blocks for (grows on demand)
     uint32_t gbits = 13;                                    // log2 of the coarse key bins (tuned from the fullest bin seen; any value gives the same result)
     bool gbits_fixed = false;                               // PCOP_BIN_BITS given: no tuning
@@ -281,8 +282,6 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             if (c->lds_ordered) k_bucket_reduce<true><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
             else k_bucket_reduce<false><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_bucket_reduce");
-            k_bucket_scan<<<dim3(1, nf), kBinThreads, 0, s>>>(fr);
-            mark(c, "k_bucket_scan");
             k_voxel_gather<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);   // (also marks the grid cells of a chain frame: see marks_cells below)
             mark(c, "k_voxel_gather");
         } else {
@@ -358,7 +357,11 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
         mark(c, "k_cell_flatten");
         k_kept_apply<<<sg, kBlock, 0, s>>>(fr, c->npass_csr, (uint32_t)MAXB);
         mark(c, "k_kept_apply");
-        for (uint32_t p = 0; p < c->npass_csr; ++p) {
+        if (nf == 1 && c->npass_csr == 1 && MAXB == kNarrowBits && c->csr_onepass) {   // one frame, at most 255 kept clusters: one kernel
+            // (a batch keeps the three launches: tiles that wait for lower tiles hold wave slots the other contexts' kernels want)
+            k_csr_onepass<<<pg, kBlock, 0, s>>>(fr);
+            mark(c, "k_csr_onepass");
+        } else for (uint32_t p = 0; p < c->npass_csr; ++p) {
             k_csr_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
             mark(c, "k_csr_hist");
             k_table_scan<<<dim3(kBinsGrid, nf), kBlock, 0, s>>>(fr, 2, (int)p);
@@ -960,7 +963,6 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         TRY(dev_alloc(c, &f.tcnt, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.tbase, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.bucket_pub, (size_t)kNbMax));
-        TRY(dev_alloc(c, &f.vbase, (size_t)kNbMax + 1));
     }
     TRY(host_alloc(c, &sl.h_args, 1));
     TRY(host_alloc(c, &sl.h_state, 1));
@@ -1034,6 +1036,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     c->maxbits = c->radix_bits_target <= kNarrowBits ? kNarrowBits : kMaxBits;
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char* e = getenv("PCOP_VOXEL_PATH")) c->voxel_stream = std::string(e) != "sort";
+    if (const char* e = getenv("PCOP_CSR_ONEPASS")) c->csr_onepass = atoi(e) != 0;
     if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
     if (const char* e = getenv("PCOP_BIN_BITS")) { c->gbits = (uint32_t)std::min<int>(kBinBitsMax, std::max<int>(kBinBitsMin, atoi(e))); c->gbits_fixed = true; }
     if (const char* e = getenv("PCOP_CELL_BLOCKS")) c->cell_blocks = (uint32_t)std::max(64, atoi(e));

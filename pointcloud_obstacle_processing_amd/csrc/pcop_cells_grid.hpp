@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
 // so the chain has no k_cell_mark launch.  One block per bucket.  A frame the voxel grid passed through (or gave no voxels)
 // has no buckets: its cell stage sees the input cloud, marked here by all blocks together.
 __global__ __launch_bounds__(kBlock) void k_voxel_gather(Frame* frames) {
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
@@ -120,10 +121,17 @@ __global__ __launch_bounds__(kBlock) void k_voxel_gather(Frame* frames) {
     CellMarker mark;
     if (cells) mark.init(st);
     if (st->vpath && st->n_valid && !st->passthrough) {
-        const uint32_t b = blockIdx.x;
-        if (b >= st->nbuckets) return;
+        const uint32_t b = blockIdx.x, nb = st->nbuckets;
+        if (b >= nb) return;
+        const uint32_t* __restrict__ bucket_pub = F.bucket_pub;
+        // output rank of the bucket's first voxel = voxels of the buckets before it (a few hundred words: every block adds
+        // them up for itself rather than wait for a scan kernel); the last bucket's block knows M
+        uint32_t before = 0;
+        for (uint32_t i = threadIdx.x; i < b; i += kBlock) before += bucket_pub[i];
+        const uint32_t base = block_sum(before, s_w);
         const float4* __restrict__ scratch = F.rec_b;
-        const uint32_t first = F.binfo[b].x, nvox = F.bucket_pub[b], base = F.vbase[b];
+        const uint32_t first = F.binfo[b].x, nvox = bucket_pub[b];
+        if (b == nb - 1u && threadIdx.x == 0) finish_voxel(st, base + nvox);
         for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
             const float4 p = scratch[first + v];
             const uint32_t i = base + v;

@@ -12,7 +12,7 @@
 //     k_bin_scatter           ONE stable partition of packed 12-byte xyz records by bucket
 //     k_bucket_reduce         per bucket: occupancy bits in LDS -> local voxel ids, stable LDS counting
 //                             sort, one lane per voxel sums its run in order -> the bucket's centroids
-//     k_bucket_scan, k_voxel_gather  buckets' voxel counts -> output ranks, M; centroids to their ranks (and, in a
+//     k_voxel_gather          buckets' voxel counts -> output ranks, M; centroids to their ranks (and, in a
 //                             chain frame on the dense cell grid, each marks its grid cell on the way)
 //    sort path (fallback for grids or voxel counts the streaming path does not cover):
 //     k_radix_hist / k_table_scan / k_radix_scatter   (x passes) stable LSD radix partition of
@@ -215,7 +215,6 @@ struct Frame {
     uint32_t tstride, cap;            // tiles a context provides for, rounded up to a multiple of 8; points a slot provides for
     DevPtr<float> h_aux;              // pinned host: per-point values a call hands to the host (mean neighbour distances)
     DevPtr<uint32_t> bucket_pub;      // [bucket]: its voxel count
-    DevPtr<uint32_t> vbase;           // [bucket]: output rank of its first voxel
     // dense cell grid (null when the context was created without it)
     DevPtr<uint8_t> cflag;            // one byte per grid cell: occupied?  all zero between frames
     DevPtr<uint2> cmap;               // per 32 cells: {occupancy bits, occupied cells before this word}

@@ -693,8 +693,8 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 //   k_bucket_reduce : a bucket lives in LDS: occupancy bits of its key range -> local voxel ids (rank of the key),
 //                     stable counting sort by id, one lane per voxel sums its run in order from 0.0f and divides
 //                     by float(count); the centroids stay at the bucket's place, the bucket publishes its voxel count
-//   k_bucket_scan   : exclusive scan of the buckets' voxel counts -> output rank of every bucket's first voxel, M
-//   k_voxel_gather  : (pcop_cells_grid.hpp) centroids to their ranks = voxel key order, grid cells marked on the way
+//   k_voxel_gather  : (pcop_cells_grid.hpp) the voxels of the lower buckets added up -> output rank of the bucket's first
+//                     voxel, M; centroids to their ranks = voxel key order, grid cells marked on the way
 // Same float operations in the same order as the sort path.  No global atomics, no scattered global access: the
 // cloud is read three times (bounds, histogram, partition), written once and read once as 12-byte records.
 // Any bucket plan that respects the two limits gives the same result, so the host may tune gbits freely.
@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     uint32_t ttot;
     uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
     const uint32_t nvox = ttot >> 16;
-    if (threadIdx.x == 0) bucket_pub[b] = nvox;   // k_bucket_scan turns the counts into output ranks
+    if (threadIdx.x == 0) bucket_pub[b] = nvox;   // k_voxel_gather adds the counts up to output ranks
     {
         uint32_t ro[4], vo[4];
 #pragma unroll
@@ -1481,27 +1481,6 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     PCOP_STAMP(F, 2, 20, 150);
     __syncthreads();   // the next bucket clears and fills the same LDS
     }
-}
-
-// Output rank of every bucket's first voxel (exclusive scan of the buckets' voxel counts), and M.  One block per frame.
-__global__ __launch_bounds__(kBinThreads) void k_bucket_scan(Frame* frames) {
-    constexpr int NW = kBinThreads / kWave;
-    constexpr uint32_t kPer = kNbMax / kBinThreads;   // 4 consecutive buckets per thread
-    __shared__ uint32_t s_w[NW];
-    Frame& F = frames[blockIdx.y];
-    DevState* st = &F.st;
-    const uint32_t* __restrict__ bucket_pub = F.bucket_pub;
-    uint32_t* __restrict__ vbase = F.vbase;
-    if (stream_off(st)) return;
-    const uint32_t nb = st->nbuckets;
-    uint32_t v[kPer], sum = 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) { const uint32_t b = threadIdx.x * kPer + k; v[k] = b < nb ? bucket_pub[min(b, kNbMax - 1u)] : 0u; sum += v[k]; }
-    uint32_t m;
-    uint32_t run = block_excl_scan_n<NW>(sum, s_w, &m);
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) { const uint32_t b = threadIdx.x * kPer + k; if (b < nb) vbase[b] = run; run += v[k]; }
-    if (threadIdx.x == 0) finish_voxel(st, m);
 }
 
 // ------------------------------------------------------------------------------------------
