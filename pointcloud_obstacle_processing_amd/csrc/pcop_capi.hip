@@ -115,6 +115,7 @@ struct pcop_ctx {
     uint32_t nb_cap = kNbMin;                               // buckets the launch provides LDS and blocks for (grows on demand)
     uint32_t gbits = 13;                                    // log2 of the coarse key bins (tuned from the fullest bin seen; any value gives the same result)
     bool gbits_fixed = false;                               // PCOP_BIN_BITS given: no tuning
+    bool heavy_ok = false;           // streaming voxel path: k_heavy_split is in the launch sequence (a frame had a coarse bin above a bucket at the finest bins)
     // LDS atomic adds of one wave instruction return their old values in lane order on this device (checked by
     // k_lds_order_probe when the context is made; PCOP_LDS_ORDER=0 skips the check and keeps the peer-mask ranks)
     bool lds_ordered = false;
@@ -279,6 +280,10 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
                 else k_bin_scatter<8, false><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr);
             }
             mark(c, "k_bin_scatter");
+            if (c->heavy_ok) {   // (only once a frame needed it: an ordinary cloud has no bin above a bucket)
+                k_heavy_split<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
+                mark(c, "k_heavy_split");
+            }
             if (c->lds_ordered) k_bucket_reduce<true><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
             else k_bucket_reduce<false><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_bucket_reduce");
@@ -400,7 +405,7 @@ uint32_t fill_frame_args(pcop_ctx* c) {
         a.min_cluster = (uint32_t)p.min_cluster; a.max_cluster = (uint32_t)p.max_cluster;
         a.emit_cloud = c->emit_cloud ? 1u : 0u; a.out_layout = (uint32_t)c->out_layout; a.out_soa_stride = sl.n; a.debug_skip_union = c->debug_skip_union;
         a.voxel_stream = stream_on(c) ? 1u : 0u; a.nb_cap = c->nb_cap; a.cell_grid = grid_on(c) ? 1u : 0u; a.gbits = c->gbits;
-        a.tile = 0u; a.pad0 = 0u;   // set below, once the launch bucket is known
+        a.tile = 0u; a.heavy_ok = c->heavy_ok ? 1u : 0u;   // (tile: set below, once the launch bucket is known)
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         a.n_dev = f == 0 ? c->cur_n_dev : nullptr; a.sor_thr = 0.0;
         nmax = std::max(nmax, sl.n);
@@ -420,7 +425,7 @@ int enqueue_batch(pcop_ctx* c) {
         HIPCHK(c, hipGetLastError());
     } else {
         const bool st_on = stream_on(c);
-        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? tile_for(nb, c->nframes) : 0u, st_on ? 1u : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
+        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? tile_for(nb, c->nframes) : 0u, st_on ? (c->heavy_ok ? 2u : 1u) : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
                            grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
@@ -542,7 +547,10 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
                     if (hs->err & kErrReplanCtiles) c->ctiles = std::max(c->ctiles, std::min(kCmapCells / 32u / kVmapTile, pow2_at_least(div_up(hs->cmap_words, kVmapTile)) * 2u));
                 }
             }
-            if ((e & kErrReplanBins) && (c->gbits >= kBinBitsMax || c->gbits_fixed)) e |= kErrReplanPath;   // the finest bins are still too coarse
+            if ((e & kErrReplanBins) && (c->gbits >= kBinBitsMax || c->gbits_fixed)) {   // the finest bins are still too coarse:
+                if (!c->heavy_ok && !(e & kErrReplanPath)) { c->heavy_ok = true; e &= ~(uint32_t)kErrReplanBins; }   // bins above a bucket get split (k_heavy_split)
+                else e |= kErrReplanPath;
+            }
             if (e & kErrReplanPath) {
                 c->stream_ok = false;            // this cloud does not fit the streaming voxel path: sort path from here on
                 c->npass_voxel = kMaxPasses;     // (its own plan check then trims the pass count)
@@ -963,6 +971,8 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         TRY(dev_alloc(c, &f.tcnt, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.tbase, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.bucket_pub, (size_t)kNbMax));
+        TRY(dev_alloc(c, &f.hsub, ((size_t)kNbMax + 1) * kHeavyGroups));
+        TRY(dev_alloc(c, &f.hparts, (size_t)kNbMax + 1));
     }
     TRY(host_alloc(c, &sl.h_args, 1));
     TRY(host_alloc(c, &sl.h_state, 1));
@@ -1103,7 +1113,7 @@ int pcop_max_frames(const pcop_ctx* c) { return c ? (int)c->max_frames : 0; }
 int pcop_set_params(pcop_ctx* c, const pcop_params* p) {
     if (!c || !p) return PCOP_ERR_ARG;
     if (c->in_flight) { c->err = "parameters cannot change while a batch is in flight (its re-planning and ordering read them)"; return PCOP_ERR_STATE; }
-    if (!c->params_set || p->leaf != c->params.leaf) c->stream_ok = true;   // a new leaf size is a new voxel grid
+    if (!c->params_set || p->leaf != c->params.leaf) { c->stream_ok = true; c->heavy_ok = false; }   // a new leaf size is a new voxel grid
     if (!c->params_set || p->tol != c->params.tol) c->cgrid_ok = true;      // a new tolerance is a new cell grid
     c->params = *p;
     c->params_set = true;

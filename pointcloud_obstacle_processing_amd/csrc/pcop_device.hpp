@@ -68,6 +68,9 @@ constexpr uint32_t kBinThreads = 1024;          // threads of k_bin_hist / k_bin
 constexpr uint32_t kBinBitsMin = 11, kBinBitsMax = 14;   // coarse key bins per frame: 2^11 .. 2^14 (a host hint; any value gives the same result)
 constexpr uint32_t kBucketCap = 2048;           // points per bucket (k_bucket_reduce: 256 threads x 8 records, all in LDS)
 constexpr uint32_t kBucketCells = 1u << 17;     // grid cells a bucket may span (bits of its LDS occupancy map)
+constexpr uint32_t kHeavyMax = 4u * 2048u;       // points of a coarse bin that holds more than a bucket and is split by k_heavy_split (beyond: sort path)
+constexpr uint32_t kHeavyGroups = 16;           // ... into at most this many buckets
+constexpr uint32_t kHeavySub = 2048;            // ... along this many key sub-ranges
 constexpr uint32_t kNbMin = 1024, kNbMax = 4096;   // buckets per frame a launch provides LDS for (grows on demand)
 constexpr uint32_t kScatThreads = 512, kScatItems = 8, kScatChunk = kScatThreads * kScatItems;   // k_bin_scatter: a tile in chunks of 4096
 constexpr uint32_t kCmapCells = 1u << 24;       // dense cell grid: largest grid (cells, margins included) with an occupancy map
@@ -129,7 +132,7 @@ struct FrameArgs {
     uint32_t emit_cloud, out_layout, out_soa_stride, debug_skip_union;
     uint32_t voxel_stream, nb_cap;            // streaming voxel path requested; buckets the launch has LDS for
     uint32_t cell_grid, gbits;                // dense cell grid requested (else: the hash table of cells); log2 of the coarse bins wanted
-    uint32_t tile, pad0;                      // streaming voxel path: points per tile (kBinTile or kBinTileSmall)
+    uint32_t tile, heavy_ok;                  // streaming voxel path: points per tile (kBinTile or kBinTileSmall); k_heavy_split is in the launch sequence
     DevPtr<const float> src_x, src_y, src_z;
     DevPtr<const uint32_t> n_dev;             // when set: the point count lives on the device (at most n): the cloud a previous kernel kept
     double sor_thr;                           // statistical outlier removal: mean + stddev_mul * sigma, formed by the host between the two halves of the node chain
@@ -215,6 +218,8 @@ struct Frame {
     uint32_t tstride, cap;            // tiles a context provides for, rounded up to a multiple of 8; points a slot provides for
     DevPtr<float> h_aux;              // pinned host: per-point values a call hands to the host (mean neighbour distances)
     DevPtr<uint32_t> bucket_pub;      // [bucket]: its voxel count
+    DevPtr<uint4> hsub;               // [bucket][kHeavyGroups]: the buckets a heavy bucket was split into (binfo's fields)
+    DevPtr<uint32_t> hparts;          // [bucket]: how many
     // dense cell grid (null when the context was created without it)
     DevPtr<uint8_t> cflag;            // one byte per grid cell: occupied?  all zero between frames
     DevPtr<uint2> cmap;               // per 32 cells: {occupancy bits, occupied cells before this word}

@@ -844,7 +844,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
     for (int i = 0; i < NW; ++i) maxbin = max(maxbin, s_max[i]);
     if (threadIdx.x == 0) st->maxbin = maxbin;
     const uint32_t bmax = min(G, kBucketCells >> cs);   // bins a bucket may span
-    if (maxbin > kBucketCap || bmax == 0u) {            // bins too coarse for this cloud: the host asks for finer ones
+    // A bin with more points than a bucket: finer bins are asked for; when there are none finer (a dense sheet of points
+    // lying in a few rows of the key space) the bin becomes a bucket of its own - the window rule below does that by
+    // itself - which k_heavy_split cuts into buckets along the keys before k_bucket_reduce sees it.
+    const bool finest = st->gbits >= kBinBitsMax || cs == 0u;
+    if (bmax == 0u || (maxbin > kBucketCap && !(finest && (*F.args).heavy_ok && maxbin <= kHeavyMax))) {
         if (threadIdx.x == 0) atomicOr(&st->err, (uint32_t)kErrReplanBins);
         return;
     }
@@ -1266,6 +1270,141 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
     }
 }
 
+// A bucket with more than kBucketCap points (a single coarse bin, k_bin_plan) is cut into buckets that fit: counts of up
+// to kHeavySub equal key sub-ranges, sub-ranges packed greedily into groups of at most kBucketCap points, the records
+// partitioned by group - stably, so that index order survives - through the centroid planes (idle until k_voxel_gather)
+// and written back over the bucket's records.  hsub[b][g] then describes group g the way binfo describes a bucket, and
+// k_bucket_reduce runs them one after the other.  One block per bucket; blocks of ordinary buckets return at once.
+__global__ __launch_bounds__(kBlock) void k_heavy_split(Frame* frames) {
+    __shared__ uint32_t s_cnt[kHeavySub];
+    __shared__ uint8_t s_grp[kHeavySub];
+    __shared__ uint32_t s_goff[kHeavyGroups + 1], s_gsub[kHeavyGroups + 1], s_cur[kHeavyGroups];
+    __shared__ uint32_t s_hist[kWavesPerBlock * kHeavyGroups];
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    __shared__ uint32_t s_ng;
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    if (stream_off(st)) return;
+    const uint32_t b = blockIdx.x;
+    if (b >= st->nbuckets) return;
+    const uint4 info = F.binfo[b];
+    if (info.y <= kBucketCap) return;
+    Rec3* __restrict__ recs = reinterpret_cast<Rec3*>(F.rec_a.get());
+    float* __restrict__ tx = F.cen_x; float* __restrict__ ty = F.cen_y; float* __restrict__ tz = F.cen_z;
+    const uint32_t first = info.x, C = info.y, key_lo = info.z, span = info.w;
+    uint32_t hs = 0u;
+    while (((span + (1u << hs) - 1u) >> hs) > kHeavySub) ++hs;
+    const uint32_t nsub = (span + (1u << hs) - 1u) >> hs;
+    VoxelKey key; key.init(st);
+    for (uint32_t i = threadIdx.x; i < kHeavySub; i += kBlock) s_cnt[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < C; i += kBlock) {
+        const uint32_t lk = key(recs[first + i]) - key_lo;
+        atomicAdd(&s_cnt[min(lk >> hs, nsub - 1u)], 1u);
+    }
+    __syncthreads();
+    // Groups of consecutive sub-ranges with at most kBucketCap points each, by a window rule (no serial walk): a sub-range
+    // belongs to window (points before it) / (kBucketCap / 2); the sub-ranges that start in one window hold less than
+    // half a capacity plus the last one, and no sub-range may hold more than half a capacity itself (else: sort path), so
+    // a window is a group.  Thread t owns the 8 consecutive sub-ranges from 8 t.
+    {
+        constexpr uint32_t kPer = kHeavySub / kBlock;   // 8
+        constexpr uint32_t kHalf = kBucketCap / 2u;
+        uint32_t c[kPer], csum = 0u, cmax = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) { c[k] = s_cnt[threadIdx.x * kPer + k]; csum += c[k]; cmax = max(cmax, c[k]); }
+        uint32_t total;
+        const uint32_t p0 = block_excl_scan(csum, s_w, &total);
+        __syncthreads();   // (s_cnt is read; it now takes the points before each sub-range)
+        uint32_t r = p0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) { s_cnt[threadIdx.x * kPer + k] = r; r += c[k]; }
+        __syncthreads();
+        // a group starts at sub-range i (with points, or i = 0) when its window differs from that of the sub-range before it
+        uint32_t starts = 0u, nst = 0u;
+        r = p0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t i = threadIdx.x * kPer + k;
+            const bool st_here = i < nsub && (i == 0u || r / kHalf != s_cnt[i - 1u] / kHalf);
+            if (st_here) { starts |= 1u << k; ++nst; }
+            r += c[k];
+        }
+        uint32_t ngroups;
+        uint32_t g = block_excl_scan(nst, s_w, &ngroups);
+        const bool bad = __syncthreads_or((cmax > kHalf || ngroups > kHeavyGroups) ? 1 : 0) != 0;
+        r = p0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t i = threadIdx.x * kPer + k;
+            if ((starts >> k) & 1u) { if (!bad) { s_gsub[g] = i; s_goff[g] = r; } ++g; }
+            if (i < nsub) s_grp[i] = (uint8_t)(g - 1u);
+            r += c[k];
+        }
+        if (threadIdx.x == 0) {
+            if (bad) atomicOr(&st->err, (uint32_t)kErrReplanPath);   // the sort path takes any cloud
+            else { s_gsub[ngroups] = nsub; s_goff[ngroups] = C; }
+            s_ng = bad ? 0u : ngroups;
+        }
+    }
+    if (threadIdx.x < kHeavyGroups) s_cur[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t ng = s_ng;
+    if (ng == 0u) { if (threadIdx.x == 0) F.hparts[b] = 0u; return; }
+    const uint32_t w = threadIdx.x / kWave, lane = lane_id();
+    uint32_t* hist_w = s_hist + w * kHeavyGroups;
+    constexpr uint32_t kItemsH = 8u, kChunkH = kBlock * kItemsH;
+    for (uint32_t cb = 0; cb < C; cb += kChunkH) {
+        for (uint32_t i = threadIdx.x; i < kWavesPerBlock * kHeavyGroups; i += kBlock) s_hist[i] = 0u;
+        __syncthreads();
+        Rec3 rec[kItemsH];
+        uint32_t grp[kItemsH], lrank[kItemsH];
+        const uint32_t pbase = cb + w * (kItemsH * kWave) + lane;   // position in the bucket = index order
+#pragma unroll
+        for (uint32_t j = 0; j < kItemsH; ++j) rec[j] = recs[first + min(pbase + j * kWave, C - 1u)];
+#pragma unroll
+        for (uint32_t j = 0; j < kItemsH; ++j) {
+            const bool active = pbase + j * kWave < C;
+            const uint32_t lk = key(rec[j]) - key_lo;
+            const uint32_t g = active ? (uint32_t)s_grp[min(lk >> hs, nsub - 1u)] : 0u;
+            const uint64_t peers = match_digit(g, 7u, active);   // kHeavyGroups <= 128
+            const uint32_t rank = (uint32_t)__popcll(peers & lanemask_lt());
+            uint32_t old = 0u;
+            if (active) old = hist_w[g];
+            if (active && rank == 0u) hist_w[g] = old + (uint32_t)__popcll(peers);
+            grp[j] = g; lrank[j] = old + rank;
+        }
+        __syncthreads();
+        if (threadIdx.x < kHeavyGroups) {   // per group: where each wave's records go, the group's cursor moved past the chunk
+            uint32_t run = s_cur[threadIdx.x];
+#pragma unroll
+            for (uint32_t q = 0; q < (uint32_t)kWavesPerBlock; ++q) { const uint32_t t = s_hist[q * kHeavyGroups + threadIdx.x]; s_hist[q * kHeavyGroups + threadIdx.x] = run; run += t; }
+            s_cur[threadIdx.x] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < kItemsH; ++j) {
+            if (pbase + j * kWave < C) {
+                const uint32_t dest = first + s_goff[grp[j]] + hist_w[grp[j]] + lrank[j];
+                tx[dest] = rec[j].x; ty[dest] = rec[j].y; tz[dest] = rec[j].z;
+            }
+        }
+        __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < C; i += kBlock) {
+        Rec3 r; r.x = tx[first + i]; r.y = ty[first + i]; r.z = tz[first + i];
+        recs[first + i] = r;
+    }
+    if (threadIdx.x < ng) {
+        const uint32_t g = threadIdx.x;
+        const uint32_t k0 = s_gsub[g] << hs, k1 = min(span, s_gsub[g + 1u] << hs);
+        F.hsub[(size_t)b * kHeavyGroups + g] = make_uint4(first + s_goff[g], s_goff[g + 1u] - s_goff[g], key_lo + k0, k1 - k0);
+    }
+    if (threadIdx.x == 0) F.hparts[b] = ng;
+}
+
 template <bool ORDERED>   // as in k_bin_scatter
 __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     constexpr uint32_t NW = kBlock / kWave;                    // 4 waves; a wave ranks 512 consecutive points of the bucket
@@ -1274,6 +1413,7 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     constexpr uint32_t kMapWords = kBucketCells / 32u;         // 4096
     constexpr uint32_t kPerW = kMapWords / kBlock;             // at most 16 occupancy words per thread
     constexpr uint32_t kPlane = kBucketCap + kBucketCap / 32u + 8u;   // a staged coordinate plane: slot s lives at s + (s >> 5)
+    static_assert(kHeavyGroups <= 128u, "k_heavy_split matches groups on 7 bits");
     static_assert(kPlane * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPlane * 12u];   // occupancy bits + running counts, then the staged records (three planes)
     __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kBucketCap];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3
@@ -1309,10 +1449,23 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     for (uint32_t it = 0; it < kBucketsPerBlock; ++it) {
     const uint32_t b = blockIdx.x * kBucketsPerBlock + it;
     if (b >= nb) break;
-    const uint4 info = info_n;   // {first record, records, first key, keys spanned}
+    const uint4 info_b = info_n;   // {first record, records, first key, keys spanned}
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) rec[j] = recn[j];
     if (it + 1u < kBucketsPerBlock && b + 1u < nb) { info_n = binfo[b + 1u]; request(recn, info_n); }
+    // a heavy bucket comes as the buckets k_heavy_split cut it into, taken one after the other; their voxels follow each
+    // other in the bucket's part of the scratch records
+    const bool heavy = info_b.y > kBucketCap;
+    const uint32_t nparts = heavy ? min(F.hparts[b], kHeavyGroups) : 1u;
+    uint32_t nv_acc = 0u;
+    bool failed = heavy && nparts == 0u;
+    for (uint32_t part = 0; part < nparts && !failed; ++part) {
+    uint4 info = info_b;
+    if (heavy) {
+        info = F.hsub[(size_t)b * kHeavyGroups + part];
+        if (info.y == 0u) continue;   // (a group of empty key sub-ranges at the end)
+        request(rec, info);
+    }
     const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
     // A bucket that spans at most kBucketCap cells sorts by the cell itself (ids of empty cells get empty runs);
     // a wider one first ranks its occupied cells through an occupancy map, so that ids stay below the point count.
@@ -1337,10 +1490,7 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     }
     bad = __syncthreads_or(bad ? 1 : 0) != 0;
     PCOP_STAMP(F, 2, 1, 150);
-    if (bad) {   // publish "present, no voxels", so that the higher buckets do not wait
-        if (threadIdx.x == 0) { atomicOr(&st->err, (uint32_t)kErrInternal); bucket_pub[b] = 0u; }
-        continue;
-    }
+    if (bad) { failed = true; break; }
     if (!direct) {
 #pragma unroll
         for (uint32_t j = 0; j < kItemsB; ++j)
@@ -1425,7 +1575,6 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     uint32_t ttot;
     uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
     const uint32_t nvox = ttot >> 16;
-    if (threadIdx.x == 0) bucket_pub[b] = nvox;   // k_voxel_gather adds the counts up to output ranks
     {
         uint32_t ro[4], vo[4];
 #pragma unroll
@@ -1475,11 +1624,17 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
                 for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
             }
             const float fc = (float)(e0 - s0);
-            scratch[info.x + s_vr[v]] = make_float4(sx / fc, sy / fc, sz / fc, 0.0f);
+            scratch[info_b.x + nv_acc + s_vr[v]] = make_float4(sx / fc, sy / fc, sz / fc, 0.0f);
         }
     }
+    nv_acc += nvox;
     PCOP_STAMP(F, 2, 20, 150);
     __syncthreads();   // the next bucket clears and fills the same LDS
+    }
+    if (threadIdx.x == 0) {   // k_voxel_gather adds the counts up to output ranks
+        if (failed) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)kErrInternal); bucket_pub[b] = 0u; }
+        else bucket_pub[b] = nv_acc;
+    }
     }
 }
 
