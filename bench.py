@@ -278,7 +278,12 @@ def worker(args):
             nbytes = B * kernel_alg_bytes(nm, n0, m_vox, n_cells)
             return ms, nbytes, (nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
 
-        dom = max((nm for nm in totals if nm.startswith("k_")), key=lambda k: totals[k])
+        # the dominant kernel: the largest share of the batch; two kernels within 3 % of each other (k_bin_scatter and
+        # k_bucket_reduce trade places from run to run) are told apart by their algorithmic bytes - the one that moves more
+        # is the one the HBM bound is about
+        kern = [nm for nm in totals if nm.startswith("k_")]
+        top = max(totals[nm] for nm in kern)
+        dom = max((nm for nm in kern if totals[nm] >= 0.97 * top), key=lambda k: kernel_alg_bytes(k, n0, m_vox, n_cells))
         dom_ms, dom_bytes, achieved = roof(dom)
         total_ms = sum(totals.values())
         by_kernel = []
