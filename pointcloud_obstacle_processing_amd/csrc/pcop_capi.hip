@@ -1652,18 +1652,24 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
             const float* py = from_in ? hs->src_y.get() : sl.f.cen_y.get();
             const float* pz = from_in ? hs->src_z.get() : sl.f.cen_z.get();
             float* rb = reinterpret_cast<float*>(sl.f.rec_b.get());
-            PlaneScratch s0{{sl.in_x, sl.in_y, sl.in_z}}, s1{{rb, rb + c->cap, rb + 2 * c->cap}};
-            // neither scratch set may be the cloud of the first round: after the outlier removal it sits in rec_b's planes,
-            // after a pass-through possibly in the staging planes
-            PlaneScratch first = s0, second = s1;
-            if (px == sl.in_x) { first = s1; second = s0; }
-            if (px == sl.in_x && sor) { c->err = "internal: plane removal scratch"; rc = PCOP_ERR_STATE; break; }
+            float* ra = reinterpret_cast<float*>(sl.f.rec_a.get());
+            // what is left alternates between the planes of rec_a and rec_b (16 bytes per point each; both idle between the
+            // voxel / outlier steps and the cell stage).  After the outlier removal the cloud sits in rec_b's planes, so the
+            // first round must not write there.  The staged input is never written: a re-plan runs the frame again from it.
+            PlaneScratch s0{{ra, ra + c->cap, ra + 2 * c->cap}}, s1{{rb, rb + c->cap, rb + 2 * c->cap}};
+            PlaneScratch first = px == rb ? s0 : s1, second = px == rb ? s1 : s0;
             const float *ox, *oy, *oz;
             uint32_t left = 0;
             plane_coeffs.clear();
             c->in_flight = false;
             rc = plane_removal_loop(c, sl, px, py, pz, npts, sl.h_vox, *plane, first, second, &ox, &oy, &oz, &left, &plane_coeffs, &found_all);
             if (rc) break;
+            if (ox == ra && left) {   // the cell stage sorts its records into rec_a: what is left moves to rec_b's planes (free by now)
+                HIPCHK(c, hipMemcpyAsync(rb, ox, (size_t)left * 4, hipMemcpyDeviceToDevice, s));
+                HIPCHK(c, hipMemcpyAsync(rb + c->cap, oy, (size_t)left * 4, hipMemcpyDeviceToDevice, s));
+                HIPCHK(c, hipMemcpyAsync(rb + 2 * c->cap, oz, (size_t)left * 4, hipMemcpyDeviceToDevice, s));
+                ox = rb; oy = rb + c->cap; oz = rb + 2 * c->cap;
+            }
             k_set_cloud<<<1, 64, 0, s>>>(fr, ox, oy, oz, left);
             mark(c, "plane_removal");
         }
@@ -1682,7 +1688,8 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
         return rc;
     }
     const DevState* hs = sl.h_state;
-    if (c->emit_cloud) out->num_voxels = (int32_t)(hs->c_from_input && !hs->passthrough ? hs->c_n : hs->m);
+    // the cloud the cluster indices refer to: what the last filter step kept (also of a pass-through frame's input), else the voxel cloud
+    if (c->emit_cloud) out->num_voxels = (int32_t)((sor || plane) ? hs->c_n : (hs->c_from_input && !hs->passthrough ? hs->c_n : hs->m));
     out->voxel_xyz = (c->emit_cloud && out->num_voxels) ? sl.h_vox : nullptr;
     if (stats) {
         uint32_t totals[4] = {0, 0, 0, 0};

@@ -155,3 +155,32 @@ def test_node_chain_edge_cases(capi, oracle):
     got = c.process_node(pts, occ=pc, mean_k=15, stddev_mul=1.0)
     assert got["voxel_xyz"].tobytes() == ref["cloud"].tobytes() and np.array_equal(got["indices"], ref["indices"])
     c.close()
+
+
+@pytest.mark.parametrize("mean_k,use_plane", [(0, True), (15, False), (4, True)])
+def test_node_chain_on_a_pass_through_frame(capi, oracle, mean_k, use_plane):
+    """A cloud whose voxel grid would overflow (blobs 40 m apart at leaf 0.01: VoxelGrid's "output = input" rule) and the
+    filter steps after it: the cloud returned is the one the cluster indices refer to - what the last step kept of the
+    INPUT - not the pass-through cloud (found by the randomised campaign, tests/tools/fuzz.py)."""
+    rng = np.random.default_rng(77)
+    centres = rng.uniform(-20, 20, (25, 3))
+    pts = (centres[rng.integers(0, 25, 5000)] + rng.normal(0, 0.03, (5000, 3))).astype(f32)
+    leaf, tol, mn, mx, thr = 0.01, 0.1, 2, 20000, 0.4
+    vox, passthrough = oracle.voxel_downsample(pts, leaf)
+    assert passthrough and len(vox) == len(pts)
+    cur = vox
+    if mean_k:
+        cur = oracle.sor(cur, mean_k, 1.0)["xyz"]
+    if use_plane:
+        cur = oracle.segment_planes(cur, thr)["xyz"]
+    assert 0 < len(cur) < len(pts)
+    ro, ri = oracle.euclidean_clusters(cur, tol, mn, mx)
+    c = capi.Context(len(pts))
+    c.set_params(leaf=leaf, tol=tol, min_cluster=mn, max_cluster=mx, publish_clouds=1)
+    for rep in range(2):
+        got = c.process_node(pts, mean_k=mean_k, stddev_mul=1.0, plane=capi.plane_params(thr) if use_plane else None)
+        assert got["passthrough"] == 1
+        assert got["voxel_xyz"].tobytes() == cur.tobytes()
+        assert np.array_equal(got["offsets"], ro) and np.array_equal(got["indices"], ri)
+        assert got["n_clustered"] == len(cur)
+    c.close()

@@ -1,5 +1,5 @@
 """Randomised parity campaign: many small and mid-sized clouds of awkward shapes through the GPU chain, the occupancy
-step and the outlier removal, each compared with the CPU oracle.  usage: python tests/tools/fuzz.py [cases] [seed]"""
+step, the outlier removal, the plane removal and the node's chain in one call, each compared with the CPU oracle.  usage: python tests/tools/fuzz.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -130,6 +130,46 @@ for it in range(cases):
                     and np.array_equal(g["row_avg"], r["row_avg"]) and g["index_errors"] == r["index_errors"]):
                 fails += 1
                 print("OCC MISMATCH", it, kind, n, scale, flush=True)
+    if it % 6 == 3 and n >= 3 and os.environ.get("PCOP_CELL_PATH") != "hash":   # plane removal, and the node's chain in one call
+        thr = float(rng.choice([0.005, 0.02, 0.1])) * max(scale, 0.1)
+        g = ctx.segment_planes(pts, capi.plane_params(thr))
+        r = O.segment_planes(pts, thr)
+        if not (g["xyz"].tobytes() == r["xyz"].tobytes() and g["n_planes"] == r["n_planes"] and g["coeffs"].tobytes() == r["coeffs"].tobytes()
+                and g["found_all"] == r["found_all"]):
+            fails += 1
+            print("PLANES MISMATCH", it, kind, n, scale, thr, flush=True)
+        mk = int(rng.choice([0, 4, 15]))
+        use_plane = bool(rng.integers(0, 2))
+        po = O.occ_params(-0.6 * scale, 0.7 * scale, -0.5 * scale, 0.8 * scale, -scale, scale, 0.15 * max(scale, 0.1), 0.5)
+        pc = capi.OccParams(po.x_min, po.x_max, po.y_min, po.y_max, po.z_min, po.z_max, po.block_size, po.dev_percent, po.grid_width, po.grid_height)
+        q = pts.copy()
+        if n > 10:
+            q[::9] = np.nan            # a depth camera's holes: whole rows
+        # the stage-by-stage chain of the restatements
+        cloud_r = O.occupancy(q, po)["xyz"]
+        vox_r, _ = O.voxel_downsample(cloud_r, leaf)
+        refuse = mk and 0 < len(vox_r) <= mk          # the reference reads past its k-NN result there: refused
+        try:
+            gn = ctx.process_node(q, occ=pc, mean_k=mk, stddev_mul=1.0, plane=capi.plane_params(thr) if use_plane else None, is_dense=False)
+            if refuse:
+                okn = False
+            else:
+                cur = vox_r
+                if mk and len(cur):
+                    cur = O.sor(cur, mk, 1.0)["xyz"]
+                if use_plane:
+                    cur = O.segment_planes(cur, thr)["xyz"]
+                ro, ri = O.euclidean_clusters(cur, tol, mn, mx)
+                gv = gn["voxel_xyz"] if gn["voxel_xyz"] is not None else np.zeros((0, 3), dtype=f32)
+                okn = gv.tobytes() == cur.tobytes() and np.array_equal(gn["offsets"], ro) and np.array_equal(gn["indices"], ri)
+        except capi.PcopError as e:
+            okn = (refuse and e.status == -2) or e.status == -7
+        if not okn:
+            fails += 1
+            print("NODE CHAIN MISMATCH", it, kind, n, scale, p, mk, use_plane, thr, flush=True)
+            if os.environ.get("FUZZ_DUMP"):
+                np.savez(os.path.join(os.environ["FUZZ_DUMP"], "fuzz_fail_%d.npz" % it), q=q, leaf=leaf, tol=tol, mn=mn, mx=mx, mk=mk, use_plane=use_plane, thr=thr, scale=scale)
+        ctx.set_params(publish_clouds=1, **p)
     if it % 20 == 19:
         print("  ... %d cases, %d mismatches, %.0f s" % (it + 1, fails, time.time() - t0), flush=True)
 print("cases %d, mismatches %d, %.1f s" % (cases, fails, time.time() - t0))

@@ -1,0 +1,38 @@
+"""Replay a node-chain case the fuzz campaign dumped (FUZZ_DUMP=dir): which part of the result differs?"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+from oracle import oracle as O
+from pointcloud_obstacle_processing_amd import capi
+f32 = np.float32
+for path in sys.argv[1:]:
+    d = np.load(path)
+    q, leaf, tol, mn, mx, mk, use_plane, thr, scale = d["q"], float(d["leaf"]), float(d["tol"]), int(d["mn"]), int(d["mx"]), int(d["mk"]), bool(d["use_plane"]), float(d["thr"]), float(d["scale"])
+    ctx = capi.Context(60_000, max_frames=2)
+    ctx.set_params(publish_clouds=1, leaf=leaf, tol=tol, min_cluster=mn, max_cluster=mx)
+    po = O.occ_params(-0.6 * scale, 0.7 * scale, -0.5 * scale, 0.8 * scale, -scale, scale, 0.15 * max(scale, 0.1), 0.5)
+    pc = capi.OccParams(po.x_min, po.x_max, po.y_min, po.y_max, po.z_min, po.z_max, po.block_size, po.dev_percent, po.grid_width, po.grid_height)
+    cloud_r = O.occupancy(q, po)["xyz"]
+    vox_r, pt = O.voxel_downsample(cloud_r, leaf)
+    cur = vox_r
+    thr_r = None
+    if mk and len(cur):
+        s = O.sor(cur, mk, 1.0); cur = s["xyz"]; thr_r = s["threshold"]
+    n_inl = len(cur)
+    if use_plane:
+        pl = O.segment_planes(cur, thr); cur = pl["xyz"]
+    ro, ri = O.euclidean_clusters(cur, tol, mn, mx)
+    for rep in range(2):
+        gn = ctx.process_node(q, occ=pc, mean_k=mk, stddev_mul=1.0, plane=capi.plane_params(thr) if use_plane else None, is_dense=False)
+        gv = gn["voxel_xyz"] if gn["voxel_xyz"] is not None else np.zeros((0, 3), dtype=f32)
+        print(os.path.basename(path), "n", len(q), "leaf", leaf, "tol", tol, "mk", mk, "plane", use_plane, thr, "| passthrough", pt, "kept", len(cloud_r), "vox", len(vox_r), "inl", n_inl, "cur", len(cur),
+              "| gpu: filtered", gn["n_filtered"], "vox", gn["n_voxels"], "inl", gn["n_inliers"], "planes", gn["n_planes"], "clustered", gn["n_clustered"], "cloud", len(gv),
+              "| cloud equal", gv.tobytes() == cur.tobytes(), "offsets", np.array_equal(gn["offsets"], ro), "indices", np.array_equal(gn["indices"], ri), "thr", gn.get("threshold"), thr_r)
+    # stage by stage on the GPU
+    g_occ = ctx.occupancy_filter(q, pc)
+    print("   stage occ equal", g_occ["xyz"].tobytes() == cloud_r.tobytes())
+    gvx, gpt = ctx.voxel_downsample(cloud_r)
+    print("   stage voxel equal", gvx.tobytes() == vox_r.tobytes(), gpt, pt)
+    ctx.close()
