@@ -22,14 +22,26 @@ menu = [
     ("C2", dict(leaf=0.05, tol=0.01), 30.0),           # huge extent / tiny tolerance: cell grid too large -> hash table
     ("C1", dict(leaf=0.0005, tol=0.05), 1.0),          # voxel grid beyond 2^26 cells -> sort path
     ("C3", dict(leaf=0.02, tol=0.1), 1.0),
+    ("SHEET", dict(leaf=0.01, tol=0.05), 1.0),         # a dense sheet in a tall box: coarse bins above a bucket -> k_heavy_split
 ]
+
+
+def sheet(n, seed):
+    r = np.random.default_rng(seed)
+    a = np.concatenate([r.uniform(0, 2, (n, 2)), r.normal(0.5, 0.001, (n, 1))], axis=1)
+    b = r.uniform(0, 2, (max(n // 200, 8), 3))
+    q = np.concatenate([a, b]).astype(f32)
+    return q[r.permutation(len(q))][:n]
+
+
 fails = 0
 t0 = time.time()
 paths = set()
 for it in range(steps):
     cfg, prm, stretch = menu[int(rng.integers(0, len(menu)))]
     n = int(rng.choice([5_000, 150_000, 600_000, 1_000_000] if big else [5_000, 40_000, 150_000, 400_000]))
-    pts = (synth.make_cloud(cfg, n=n, seed=int(rng.integers(0, 1 << 30))) * f32(stretch)).astype(f32)
+    seed = int(rng.integers(0, 1 << 30))
+    pts = sheet(n, seed) if cfg == "SHEET" else (synth.make_cloud(cfg, n=n, seed=seed) * f32(stretch)).astype(f32)
     p = dict(prm, min_cluster=int(rng.choice([1, 5])), max_cluster=int(rng.choice([20000, 10**9])))
     ctx.set_params(publish_clouds=1, **p)
     try:
@@ -45,6 +57,23 @@ for it in range(steps):
     if not ok:
         fails += 1
         print("MISMATCH step", it, cfg, n, stretch, p, flush=True)
+    if it % 4 == 1 and n <= 150_000 and stretch == 1.0 and os.environ.get("PCOP_CELL_PATH") != "hash":   # the node's chain on the same context, in between
+        mk = int(rng.choice([0, 15])); use_plane = bool(rng.integers(0, 2)); thr = 0.04
+        try:
+            cur, _ = O.voxel_downsample(pts, p["leaf"])
+            if mk and len(cur) > mk: cur = O.sor(cur, mk, 1.0)["xyz"]
+            elif mk: mk = 0
+            if use_plane: cur = O.segment_planes(cur, thr)["xyz"]
+            ro, ri = O.euclidean_clusters(cur, p["tol"], p["min_cluster"], p["max_cluster"])
+            gn = ctx.process_node(pts, mean_k=mk, stddev_mul=1.0, plane=capi.plane_params(thr) if use_plane else None)
+            gv = gn["voxel_xyz"] if gn["voxel_xyz"] is not None else np.zeros((0, 3), dtype=f32)
+            okn = gv.tobytes() == cur.tobytes() and np.array_equal(gn["offsets"], ro) and np.array_equal(gn["indices"], ri)
+        except capi.PcopError as e:
+            okn = False
+            print("ERROR (node chain)", e, flush=True)
+        if not okn:
+            fails += 1
+            print("NODE CHAIN MISMATCH step", it, cfg, n, p, mk, use_plane, flush=True)
     if it % 10 == 9:
         print("  ... %d steps, %d mismatches, %.0f s, (voxel, cell) paths seen %s" % (it + 1, fails, time.time() - t0, sorted(paths)), flush=True)
 print("steps %d, mismatches %d, paths %s, %.1f s" % (steps, fails, sorted(paths), time.time() - t0))
