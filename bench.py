@@ -331,7 +331,7 @@ def worker(args):
         }
 
         # ---- end to end: the same pipeline fed from pinned host memory (12 MB per frame over PCIe inside the timed region) ----
-        if not args.no_end_to_end:
+        if not args.no_end_to_end and world == 1:   # (N = 1 only, like the CPU leg: the other ranks would only wait)
             import ctypes as C
             host = [torch.from_numpy(np.ascontiguousarray(synth.make_cloud(args.config, seed=s).T.reshape(-1))).pin_memory() for s in seeds[:4]]
             hp = (C.c_void_p * B)(*[C.c_void_p(host[i % len(host)].data_ptr()) for i in range(B)])
@@ -365,7 +365,7 @@ def worker(args):
 
         # ---- CPU baseline: the oracle (a restatement of the PCL path, not PCL) on this box's host cores; its results for the
         #      first frames are then compared with what the GPU gives for the same clouds (outside every timed region) ----
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as O
             O.build()
             clouds = [synth.make_cloud(args.config, seed=s) for s in seeds[: min(2, len(seeds))]]
