@@ -1,7 +1,7 @@
 """After k_cgrid_hook + k_cell_compress (PCOP_DEBUG_SKIP_UNION=1): how many trees, and where, on a field frame with strays."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["PCOP_DEBUG_SKIP_UNION"] = "1"
 import torch  # noqa

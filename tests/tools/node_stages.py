@@ -1,7 +1,7 @@
 import os, sys, time, json
 import numpy as np
-ROOT = "/root/repo"
-sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from oracle import oracle as O
 from pointcloud_obstacle_processing_amd import capi, synth

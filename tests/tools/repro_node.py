@@ -1,7 +1,7 @@
 """Replay a node-chain case the fuzz campaign dumped (FUZZ_DUMP=dir): which part of the result differs?"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa
 from oracle import oracle as O
