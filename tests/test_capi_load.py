@@ -61,3 +61,11 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pcop_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_root_tools_do_not_touch_the_oracle():
+    """tools/ at the repository root is oracle-free (profile reduction, sweeps); what needs the oracle lives in tests/tools."""
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            text = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
+            assert "pcop_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
