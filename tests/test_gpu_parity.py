@@ -546,6 +546,33 @@ def test_stream_path_heavy_bins_are_split(capi, oracle, monkeypatch):
     c.close()
 
 
+def test_stream_path_without_lane_ordered_atomics(capi, oracle, monkeypatch):
+    """PCOP_LDS_ORDER=0: the instances of k_bin_scatter / k_bucket_reduce that build their stable ranks from peer masks
+    instead of the return values of LDS atomic adds (what a device failing the probe at context creation would run)."""
+    monkeypatch.setenv("PCOP_VOXEL_PATH", "stream")
+    monkeypatch.setenv("PCOP_LDS_ORDER", "0")
+    c = capi.Context(400_000, max_frames=2)
+    for cfg, n, seed in (("C3", 300_000, 8), ("C2", 100_000, 9), ("C1", 10_000, 10)):
+        p = synth.params_of(cfg)
+        pts = synth.make_cloud(cfg, n=n, seed=seed)
+        c.set_params(publish_clouds=1, **p)
+        ref = oracle.process_xyz(pts, **p)
+        got = c.process_xyz(pts)
+        assert c.debug_state().vpath == 1
+        assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    # two frames in one batch
+    p = synth.params_of("C3")
+    c.set_params(publish_clouds=1, **p)
+    frames = [synth.make_cloud("C3", n=200_000, seed=11), synth.make_cloud("C3", n=120_000, seed=12)]
+    c.submit_batch_host(frames)
+    for got, pts in zip(c.wait_batch(), frames):
+        ref = oracle.process_xyz(pts, **p)
+        assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+        assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    c.close()
+
+
 def test_stream_path_huge_sparse_grid(capi, oracle, monkeypatch):
     """A voxel grid of more than 2^26 cells (tens of metres at leaf 0.02): still the streaming path, same answer."""
     monkeypatch.setenv("PCOP_VOXEL_PATH", "stream")
