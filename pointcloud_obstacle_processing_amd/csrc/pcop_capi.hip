@@ -112,6 +112,7 @@ struct pcop_ctx {
     // path and the context stays there until the leaf size changes
     bool voxel_stream = true, stream_ok = true;
     bool csr_onepass = true;         // PCOP_CSR_ONEPASS=0: the three-kernel form of the CSR partition also for a single pass
+    bool csr_small = true;           // the last batch's clouds had few enough points for the one-kernel form (its look-back grows with the square of the tiles)
     uint32_t nb_cap = kNbMin;                               // buckets the launch provides LDS and blocks for (grows on demand)
     uint32_t gbits = 13;                                    // log2 of the coarse key bins (tuned from the fullest bin seen; any value gives the same result)
     bool gbits_fixed = false;                               // PCOP_BIN_BITS given: no tuning
@@ -362,7 +363,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
         mark(c, "k_cell_flatten");
         k_kept_apply<<<sg, kBlock, 0, s>>>(fr, c->npass_csr, (uint32_t)MAXB);
         mark(c, "k_kept_apply");
-        if (nf == 1 && c->npass_csr == 1 && MAXB == kNarrowBits && c->csr_onepass) {   // one frame, at most 255 kept clusters: one kernel
+        if (nf == 1 && c->npass_csr == 1 && MAXB == kNarrowBits && c->csr_onepass && c->csr_small) {   // one frame, at most 255 kept clusters: one kernel
             // (a batch keeps the three launches: tiles that wait for lower tiles hold wave slots the other contexts' kernels want)
             k_csr_onepass<<<pg, kBlock, 0, s>>>(fr);
             mark(c, "k_csr_onepass");
@@ -425,7 +426,7 @@ int enqueue_batch(pcop_ctx* c) {
         HIPCHK(c, hipGetLastError());
     } else {
         const bool st_on = stream_on(c);
-        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr, c->nframes, st_on ? tile_for(nb, c->nframes) : 0u, st_on ? (c->heavy_ok ? 2u : 1u) : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
+        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr | ((c->csr_onepass && c->csr_small) ? 0x100u : 0u), c->nframes, st_on ? tile_for(nb, c->nframes) : 0u, st_on ? (c->heavy_ok ? 2u : 1u) : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
                            grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
@@ -539,6 +540,9 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             if (attempt >= 6) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
             if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));
             if (kb_csr) c->npass_csr = std::max(c->npass_csr, passes_for(c, kb_csr));
+            if (e & kErrReplanCsr)
+                for (uint32_t f = 0; f < c->nframes; ++f)
+                    if (c->slots[f].h_state->c_n > kCsrOnepassMax) c->csr_small = false;   // (k_csr_onepass refused the frame)
             if (e & kErrReplanCpath) {
                 c->cgrid_ok = false;             // the cell grid of this cloud is too large for an occupancy map: hash table from here on
             } else if (e & kErrReplanCtiles) {
@@ -580,6 +584,11 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
     }
     if (kb_voxel) c->npass_voxel = passes_for(c, kb_voxel);
     if (kb_csr) c->npass_csr = passes_for(c, kb_csr);
+    if (c->kind != kFrameVoxelOnly) {
+        uint32_t cn = 0;
+        for (uint32_t f = 0; f < c->nframes; ++f) cn = std::max(cn, c->slots[f].h_state->c_n);
+        c->csr_small = cn <= kCsrOnepassMax;
+    }
     if (c->kind != kFrameVoxelOnly) {
         uint64_t pts = 0, cells = 0;
         for (uint32_t f = 0; f < c->nframes; ++f) {

@@ -256,6 +256,8 @@ __global__ __launch_bounds__(kBlock) void k_csr_scatter(const Frame* frames, int
 // on higher ones and blocks are dispatched in index order; k_kept_apply zeroes the flags).  Used for single frames: it
 // saves two launches (10 us of a 0.21 ms frame); in a batch with other contexts in flight the waiting tiles hold wave
 // slots and the three-launch form is 1.7 x faster.
+constexpr uint32_t kCsrOnepassMax = 1u << 18;   // points (128 tiles): beyond, the tiles' look-back (quadratic in the tiles) costs more than two launches
+
 __global__ __launch_bounds__(kBlock) void k_csr_onepass(const Frame* frames) {
     constexpr uint32_t NB = (1u << kNarrowBits) + 1u;
     __shared__ uint32_t s_hist[kWavesPerBlock * NB];
@@ -269,6 +271,10 @@ __global__ __launch_bounds__(kBlock) void k_csr_onepass(const Frame* frames) {
     uint32_t* flags = F.tile_a;
     uint32_t count, bits, shift;
     if (!csr_pass_info(st, 0, &count, &bits, &shift)) return;
+    if (count > kCsrOnepassMax) {   // too many tiles for the look-back: the host re-runs the frame with the three-launch form
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(const_cast<uint32_t*>(&st->err), (uint32_t)kErrReplanCsr);
+        return;
+    }
     const uint32_t tile_base = blockIdx.x * kTile;
     if (tile_base >= count) return;
     const uint32_t nb = (1u << bits) + 1u, trash = st->n_kept;
