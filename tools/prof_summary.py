@@ -9,8 +9,8 @@ for r in rows:
 acc = {k: v for k, v in acc.items() if "pcop::k_" in k and "probe" not in k and "unpack" not in k}
 import statistics
 nb = int(statistics.median(len(v) for v in acc.values()))   # launches of a kernel that runs once per batch (a kernel seen only while the plan settles counts less)
-acc = {k: v for k, v in acc.items() if len(v) >= nb}
-items = sorted(((k, sum(v) / len(v), len(v) // nb) for k, v in acc.items()), key=lambda t: -t[1] * t[2])
+acc = {k: v for k, v in acc.items() if 2 * len(v) >= nb}   # (a kernel seen only while the plan settles is left out)
+items = sorted(((k, sum(v) / len(v), max(1, round(len(v) / nb))) for k, v in acc.items()), key=lambda t: -t[1] * t[2])
 tot = 0.0
 print("%-66s %10s %4s %12s" % ("kernel (batch of %d frames per launch)" % batch, "avg_us", "x", "us/frame"))
 for k, a, c in items:
