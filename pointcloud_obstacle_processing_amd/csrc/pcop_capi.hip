@@ -537,7 +537,9 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (e & kErrInternal) { c->in_flight = false; scrub_flags(c); c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
         if (e & kErrSorFew) { c->in_flight = false; scrub_flags(c); c->err = "fewer points than mean_k + 1"; return PCOP_ERR_STATE; }
         if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanBins | kErrReplanCpath | kErrReplanCtiles)) {
-            if (attempt >= 6) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
+            // (every adaptive piece may have to move once for a cloud unlike the last: bins, buckets, heavy bins, voxel path,
+            //  pass counts, occupancy tiles, cell path, CSR form - each moves towards "larger" only, so the loop ends)
+            if (attempt >= 16) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
             if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));
             if (kb_csr) c->npass_csr = std::max(c->npass_csr, passes_for(c, kb_csr));
             if (e & kErrReplanCsr)
@@ -559,7 +561,12 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
                 c->stream_ok = false;            // this cloud does not fit the streaming voxel path: sort path from here on
                 c->npass_voxel = kMaxPasses;     // (its own plan check then trims the pass count)
             } else if (e & kErrReplanBins) {
-                ++c->gbits;                      // finer coarse bins
+                uint32_t worst = 0;              // finer coarse bins: a bit halves a bin, so go straight to where the fullest one fits
+                for (uint32_t f = 0; f < c->nframes; ++f)
+                    if (c->slots[f].h_state->err & kErrReplanBins) worst = std::max(worst, c->slots[f].h_state->maxbin);
+                uint32_t more = 1;
+                while (more < kBinBitsMax - kBinBitsMin && (worst >> more) > kBucketCap) ++more;
+                c->gbits = std::min(kBinBitsMax, c->gbits + more);
             } else if (e & kErrReplanVcap) {
                 for (uint32_t f = 0; f < c->nframes; ++f) {
                     const DevState* hs = c->slots[f].h_state;
@@ -1602,7 +1609,7 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
         return PCOP_OK;
     };
     for (int attempt = 0;; ++attempt) {
-        if (attempt >= 8) { c->cur_n_dev = nullptr; c->retry_to_caller = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
+        if (attempt >= 16) { c->cur_n_dev = nullptr; c->retry_to_caller = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
         if (!sor && !plane) {   // the plain chain on the kept cloud; finish_batch re-plans by itself (the mailbox keeps the device count)
             c->retry_to_caller = false;
             if ((rc = enqueue_batch(c))) break;
