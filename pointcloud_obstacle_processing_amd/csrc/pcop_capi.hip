@@ -111,6 +111,7 @@ struct pcop_ctx {
     // kNbMax buckets, or a coarse bin above a bucket's capacity even with the finest bins) is re-run on the sort
     // path and the context stays there until the leaf size changes
     bool voxel_stream = true, stream_ok = true;
+    bool stream_single = false;      // PCOP_VOXEL_PATH=stream: the streaming voxel path also for a single frame (default: batches only)
     bool csr_onepass = true;         // PCOP_CSR_ONEPASS=0: the three-kernel form of the CSR partition also for a single pass
     bool csr_small = true;           // the last batch's clouds had few enough points for the one-kernel form (its look-back grows with the square of the tiles)
     uint32_t nb_cap = kNbMin;                               // buckets the launch provides LDS and blocks for (grows on demand)
@@ -223,7 +224,12 @@ uint32_t hash_cap_for(uint32_t n) {
 uint32_t tile_for(uint32_t nb, uint32_t nf) { return (uint64_t)nf * div_up(nb, kBinTile) >= 256u ? kBinTile : kBinTileSmall; }
 
 bool grid_on(const pcop_ctx* c) { return c->cell_grid && c->cgrid_ok && !c->crowded_cells && c->kind != kFrameVoxelOnly; }
-bool stream_on(const pcop_ctx* c) { return c->voxel_stream && c->stream_ok && c->kind != kFrameClusterOnly; }
+// The streaming voxel path wins by its traffic when frames share launches; a single frame is bound by launch count and
+// latency, where the radix path's three passes are shorter (measured on every BASELINE config: 0.208 against 0.219 ms on
+// C3).  So, unless PCOP_VOXEL_PATH says otherwise: batches stream, single frames sort.  Both give the same bytes.
+bool stream_on(const pcop_ctx* c) {
+    return c->voxel_stream && c->stream_ok && c->kind != kFrameClusterOnly && (c->nframes > 1 || c->stream_single);
+}
 
 // The launch sequence of one batch.  nb = launch-size bucket (>= every frame's point count), nf =
 // frames; all real counts are read on the device.  Everything here is capturable into a hipGraph.
@@ -1061,7 +1067,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     }
     c->maxbits = c->radix_bits_target <= kNarrowBits ? kNarrowBits : kMaxBits;
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
-    if (const char* e = getenv("PCOP_VOXEL_PATH")) c->voxel_stream = std::string(e) != "sort";
+    if (const char* e = getenv("PCOP_VOXEL_PATH")) { c->voxel_stream = std::string(e) != "sort"; c->stream_single = std::string(e) == "stream"; }
     if (const char* e = getenv("PCOP_CSR_ONEPASS")) c->csr_onepass = atoi(e) != 0;
     if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
     if (const char* e = getenv("PCOP_BIN_BITS")) { c->gbits = (uint32_t)std::min<int>(kBinBitsMax, std::max<int>(kBinBitsMin, atoi(e))); c->gbits_fixed = true; }
