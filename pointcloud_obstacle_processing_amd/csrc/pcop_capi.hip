@@ -305,7 +305,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
                 k_radix_scatter<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
                 mark(c, "k_radix_scatter");
             }
-            k_voxel_reduce<<<sg, kBlock, 0, s>>>(fr, c->npass_voxel);
+            k_voxel_reduce<<<sg, kBlock, 0, s>>>(fr, c->npass_voxel, fold_grid ? 1u : 0u);   // (fold_grid: the cell grid is set up, the centroids mark their cells)
             mark(c, "k_voxel_reduce");
         }
     }
@@ -322,9 +322,9 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
                 k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, 2u | 4u);
                 mark(c, "k_voxel_setup");
             }
-            // a chain frame on the streaming voxel path has its cells marked by k_voxel_gather (same launch sequence, grid
-            // set up before the voxel stage)
-            const bool marks_cells = kind == kFrameChain && (parts & kPartVoxel) && stream_on(c) && !(parts & kPartOwnGridSetup);
+            // a chain frame has its cells marked by the voxel stage's last kernel (same launch sequence, grid set up before
+            // the voxel stage)
+            const bool marks_cells = kind == kFrameChain && (parts & kPartVoxel) && !(parts & kPartOwnGridSetup);   // by k_voxel_gather / k_voxel_reduce
             if (!marks_cells) {
                 k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
                 mark(c, "k_cell_mark");

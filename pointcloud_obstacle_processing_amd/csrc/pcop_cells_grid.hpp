@@ -23,7 +23,6 @@ namespace pcop {
 //   k_cell_place    (shared with the hash path) records sorted by cell
 //   k_cgrid_hook / k_cell_compress / k_cgrid_union   components, lane = cell
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool cgrid_off(const DevState* st) { return cluster_stage_off(st) || !st->cpath; }
 
 // The whole block: grid origin and size from the bounding box in st->vmin / vmax (a superset of what the cell stage will
 // see), the scan tiles' publish words cleared.  npts_max bounds the points that will enter the cell stage; empty: none will.
@@ -61,35 +60,6 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_setup(Frame* frames) {
     Frame& F = frames[blockIdx.y];
     cgrid_setup_block(F, F.st.c_n, F.st.c_n == 0u);
 }
-
-// Grid position of a point of the cell stage; its cell's flag byte set.  0 (and an error bit) for a point the grid cannot take.
-struct CellMarker {
-    double ig;
-    long long c0x, c0y, c0z, d0, d1, d2;
-    uint32_t rowbits, plane;
-    __device__ __forceinline__ void init(const DevState* st) {
-        ig = st->inv_cell;
-        c0x = st->c0[0]; c0y = st->c0[1]; c0z = st->c0[2];
-        d0 = st->c_dim[0]; d1 = st->c_dim[1]; d2 = st->c_dim[2];
-        rowbits = st->c_rowbits; plane = st->c_plane;
-    }
-    __device__ __forceinline__ uint32_t operator()(DevState* st, uint8_t* __restrict__ cflag, float px, float py, float pz) const {
-        if (!finite3(px, py, pz)) {   // radiusSearch on a non-finite point is undefined in PCL
-            atomicOr(&st->err, (uint32_t)kErrNonFinite);
-            return 0u;
-        }
-        const long long gx = (long long)floor((double)px * ig) - c0x, gy = (long long)floor((double)py * ig) - c0y,
-                        gz = (long long)floor((double)pz * ig) - c0z;
-        // two free cells on every side keep the whole 5x5x5 stencil inside the array
-        if (gx < 2 || gy < 2 || gz < 2 || gx > d0 - 3 || gy > d1 - 3 || gz > d2 - 3) {
-            atomicOr(&st->err, (uint32_t)kErrReplanCpath);
-            return 0u;
-        }
-        const uint32_t pos = (uint32_t)gz * plane + (uint32_t)gy * rowbits + (uint32_t)gx;
-        cflag[pos] = 1;
-        return pos;
-    }
-};
 
 __global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
     Frame& F = frames[blockIdx.y];

@@ -75,9 +75,6 @@ __device__ __forceinline__ uint32_t hash_lookup(const unsigned long long* __rest
     }
 }
 
-__device__ __forceinline__ bool cluster_stage_off(const DevState* st) {
-    return st->err || st->trivial || st->kind == kFrameVoxelOnly;
-}
 
 // Every point: its cell's slot and its rank inside the cell.  Runs of consecutive points that
 // fall in one cell (frequent: the points arrive in voxel order) share one set of atomics.

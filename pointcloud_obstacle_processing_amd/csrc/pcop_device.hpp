@@ -364,6 +364,41 @@ __device__ __forceinline__ bool make_plan(RadixPlan* pl, uint32_t key_bits, uint
     return each <= maxbits;
 }
 
+// ---- predicates and the cell marker shared by the voxel and the cell stage -------------------------------------------
+__device__ __forceinline__ bool cluster_stage_off(const DevState* st) {
+    return st->err || st->trivial || st->kind == kFrameVoxelOnly;
+}
+__device__ __forceinline__ bool cgrid_off(const DevState* st) { return cluster_stage_off(st) || !st->cpath; }
+
+// Grid position of a point of the cell stage; its cell's flag byte set.  0 (and an error bit) for a point the grid cannot take.
+struct CellMarker {
+    double ig;
+    long long c0x, c0y, c0z, d0, d1, d2;
+    uint32_t rowbits, plane;
+    __device__ __forceinline__ void init(const DevState* st) {
+        ig = st->inv_cell;
+        c0x = st->c0[0]; c0y = st->c0[1]; c0z = st->c0[2];
+        d0 = st->c_dim[0]; d1 = st->c_dim[1]; d2 = st->c_dim[2];
+        rowbits = st->c_rowbits; plane = st->c_plane;
+    }
+    __device__ __forceinline__ uint32_t operator()(DevState* st, uint8_t* __restrict__ cflag, float px, float py, float pz) const {
+        if (!finite3(px, py, pz)) {   // radiusSearch on a non-finite point is undefined in PCL
+            atomicOr(&st->err, (uint32_t)kErrNonFinite);
+            return 0u;
+        }
+        const long long gx = (long long)floor((double)px * ig) - c0x, gy = (long long)floor((double)py * ig) - c0y,
+                        gz = (long long)floor((double)pz * ig) - c0z;
+        // two free cells on every side keep the whole 5x5x5 stencil inside the array
+        if (gx < 2 || gy < 2 || gz < 2 || gx > d0 - 3 || gy > d1 - 3 || gz > d2 - 3) {
+            atomicOr(&st->err, (uint32_t)kErrReplanCpath);
+            return 0u;
+        }
+        const uint32_t pos = (uint32_t)gz * plane + (uint32_t)gy * rowbits + (uint32_t)gx;
+        cflag[pos] = 1;
+        return pos;
+    }
+};
+
 }  // namespace pcop
 
 // the kernels, by stage (each part opens namespace pcop itself)

@@ -575,7 +575,9 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 constexpr uint32_t kSpinLimit = 1u << 24;
 constexpr uint32_t kReduceBucketsPerBlock = 2u;   // k_bucket_reduce: consecutive buckets per block
 
-__global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t npass) {
+// mark_cells: a chain frame on the dense cell grid (set up by k_voxel_setup): every centroid marks its grid cell as it is
+// written, so the cell stage has no k_cell_mark launch (k_voxel_gather does the same on the streaming path).
+__global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t npass, uint32_t mark_cells) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     __shared__ Rec3 s_rec[kScanTile];
     __shared__ uint32_t s_key[kScanTile + 1];
@@ -586,8 +588,18 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
     uint32_t* __restrict__ tile_heads = F.tile_a;
     float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
     if (st->err || st->kind == kFrameClusterOnly) return;
+    const bool cells = mark_cells && !cgrid_off(st);
+    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
+    CellMarker mark;
+    if (cells) mark.init(st);
     if (st->passthrough) {   // "output = *input_": the voxel cloud is the input cloud, every point kept
         if (blockIdx.x == 0 && threadIdx.x == 0) finish_voxel(st, st->n_in);
+        if (cells) {   // the cell stage sees the input cloud: each tile marks its points
+            const float* __restrict__ x = st->src_x; const float* __restrict__ y = st->src_y; const float* __restrict__ z = st->src_z;
+            const uint32_t nin = st->n_in;
+            for (uint32_t i = blockIdx.x * kScanTile + threadIdx.x; i < min(nin, (blockIdx.x + 1u) * (uint32_t)kScanTile); i += kBlock)
+                pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
+        }
         return;
     }
     const uint32_t n = st->n_valid;
@@ -673,7 +685,10 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const uint32_t h = k * kBlock + threadIdx.x;
-        if (h < tot) { cx[before + h] = ox[k]; cy[before + h] = oy[k]; cz[before + h] = oz[k]; }
+        if (h < tot) {
+            cx[before + h] = ox[k]; cy[before + h] = oy[k]; cz[before + h] = oz[k];
+            if (cells) pt_pos[before + h] = mark(st, cflag, ox[k], oy[k], oz[k]);
+        }
     }
 }
 
@@ -1651,8 +1666,6 @@ __device__ __forceinline__ uint32_t flags_to_bits(const uint4& v) {
 // One block per kVmapTile occupancy words: bytes -> bits (and the bytes are zeroed again for the
 // next frame), popcount scan; the tile publishes its count and adds up the counts of the lower
 // tiles (same publish / bounded-wait scheme as k_voxel_reduce).  The last tile knows the total: n_cells.
-__device__ __forceinline__ bool cluster_stage_off(const DevState* st);
-
 __global__ __launch_bounds__(kBlock) void k_occ_scan(Frame* frames) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     __shared__ uint16_t s_half[2 * kVmapTile];
