@@ -8,22 +8,30 @@ grid_of = {}
 
 
 def load(d):
+    # frames per launch = grid size in y, from the kernel trace of the same run (the counter file has the total grid only)
+    ydim = {}
+    try:
+        for r in csv.DictReader(open(d + "/pmc_kernel_trace.csv")):
+            ydim[r["Dispatch_Id"]] = int(r["Grid_Size_Y"])
+    except (OSError, KeyError):
+        pass
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(d + "/pmc_counter_collection.csv")):
-        acc[r["Kernel_Name"]].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
+        acc[r["Kernel_Name"]].append((float(r["Counter_Value"]), int(r["Grid_Size"]), ydim.get(r["Dispatch_Id"], batch)))
     return acc
 
 
 F, W = load(fdir), load(wdir)
 res = {}
 print("%-58s %12s %12s %12s" % ("kernel", "fetch_KiB", "write_KiB", "hbm_MB/launch"))
-for k in sorted(F, key=lambda k: -sum(v for v, _ in F[k])):
+for k in sorted(F, key=lambda k: -sum(v for v, _, _ in F[k])):
     if not k.startswith("pcop::") and "pcop::" not in k:
         continue
-    # batched launches only: the largest grid of this kernel
-    gmax = max(g for _, g in F[k])
-    fv = [v for v, g in F[k] if g == gmax]
-    wv = [v for v, g in W.get(k, []) if g == gmax]
+    # batched launches only (the run's single-frame latency leg launches the same kernels, and some of its own, for one frame)
+    fv = [v for v, g, y in F[k] if y == batch]
+    wv = [v for v, g, y in W.get(k, []) if y == batch]
+    if not fv:
+        continue
     f = sum(fv) / max(len(fv), 1)
     w = sum(wv) / max(len(wv), 1)
     hbm = (2.0 * f + w) * 1024.0
