@@ -5,30 +5,35 @@
 //   voxel grid (replaces pcl::VoxelGrid::applyFilter, called at od.cpp:282-285)
 //     k_frame_init            mailbox -> DevState
 //     k_minmax, k_voxel_setup pcl::getMinMax3D; min_b/div_b/divb_mul, the overflow rule, the plan
-//    streaming path (default; no scattered global access anywhere):
+//    streaming path (batches of frames; no scattered global access anywhere):
 //     k_bin_hist              per 16384-point tile: counts of the coarse key bins (key >> cshift)
 //     k_bin_colsum, k_bin_plan  bins -> buckets of consecutive bins, at most kBucketCap points each
 //     k_bin_tilecnt, k_bin_colscan  per (tile, bucket): where the tile's points start inside the bucket
 //     k_bin_scatter           ONE stable partition of packed 12-byte xyz records by bucket
+//     k_heavy_split           (only once a frame needed it) a coarse bin above a bucket, cut into buckets along the keys
 //     k_bucket_reduce         per bucket: occupancy bits in LDS -> local voxel ids, stable LDS counting
 //                             sort, one lane per voxel sums its run in order -> the bucket's centroids
 //     k_voxel_gather          buckets' voxel counts -> output ranks, M; centroids to their ranks (and, in a
 //                             chain frame on the dense cell grid, each marks its grid cell on the way)
-//    sort path (fallback for grids or voxel counts the streaming path does not cover):
+//    sort path (single frames - the shorter chain of launches - and clouds the streaming path does not cover):
 //     k_radix_hist / k_table_scan / k_radix_scatter   (x passes) stable LSD radix partition of
 //                             packed xyz records by PCL's linear voxel index
-//     k_voxel_reduce          run heads -> rank; in-order float32 sums -> centroids
+//     k_voxel_reduce          run heads -> rank; in-order float32 sums -> centroids (which mark their grid cells)
 //   cell grid (replaces the FLANN kd-tree built at od.cpp:791-792): cells of edge tol/1.99
 //    dense grid (default): k_cgrid_setup, k_cell_mark, k_occ_scan, k_cell_count, k_cell_starts,
 //                          k_cell_place   occupancy bits -> cell ids; points sorted by cell
 //    hash table (fallback): k_cell_insert, k_slot_count, k_slot_apply, k_cell_place
 //   clusters (replaces EuclideanClusterExtraction::extract, od.cpp:446-454)
-//     k_cgrid_hook | k_cell_hook, k_cell_compress, k_cgrid_union | k_cell_union
+//     k_cgrid_hook | k_cell_hook, k_cell_compress, k_cgrid_union (+ k_cgrid_fix: single frames) | k_cell_union
 //                             connected components of the cell graph
 //     k_cell_flatten          root per point, component sizes
 //     k_kept_apply            size filter, discovery order, CSR offsets
-//     k_csr_hist / k_table_scan / k_csr_scatter   stable partition of point indices by cluster
+//     k_csr_hist / k_table_scan / k_csr_scatter | k_csr_onepass (single frames)   stable partition of point indices by cluster
 //     k_emit                  results -> pinned host memory; hash table reset for the next frame
+//   next to the path (pcop_occupancy.hpp, pcop_neighbours.hpp, pcop_planes.hpp):
+//     k_occ_filter, k_occ_finish            bounds filter + occupancy binning (od.cpp:175-269)
+//     k_sor_setup, k_cmap_coarse, k_knn_mean, k_knn_far, k_sor_select   statistical outlier removal (od.cpp:316-340)
+//     k_plane_count, k_plane_split          RANSAC plane removal (od.cpp:342-428)
 //
 // Every count that depends on the data (valid points, voxels M, cells, clusters) lives in
 // DevState in device memory and every per-frame input comes through a pinned mailbox, so the
