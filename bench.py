@@ -125,6 +125,8 @@ def worker(args):
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("PCOP_BENCH_SAME_GPU") == "1":   # rehearsal of the N > 1 path on a one-GPU box (with --backend gloo): every rank on device 0
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.stderr.write("bench.py: WORLD_SIZE (%d) does not match --gpus (%d)\n" % (world, args.gpus))

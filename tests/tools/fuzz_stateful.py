@@ -3,6 +3,7 @@ piece of host state moves (radix pass counts, LDS per bucket, scan grids, voxel 
 crowded-cell switch); every frame is compared with the CPU oracle.  usage: fuzz_stateful.py [steps] [seed]"""
 import os, sys, time
 import numpy as np
+os.environ.setdefault("PCOP_VOXEL_PATH", "stream")   # the adaptive state worth shaking is the streaming path's (single frames would take the radix path by default)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa
