@@ -38,7 +38,9 @@ struct GraphKey {
     uint32_t stream, nb_cap, gbits;  // streaming voxel path: on?, buckets provided for (LDS, grids), log2 of the coarse bins (LDS)
     // (lds_ordered is fixed for the life of a context: not part of the key)
     uint32_t cgrid, ctiles;          // dense cell grid: on?, occupancy tiles (grid)
+    uint32_t vt;                     // tiled voxel path: 0 off, 1 on, 2 on with the order check
     bool operator<(const GraphKey& o) const {
+        if (vt != o.vt) return vt < o.vt;
         if (cgrid != o.cgrid) return cgrid < o.cgrid;
         if (ctiles != o.ctiles) return ctiles < o.ctiles;
         if (stream != o.stream) return stream < o.stream;
@@ -121,6 +123,22 @@ struct pcop_ctx {
     // LDS atomic adds of one wave instruction return their old values in lane order on this device (checked by
     // k_lds_order_probe when the context is made; PCOP_LDS_ORDER=0 skips the check and keeps the peer-mask ranks)
     bool lds_ordered = false;
+    // tiled voxel path (pcop_voxel_tiled.hpp): batches of frames, once the context knows a voxel box that holds its clouds (the
+    // union of the boxes of the frames it has seen since the leaf size was set, with a margin).  A batch the path refuses -
+    // a point outside the box, a bucket above its LDS, a grid it does not fit - is re-run on the streaming path.
+    bool vt_enabled = false, vt_ok = true;   // PCOP_VOXEL_TILED=1 switches it on (measured slower than the streaming path on C3: DESIGN.md 4.1b); vt_ok: this leaf size has not been refused for good
+    // The same box serves the streaming path: with the keys formed against it there is no bounds pass (k_minmax) - k_bin_hist takes the
+    // true bounds on its way and checks every point against the box.  PCOP_VOXEL_BOX=0 keeps the bounds pass.
+    bool sbox_enabled = true;
+    bool sbox_batch = false;                 // the batch in flight runs the streaming path on the box
+    bool vt_skip = false;                    // the batch in flight was refused: its re-run takes the streaming path
+    bool vt_checked = false;                 // the first tiled batch ran the build that verifies the order of every tile
+    bool vt_batch = false;                   // the batch in flight runs the tiled path
+    uint32_t vt_strikes = 0;                 // batches refused for a bucket above its LDS (three: off for this leaf size)
+    uint32_t vt_plan_cap = kVtPlanCap;       // points per bucket the plan aims at (PCOP_VT_CAP)
+    uint32_t vt_reduce_blocks = 1792;        // blocks of k_vt_accum over the whole batch (PCOP_VT_REDUCE_BLOCKS): seven to a CU
+    bool box_valid = false;
+    int32_t box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};   // voxel coordinates, inclusive
     std::vector<float> sor_sq;               // outlier removal: the squares of the mean distances
     const uint32_t* cur_n_dev = nullptr;     // the batch in flight takes frame 0's point count from the device (the cloud a filter kept)
     bool retry_to_caller = false;            // finish_batch hands a re-plan back to its caller instead of re-running the plain chain
@@ -231,6 +249,28 @@ bool stream_on(const pcop_ctx* c) {
     return c->voxel_stream && c->stream_ok && c->kind != kFrameClusterOnly && (c->nframes > 1 || c->stream_single);
 }
 
+// The tiled voxel path: a batch of the plain chain (not the node chain's parts), lane-ordered LDS atomics, a box, clouds of a
+// size it is built for.
+bool vt_on(const pcop_ctx* c) {
+    if (!(stream_on(c) && c->vt_enabled && c->vt_ok && c->lds_ordered && c->box_valid && !c->vt_skip)) return false;
+    if (c->retry_to_caller || c->cur_n_dev || c->nframes < 2) return false;
+    uint64_t cells = 1;
+    for (int a = 0; a < 3; ++a) cells *= (uint64_t)((int64_t)c->box_hi[a] - c->box_lo[a] + 1);
+    if (cells > (1ull << 30)) return false;
+    for (uint32_t f = 0; f < c->nframes; ++f)
+        if (c->slots[f].n < 4u * kVtTile || c->slots[f].n > (kVtMaxTiles - 1u) * kVtTile) return false;
+    return true;
+}
+
+// The streaming path without its bounds pass: any batch the streaming path serves, once there is a box.
+bool sbox_on(const pcop_ctx* c) {
+    if (!(stream_on(c) && c->sbox_enabled && c->box_valid && !c->vt_skip)) return false;
+    if (c->retry_to_caller || c->cur_n_dev) return false;
+    uint64_t cells = 1;
+    for (int a = 0; a < 3; ++a) cells *= (uint64_t)((int64_t)c->box_hi[a] - c->box_lo[a] + 1);
+    return cells <= (1ull << 30);
+}
+
 // The launch sequence of one batch.  nb = launch-size bucket (>= every frame's point count), nf =
 // frames; all real counts are read on the device.  Everything here is capturable into a hipGraph.
 enum LaunchParts : uint32_t { kPartVoxel = 1u, kPartCluster = 2u, kPartEmit = 4u, kPartAll = 7u,
@@ -257,12 +297,52 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
         k_frame_init<<<dim3(1, nf), 64, 0, s>>>(fr);
         mark(c, "k_frame_init");
     }
-    if (kind != kFrameClusterOnly && (parts & kPartVoxel)) {
-        k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, 0u);
-        mark(c, "k_minmax");
+    if (kind != kFrameClusterOnly && (parts & kPartVoxel) && c->vt_batch) {
+        const size_t bins = (size_t)1 << c->gbits;
+        const dim3 bt(std::max(1u, div_up(nb, kBinTile)), nf);      // tiles of the sampled histogram
+        const dim3 vtg(std::max(1u, div_up(nb, kVtTile)), nf);      // tiles of the sort
+        k_vt_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, c->npass_voxel, (uint32_t)MAXB, fold_grid, 1u);
+        mark(c, "k_vt_setup");
+        k_vt_sample<<<bt, kBinThreads, bins * 4u, s>>>(fr);
+        mark(c, "k_vt_sample");
+        k_bin_colsum<<<dim3((uint32_t)div_up((uint32_t)bins, kWave), nf), kBlock, 0, s>>>(fr);
+        mark(c, "k_bin_colsum");
+        k_bin_plan<<<dim3(1, nf), kBinThreads, plan_lds_bytes((uint32_t)bins), s>>>(fr);
+        mark(c, "k_bin_plan");
+        const bool chk = !c->vt_checked;
+        if (c->nb_cap <= 2u * kVtThreads) {
+            if (chk) k_vt_sort<2, true><<<vtg, kVtThreads, vt_sort_lds_bytes(2u * kVtThreads, 4096u), s>>>(fr);
+            else k_vt_sort<2, false><<<vtg, kVtThreads, vt_sort_lds_bytes(2u * kVtThreads, 4096u), s>>>(fr);
+        } else if (c->nb_cap <= 3u * kVtThreads) {
+            if (chk) k_vt_sort<3, true><<<vtg, kVtThreads, vt_sort_lds_bytes(3u * kVtThreads, 4096u), s>>>(fr);
+            else k_vt_sort<3, false><<<vtg, kVtThreads, vt_sort_lds_bytes(3u * kVtThreads, 4096u), s>>>(fr);
+        } else if (c->nb_cap <= 4u * kVtThreads) {
+            if (chk) k_vt_sort<4, true><<<vtg, kVtThreads, vt_sort_lds_bytes(4u * kVtThreads, 2048u), s>>>(fr);
+            else k_vt_sort<4, false><<<vtg, kVtThreads, vt_sort_lds_bytes(4u * kVtThreads, 2048u), s>>>(fr);
+        } else {
+            if (chk) k_vt_sort<8, true><<<vtg, kVtThreads, vt_sort_lds_bytes(8u * kVtThreads, 2048u), s>>>(fr);
+            else k_vt_sort<8, false><<<vtg, kVtThreads, vt_sort_lds_bytes(8u * kVtThreads, 2048u), s>>>(fr);
+        }
+        mark(c, "k_vt_sort");
+        // persistent waves, sixteen to a CU over the whole batch: each takes every grid-th bucket
+        k_vt_accum<<<dim3(std::max(1u, std::min(div_up(c->nb_cap, kWavesPerBlock), std::max(4u, c->vt_reduce_blocks / nf))), nf), kBlock, 0, s>>>(fr);
+        mark(c, "k_vt_accum");
+        k_vt_scan<<<dim3(1, nf), kBlock, 0, s>>>(fr);
+        mark(c, "k_vt_scan");
+        k_voxel_gather<<<dim3(div_up(c->nb_cap, kGatherPer), nf), kBlock, 0, s>>>(fr);
+        mark(c, "k_voxel_gather");
+    } else if (kind != kFrameClusterOnly && (parts & kPartVoxel)) {
         const bool stream = stream_on(c);
-        k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, (stream ? 1u : 0u) | 2u | fold_grid);
-        mark(c, "k_voxel_setup");
+        if (c->sbox_batch) {   // keys against the host's box: no bounds pass, k_bin_hist takes the bounds on its way
+            if (getenv("PCOP_DEBUG_KEEP_MINMAX")) { k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, 0u); mark(c, "k_minmax"); }
+            k_vt_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, c->npass_voxel, (uint32_t)MAXB, fold_grid, 2u);
+            mark(c, "k_vt_setup");
+        } else {
+            k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, 0u);
+            mark(c, "k_minmax");
+            k_voxel_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, kReduceBlocks, c->npass_voxel, (uint32_t)MAXB, (stream ? 1u : 0u) | 2u | fold_grid);
+            mark(c, "k_voxel_setup");
+        }
         if (stream) {
             const uint32_t tile = tile_for(nb, nf);
             const dim3 bt(std::max(1u, div_up(nb, tile)), nf);       // tiles of the coarse histogram and of the partition
@@ -415,15 +495,19 @@ uint32_t fill_frame_args(pcop_ctx* c) {
         a.tile = 0u; a.heavy_ok = c->heavy_ok ? 1u : 0u;   // (tile: set below, once the launch bucket is known)
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         a.n_dev = f == 0 ? c->cur_n_dev : nullptr; a.sor_thr = 0.0;
+        a.vt_on = c->vt_batch ? 1u : (c->sbox_batch ? 2u : 0u); a.plan_cap = c->vt_batch ? std::max(1u, c->vt_plan_cap / kVtSampleRows) : 0u;
+        for (int k = 0; k < 3; ++k) { a.box_lo[k] = c->box_lo[k]; a.box_dim[k] = (uint32_t)(c->box_hi[k] - c->box_lo[k] + 1); }
         nmax = std::max(nmax, sl.n);
     }
     c->frame_npass_csr = c->npass_csr;
     const uint32_t nb = bucket_of(c, nmax);
-    for (uint32_t f = 0; f < c->nframes; ++f) c->slots[f].h_args->tile = tile_for(nb, c->nframes);
+    for (uint32_t f = 0; f < c->nframes; ++f) c->slots[f].h_args->tile = c->vt_batch ? kBinTile : tile_for(nb, c->nframes);
     return nb;
 }
 
 int enqueue_batch(pcop_ctx* c) {
+    c->vt_batch = vt_on(c);
+    c->sbox_batch = !c->vt_batch && sbox_on(c);
     const uint32_t nb = fill_frame_args(c);
     c->ev_used = 0;
     if (c->profiling || !c->use_graph) {
@@ -433,7 +517,7 @@ int enqueue_batch(pcop_ctx* c) {
     } else {
         const bool st_on = stream_on(c);
         const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr | ((c->csr_onepass && c->csr_small) ? 0x100u : 0u), c->nframes, st_on ? tile_for(nb, c->nframes) : 0u, st_on ? (c->heavy_ok ? 2u : 1u) : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
-                           grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u};
+                           grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u, c->vt_batch ? (c->vt_checked ? 1u : 2u) : (c->sbox_batch ? 3u : 0u)};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -542,9 +626,28 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (e & kErrRange) { c->in_flight = false; scrub_flags(c); c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
         if (e & kErrInternal) { c->in_flight = false; scrub_flags(c); c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
         if (e & kErrSorFew) { c->in_flight = false; scrub_flags(c); c->err = "fewer points than mean_k + 1"; return PCOP_ERR_STATE; }
-        if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanBins | kErrReplanCpath | kErrReplanCtiles)) {
+        if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanBins | kErrReplanCpath | kErrReplanCtiles |
+                 kErrReplanBox | kErrReplanVt | kErrOrder)) {
             // (every adaptive piece may have to move once for a cloud unlike the last: bins, buckets, heavy bins, voxel path,
             //  pass counts, occupancy tiles, cell path, CSR form - each moves towards "larger" only, so the loop ends)
+            if (getenv("PCOP_DEBUG_REPLAN")) {
+                fprintf(stderr, "pcop: replan, attempt %d, bits 0x%x, vt %d;", attempt, e, c->vt_batch ? 1 : 0);
+                for (uint32_t f = 0; f < c->nframes; ++f) {
+                    const DevState* hs = c->slots[f].h_state;
+                    fprintf(stderr, " [f%u err 0x%x nb %u maxbin %u n_valid %u]", f, hs->err, hs->nbuckets, hs->maxbin, hs->n_valid);
+                }
+                fprintf(stderr, "\n");
+            }
+            if ((c->sbox_batch || c->vt_batch) && (e & kErrReplanBox)) {   // a point outside the box: this batch is re-run with the bounds pass
+                c->vt_skip = true;   // (whatever else a frame keyed against the wrong box reported says nothing about the cloud)
+                e &= ~(uint32_t)(kErrReplanPath | kErrReplanBins | kErrReplanVt | kErrReplanVcap);
+            } else if (c->vt_batch) {   // what the tiled voxel path refuses goes to the streaming path: this batch, or from here on
+                if (e & kErrOrder) c->lds_ordered = false;       // a tile came out in the wrong order: ranks from peer masks from here on
+                if ((e & kErrReplanVt) && ++c->vt_strikes >= 3u) c->vt_ok = false;
+                if (e & kErrReplanPath) { c->vt_ok = false; e &= ~(uint32_t)kErrReplanPath; }   // (the streaming path has its own limits)
+                if ((e & kErrReplanBins) && (c->gbits >= kBinBitsMax || c->gbits_fixed)) { c->vt_ok = false; e &= ~(uint32_t)kErrReplanBins; }
+                if ((e & (kErrReplanVt | kErrOrder)) || !c->vt_ok) c->vt_skip = true;
+            }
             if (attempt >= 16) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
             if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));
             if (kb_csr) c->npass_csr = std::max(c->npass_csr, passes_for(c, kb_csr));
@@ -576,7 +679,10 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             } else if (e & kErrReplanVcap) {
                 for (uint32_t f = 0; f < c->nframes; ++f) {
                     const DevState* hs = c->slots[f].h_state;
-                    if (hs->err & kErrReplanVcap) c->nb_cap = std::max(c->nb_cap, std::min(kNbMax, pow2_at_least(hs->nbuckets)));
+                    if (hs->err & kErrReplanVcap) {   // 1024, 1536 (the tiled path's sort still fits two blocks to a CU), 2048, 4096; the tiled path keeps one row more than it has buckets
+                        const uint32_t need = hs->nbuckets + (c->vt_batch ? 1u : 0u);
+                        c->nb_cap = std::max(c->nb_cap, need > kNbMin && need <= 3u * kVtThreads ? 3u * kVtThreads : std::min(kNbMax, pow2_at_least(need)));
+                    }
                 }
             }
             if (c->retry_to_caller) { c->in_flight = false; return 1; }   // (not a pcop_status: the caller runs its own sequence again)
@@ -588,6 +694,49 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
     }
     collect_times(c);
     c->in_flight = false;
+    if (c->vt_batch) c->vt_checked = true;   // (its tiles were verified, or an earlier batch's were)
+    c->vt_skip = false;
+    // the voxel box of the next batches: the union of the frames' own grids (every path leaves PCL's min_b / div_b in DevState),
+    // widened to multiples of eight voxels with a margin, so that it settles after a few batches of a steady source
+    if (c->kind != kFrameClusterOnly) {
+        bool grow = false;
+        int64_t lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) { lo[a] = c->box_valid ? c->box_lo[a] : INT64_MAX; hi[a] = c->box_valid ? c->box_hi[a] : INT64_MIN; }
+        for (uint32_t f = 0; f < c->nframes; ++f) {
+            const DevState* hs = c->slots[f].h_state;
+            if (hs->passthrough || !hs->n_valid) continue;
+            for (int a = 0; a < 3; ++a) {
+                const int64_t l = hs->min_b[a], h = (int64_t)hs->min_b[a] + hs->div_b[a] - 1;
+                if (l < lo[a]) { lo[a] = l; grow = true; }
+                if (h > hi[a]) { hi[a] = h; grow = true; }
+            }
+        }
+        if (grow) {
+            // The coarse bins are the top bits of the key, so a box that crosses a power of two of cells doubles every bin:
+            // the margin is the widest of 8 / 4 / 2 / 1 voxels (multiples of as many) that keeps the key as short as a margin of one does.
+            auto widened = [&](int sh, int64_t* l, int64_t* h, double* cells) {
+                const int64_t q = 1ll << sh;
+                *cells = 1.0;
+                for (int a = 0; a < 3; ++a) {
+                    l[a] = ((lo[a] - (sh ? q / 4 : 1)) >> sh) << sh;
+                    h[a] = ((((hi[a] + (sh ? q / 4 : 1)) >> sh) + 1) << sh) - 1;
+                    *cells *= (double)(h[a] - l[a] + 1);
+                }
+            };
+            auto bits_of = [](double cells) { int b = 1; while (b < 62 && std::ldexp(1.0, b) < cells) ++b; return b; };
+            int64_t l[3], h[3], lt[3], ht[3];
+            double cells, cells_tight;
+            widened(0, lt, ht, &cells_tight);
+            for (int sh = 3; sh >= 0; --sh) {
+                widened(sh, l, h, &cells);
+                if (bits_of(cells) == bits_of(cells_tight)) break;
+            }
+            bool fits = true;
+            for (int a = 0; a < 3; ++a) if (l[a] < -(1ll << 30) || h[a] > (1ll << 30)) fits = false;
+            c->box_valid = fits;
+            if (fits) for (int a = 0; a < 3; ++a) { c->box_lo[a] = (int32_t)l[a]; c->box_hi[a] = (int32_t)h[a]; }
+        }
+    }
     // adapt the pass counts of the next batch to what this one needed
     uint32_t kb_voxel = 0, kb_csr = 0;
     for (uint32_t f = 0; f < c->nframes; ++f) {
@@ -967,7 +1116,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
     TRY(dev_alloc(c, &f.table, ntiles * kMaxBins)); TRY(dev_alloc(c, &f.table_x, ntiles * kMaxBins));
     TRY(dev_alloc(c, &f.bin_total, (size_t)kMaxBins));
     TRY(dev_alloc(c, &f.tile_a, nscan)); TRY(dev_alloc(c, &f.tile_b, nscan));
-    TRY(dev_alloc(c, &f.partials, (size_t)kReduceBlocks));
+    TRY(dev_alloc(c, &f.partials, std::max<size_t>(kReduceBlocks, n / kBinTileSmall + 2)));   // (keys on the host's box: one per tile of k_bin_hist / k_vt_sort)
     TRY(dev_alloc(c, &f.hkey, hcap)); TRY(dev_alloc(c, &f.hcount, hcap)); TRY(dev_alloc(c, &f.hmin, hcap));
     TRY(dev_alloc(c, &f.cell_start, hcap)); TRY(dev_alloc(c, &f.parent, hcap));
     TRY(dev_alloc(c, &f.comp_size, hcap)); TRY(dev_alloc(c, &f.comp_rank, hcap)); TRY(dev_alloc(c, &f.cell_list, n + 1));
@@ -1019,7 +1168,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
 }
 
 int submit_common(pcop_ctx* c, uint32_t kind, bool emit_cloud, int out_layout, int is_dense) {
-    c->cur_n_dev = nullptr; c->retry_to_caller = false;
+    c->cur_n_dev = nullptr; c->retry_to_caller = false; c->vt_skip = false;
     c->is_dense = is_dense; c->kind = kind; c->emit_cloud = emit_cloud; c->out_layout = out_layout;
     return enqueue_batch(c);
 }
@@ -1069,6 +1218,10 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char* e = getenv("PCOP_VOXEL_PATH")) { c->voxel_stream = std::string(e) != "sort"; c->stream_single = std::string(e) == "stream"; }
     if (const char* e = getenv("PCOP_CSR_ONEPASS")) c->csr_onepass = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_VOXEL_TILED")) c->vt_enabled = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_VOXEL_BOX")) c->sbox_enabled = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_VT_CAP")) c->vt_plan_cap = (uint32_t)std::max(64, atoi(e));
+    if (const char* e = getenv("PCOP_VT_REDUCE_BLOCKS")) c->vt_reduce_blocks = (uint32_t)std::max(16, atoi(e));
     if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
     if (const char* e = getenv("PCOP_BIN_BITS")) { c->gbits = (uint32_t)std::min<int>(kBinBitsMax, std::max<int>(kBinBitsMin, atoi(e))); c->gbits_fixed = true; }
     if (const char* e = getenv("PCOP_CELL_BLOCKS")) c->cell_blocks = (uint32_t)std::max(64, atoi(e));
@@ -1106,9 +1259,32 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
                 hipFree(d_bad);
             }
             c->lds_ordered = bad == 0;
+            if (c->lds_ordered) {   // the eight-wave pattern of the tiled path
+                bad = 1;
+                if (hipMalloc(reinterpret_cast<void**>(&d_bad), 4) == hipSuccess) {
+                    if (hipMemsetAsync(d_bad, 0, 4, c->stream) == hipSuccess) {
+                        k_lds_order_probe8<<<64, kVtThreads, 0, c->stream>>>(d_bad);
+                        if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) bad = 1;
+                    }
+                    hipFree(d_bad);
+                }
+                if (bad) c->vt_enabled = false;
+                if (c->vt_enabled) {   // and the float adds k_vt_accum sums the voxels with
+                    bad = 1;
+                    if (hipMalloc(reinterpret_cast<void**>(&d_bad), 4) == hipSuccess) {
+                        if (hipMemsetAsync(d_bad, 0, 4, c->stream) == hipSuccess) {
+                            k_lds_float_order_probe<<<64, kBlock, 0, c->stream>>>(d_bad);
+                            if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) bad = 1;
+                        }
+                        hipFree(d_bad);
+                    }
+                    if (bad) c->vt_enabled = false;
+                }
+            }
         }
     }
     if (rc) { fprintf(stderr, "pcop_create: %s\n", c->err.c_str()); pcop_destroy(c); return rc; }
+    if (getenv("PCOP_DEBUG_REPLAN")) fprintf(stderr, "pcop: context: lds_ordered %d, tiled voxel path %s\n", c->lds_ordered ? 1 : 0, c->vt_enabled ? "on" : "off");
     *out = c;
     return PCOP_OK;
 }
@@ -1135,7 +1311,7 @@ int pcop_max_frames(const pcop_ctx* c) { return c ? (int)c->max_frames : 0; }
 int pcop_set_params(pcop_ctx* c, const pcop_params* p) {
     if (!c || !p) return PCOP_ERR_ARG;
     if (c->in_flight) { c->err = "parameters cannot change while a batch is in flight (its re-planning and ordering read them)"; return PCOP_ERR_STATE; }
-    if (!c->params_set || p->leaf != c->params.leaf) { c->stream_ok = true; c->heavy_ok = false; }   // a new leaf size is a new voxel grid
+    if (!c->params_set || p->leaf != c->params.leaf) { c->stream_ok = true; c->heavy_ok = false; c->vt_ok = true; c->vt_strikes = 0; c->box_valid = false; }   // a new leaf size is a new voxel grid
     if (!c->params_set || p->tol != c->params.tol) c->cgrid_ok = true;      // a new tolerance is a new cell grid
     c->params = *p;
     c->params_set = true;
@@ -1624,6 +1800,7 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
             break;
         }
         c->retry_to_caller = true;
+        c->vt_batch = false; c->sbox_batch = false;   // (the node chain launches by parts: the plain voxel stage with its bounds pass)
         const uint32_t nb = fill_frame_args(c);
         Frame* fr = c->d_frames;
         hipStream_t s = c->stream;
@@ -1806,6 +1983,7 @@ int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* byt
         {"cell_list", f.cell_list, n * 4}, {"partials", f.partials, (size_t)kReduceBlocks * sizeof(MinMaxPartial)},
         {"binfo", f.binfo, f.binfo.get() ? (size_t)(kNbMax + 1) * 16 : 0}, {"bin2bucket", f.bin2bucket, f.bin2bucket.get() ? (size_t)2 << kBinBitsMax : 0},
         {"cflag", f.cflag, f.cflag.get() ? (size_t)kCmapCells : 0}, {"slot_meta", f.slot_meta, h * 16},
+        {"hsub", f.hsub, f.hsub.get() ? ((size_t)kNbMax + 1) * kHeavyGroups * 16 : 0},   // (diagnostic builds: the tiled path's stamps)
     };
     for (const Ent& e : tab) {
         if (std::strcmp(e.nm, name) == 0) { *dev_ptr = e.p; *bytes = e.b; return PCOP_OK; }

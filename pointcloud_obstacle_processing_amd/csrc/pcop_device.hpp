@@ -80,6 +80,14 @@ constexpr uint32_t kNbMin = 1024, kNbMax = 4096;   // buckets per frame a launch
 constexpr uint32_t kScatThreads = 512, kScatItems = 8, kScatChunk = kScatThreads * kScatItems;   // k_bin_scatter: a tile in chunks of 4096
 constexpr uint32_t kCmapCells = 1u << 24;       // dense cell grid: largest grid (cells, margins included) with an occupancy map
 constexpr uint32_t kCoarseBits = 1u << 20;      // room for the blocks of 4x4x4 cells of the largest grid (partial blocks at the ends of y and z included)
+// tiled voxel path (pcop_voxel_tiled.hpp)
+constexpr uint32_t kVtTile = 8192;              // points per block of k_vt_sort: a tile is sorted by bucket inside its own region of the records
+constexpr uint32_t kVtThreads = 512, kVtItems = kVtTile / kVtThreads;   // 16 records per thread, held in registers
+constexpr uint32_t kVtSampleRows = 4;           // k_vt_sample reads one row of 64 points in four: the bucket plan comes from a quarter of the cloud
+constexpr uint32_t kVtPlanCap = 1536;           // points up to which the plan merges small coarse bins into one bucket (the sample's estimate; a bin above it is a bucket of its own)
+constexpr uint32_t kVtMaxTiles = 128;           // tiles of a frame k_vt_accum provides for (a wave's piece table: two rows to a lane): 1 M points
+constexpr uint32_t kVtSpan = 256;               // voxel ids of a wave of k_vt_accum: four words each in LDS
+constexpr uint32_t kVtSpanMax = 4096;           // voxel keys a tiled bucket may span (wider than kVtSpan: ids by rank in an occupancy map)
 constexpr int kCellMargin = 3;                  // empty cells around the grid: 2 for the 5x5x5 stencil + 1 of slack (a centroid
                                                 // may round a hair outside the bounding box of its points)        // voxel key / id of a dropped (non-finite) point
 
@@ -117,6 +125,9 @@ enum ErrBits : uint32_t {
     kErrSorFew = 2048u,      // statistical outlier removal on fewer than mean_k + 1 points (the reference reads past its search result)
     kErrReplanCpath = 256u,  // the dense cell grid does not apply to this frame (grid too large)
     kErrReplanCtiles = 512u, // the occupancy scan of the dense cell grid was launched with too few tiles
+    kErrReplanBox = 4096u,   // tiled voxel path: a point lies outside the bounding box the keys were formed with (the box of earlier frames)
+    kErrReplanVt = 8192u,    // tiled voxel path: a bucket holds more points than the sample promised (or the frame does not fit the path)
+    kErrOrder = 16384u,      // tiled voxel path, checking build: a tile came out in the wrong order (LDS atomics not lane-ordered after all)
 };
 
 enum FrameKind : uint32_t { kFrameChain = 0, kFrameVoxelOnly = 1, kFrameClusterOnly = 2 };
@@ -141,6 +152,10 @@ struct FrameArgs {
     DevPtr<const float> src_x, src_y, src_z;
     DevPtr<const uint32_t> n_dev;             // when set: the point count lives on the device (at most n): the cloud a previous kernel kept
     double sor_thr;                           // statistical outlier removal: mean + stddev_mul * sigma, formed by the host between the two halves of the node chain
+    // tiled voxel path: the voxel box the keys are formed with (a superset of every earlier frame's), the plan's bucket size in sampled points
+    uint32_t vt_on, plan_cap;                 // vt_on: 1 tiled path, 2 streaming path on the host's box (no k_minmax)
+    int32_t box_lo[3];
+    uint32_t box_dim[3];
 };
 
 // Device-resident frame state; k_emit copies it to pinned host memory at the end of a frame.
@@ -187,6 +202,12 @@ struct DevState {
     int32_t  c0[3];         // cell coordinate of grid position 0 (margin included)
     uint32_t c_dim[3];      // grid size per axis, margins included
     uint32_t maxbin;        // streaming voxel path: points in the fullest coarse bin (the host tunes gbits with it)
+    // tiled voxel path
+    uint32_t vt;            // 1: this frame's voxel stage runs the tiled path (keys relative to the host's box until k_voxel_gather puts PCL's own grid here)
+    uint32_t plan_cap;      // k_bin_plan: points per bucket (in the units of the histogram it is given); 0: kBucketCap
+    uint32_t vt_nonfinite;  // non-finite points k_vt_sort / k_bin_hist dropped
+    uint32_t sbox;          // 1: the voxel keys of this frame are formed against the host's box (tiled path, or the streaming path without its
+                            // bounds pass); k_voxel_gather / k_vt_scan put PCL's own grid here when the keys are done with
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState layout");
 
@@ -408,6 +429,7 @@ struct CellMarker {
 
 // the kernels, by stage (each part opens namespace pcop itself)
 #include "pcop_voxel.hpp"
+#include "pcop_voxel_tiled.hpp"
 #include "pcop_cells_hash.hpp"
 #include "pcop_cells_grid.hpp"
 #include "pcop_clusters.hpp"

@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 // Any bucket plan that respects the two limits gives the same result, so the host may tune gbits freely.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool stream_off(const DevState* st) {
-    return voxel_stage_off(st) || !st->vpath || st->n_valid == 0;
+    return voxel_stage_off(st) || !st->vpath || (st->n_valid == 0 && !st->sbox);   // (on the host's box the valid points are counted as the cloud is read)
 }
 
 // Diagnostic build only (-DPCOP_STAMPS): the shader clock at phase borders of one block of a kernel, into a buffer that
@@ -726,6 +726,12 @@ __device__ __forceinline__ bool stream_off(const DevState* st) {
 #else
 #define PCOP_STAMP(F, kern, idx, blk) do { } while (0)
 #endif
+
+// The same pass when the keys are formed against the host's box (DevState::sbox): there is no bounds pass before it, so it
+// also takes the true bounds of its tile (min / max are exact in any order), counts the valid points and checks every point
+// against the box (one outside: kErrReplanBox, the host re-runs the batch with the bounds pass).
+struct BoxKey;
+__device__ __forceinline__ void bin_hist_on_box(Frame& F, uint32_t* s_hist, uint32_t tile_base, uint32_t tile, uint32_t n, uint32_t G, uint32_t cs);
 
 __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -745,6 +751,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     VoxelKey key; key.init(st);
     bool bad = false;
     constexpr int kRound = kBinTileSmall / kBinThreads;   // records in flight per thread: 4
+    if (st->sbox) { bin_hist_on_box(F, s_hist, tile_base, tile, n, G, cs); return; }
     for (uint32_t r0 = 0; r0 < tile / kBinThreads; r0 += kRound) {
         Rec3 r[kRound];
 #pragma unroll
@@ -817,6 +824,10 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
     uint4* __restrict__ binfo = F.binfo;
     uint32_t* __restrict__ bucket_pub = F.bucket_pub;
     if (stream_off(st)) return;
+    if (st->sbox && !st->vt && st->n_valid == 0u) {   // (k_bin_hist found nothing valid in the cloud: an empty output, as voxel_setup makes it)
+        if (threadIdx.x == 0) { st->nbuckets = 0u; finish_voxel(st, 0); }
+        return;
+    }
     const uint32_t G = 1u << st->gbits, cs = st->cshift;
     const uint32_t per = G >= kBinThreads ? G / kBinThreads : 1u;
     uint32_t* s_Pp = reinterpret_cast<uint32_t*>(s_dyn);                                   // points before bin i (i = 0 .. G), padded
@@ -857,18 +868,23 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
     uint32_t maxbin = 0u;
 #pragma unroll
     for (int i = 0; i < NW; ++i) maxbin = max(maxbin, s_max[i]);
-    if (threadIdx.x == 0) st->maxbin = maxbin;
-    const uint32_t bmax = min(G, kBucketCells >> cs);   // bins a bucket may span
+    // The tiled path plans on a sample of the cloud (one point in kVtSampleRows): the capacity comes in the sample's units, and
+    // every segment becomes a bucket whether the sample saw points in it or not (the cloud may still have some there).
+    const bool vt = st->vt != 0u;
+    const uint32_t kCap = st->plan_cap ? st->plan_cap : kBucketCap;
+    if (threadIdx.x == 0) st->maxbin = vt ? maxbin * kVtSampleRows : maxbin;
+    const uint32_t bmax = min(G, (vt ? kVtSpanMax : kBucketCells) >> cs);   // bins a bucket may span
     // A bin with more points than a bucket: finer bins are asked for; when there are none finer (a dense sheet of points
     // lying in a few rows of the key space) the bin becomes a bucket of its own - the window rule below does that by
     // itself - which k_heavy_split cuts into buckets along the keys before k_bucket_reduce sees it.
     const bool finest = st->gbits >= kBinBitsMax || cs == 0u;
-    if (bmax == 0u || (maxbin > kBucketCap && !(finest && (*F.args).heavy_ok && maxbin <= kHeavyMax))) {
+    // (the tiled path's reduce takes a bucket of any size: there the capacity only says how far small bins are merged)
+    if (bmax == 0u || (!vt && maxbin > kCap && !(finest && (*F.args).heavy_ok && maxbin <= kHeavyMax))) {
         if (threadIdx.x == 0) atomicOr(&st->err, (uint32_t)kErrReplanBins);
         return;
     }
     // window of a bin: (points of its group before it) / capacity.  bmax is a power of two (both G and the cell limit are).
-    auto window = [&](uint32_t b, uint32_t pb) -> uint32_t { return (pb - P(b & ~(bmax - 1u))) / kBucketCap; };
+    auto window = [&](uint32_t b, uint32_t pb) -> uint32_t { return (pb - P(b & ~(bmax - 1u))) / kCap; };
     auto wstart = [&](uint32_t b, uint32_t pb, uint32_t bprev_p) -> bool {   // a window starts at bin b (b < G)
         return (b & (bmax - 1u)) == 0u || window(b, pb) != window(b - 1u, bprev_p);
     };
@@ -908,7 +924,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
                 if ((uint32_t)k + 1u < per) lastw = (wbits >> (k + 1)) & 1u;
                 else lastw = b + 1u >= G || wstart(b + 1u, pend, r);
                 const uint32_t wf = s_first[wi - 1u];
-                const bool alone = lastw && wf != b && pend - P(wf) > kBucketCap;
+                const bool alone = lastw && wf != b && pend - P(wf) > kCap;
                 if (ws || alone) { sbits |= 1u << k; ++nstart; }
                 r = pend;
             }
@@ -933,7 +949,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
         for (int k = 0; k < kPerMax; ++k) {
             if ((uint32_t)k < per) {
                 if ((sbits >> k) & 1u) {
-                    if (P(s_first[si + 1u]) != r) { fbits |= 1u << k; ++nfull; }
+                    if (vt || P(s_first[si + 1u]) != r) { fbits |= 1u << k; ++nfull; }
                     ++si;
                 }
                 r += c[k];
@@ -944,10 +960,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
     const uint32_t bk0 = block_excl_scan_n<NW>(nfull, s_w, &nb);
     if (threadIdx.x == 0) {
         st->nbuckets = nb;
-        if (nb > kNbMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
-        else if (nb > st->nb_cap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
+        // (the tiled path keeps one row more than it has buckets: the tiles' totals)
+        if (nb + (vt ? 1u : 0u) > kNbMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
+        else if (nb + (vt ? 1u : 0u) > st->nb_cap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
     }
-    if (nb > kNbMax) return;
+    if (nb + (vt ? 1u : 0u) > kNbMax) return;
     PCOP_STAMP(F, 0, 4, 0);
     if (mine) {
         uint32_t si = seg0, bk = bk0, r = run0;
@@ -1154,7 +1171,7 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
     const uint32_t tile_base = blockIdx.x * st->tile;
     if (tile_base >= n) return;
     const uint32_t nbc = PB * kScatThreads, nb = st->nbuckets, G = 1u << st->gbits, cs = st->cshift;
-    if (st->nb_cap != nbc) return;   // (the host launches the instance that matches)
+    if (st->nb_cap > nbc) return;   // (the host launches an instance that fits)
     Rec3* stage = reinterpret_cast<Rec3*>(s_dyn);
     unsigned long long* s_match = reinterpret_cast<unsigned long long*>(s_dyn);   // shares the staging area (used in turns)
     uint16_t* sbkt = reinterpret_cast<uint16_t*>(s_dyn + (size_t)kScatChunk * 12u);

@@ -1,0 +1,148 @@
+"""The tiled voxel path (csrc/pcop_voxel_tiled.hpp) against the CPU oracle, through the C ABI.
+
+The path (opt-in: PCOP_VOXEL_TILED=1) serves batches of frames once the context knows a voxel box (the first batch runs the
+streaming path and leaves one); keys against that box, a bucket plan from a sample, a tile-local sort, a wave per bucket
+that sums with lane-ordered float adds to LDS.  Whatever it refuses must come back from the streaming path with the same
+bytes.  Bit-exact centroids and indices throughout.
+"""
+import numpy as np
+import pytest
+
+from pointcloud_obstacle_processing_amd import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pointcloud_obstacle_processing_amd import capi as m
+    m.load_library()
+    return m
+
+
+@pytest.fixture(autouse=True)
+def tiled_on(monkeypatch):
+    monkeypatch.setenv("PCOP_VOXEL_TILED", "1")
+
+
+def same(got, ref):
+    assert got["num_voxels"] == len(ref["voxel_xyz"])
+    if len(ref["voxel_xyz"]):
+        assert got["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes(), "centroids differ"
+        assert np.max(np.abs(got["voxel_xyz"] - ref["voxel_xyz"]), initial=0.0) <= 1e-4   # the north star's bound, written out
+    assert np.array_equal(got["offsets"], ref["offsets"]) and np.array_equal(got["indices"], ref["indices"])
+
+
+def run(c, clouds, refs, is_dense=True):
+    c.submit_batch_host(clouds, is_dense=is_dense)
+    got = c.wait_batch()
+    for g, r in zip(got, refs):
+        same(g, r)
+    return c.debug_state()
+
+
+def test_tiled_path_matches_oracle(capi, oracle):
+    """Three rounds of one batch: the streaming path (no box yet), the tiled path with its order check, the tiled path."""
+    p = synth.params_of("C3")
+    clouds = [synth.make_cloud("C3", n=150_000, seed=310), synth.make_cloud("C3", n=100_000, seed=311),
+              synth.make_cloud("C3", n=150_000, seed=312), synth.uniform_field(40_000, 9)]
+    refs = [oracle.process_xyz(c, **p) for c in clouds]
+    c = capi.Context(150_000, max_frames=4)
+    c.set_params(publish_clouds=1, **p)
+    seen = []
+    for _ in range(3):
+        st = run(c, clouds, refs)
+        seen.append(int(st.vt))
+        # every path leaves PCL's own grid in DevState
+        pts = clouds[0]
+        inv = f32(1.0) / f32(p["leaf"])
+        lo = np.floor(pts.min(axis=0) * inv).astype(np.int64)
+        hi = np.floor(pts.max(axis=0) * inv).astype(np.int64)
+        assert list(st.min_b) == list(lo) and list(st.div_b) == list(hi - lo + 1)
+        assert st.n_valid == len(pts) and st.passthrough == 0
+    assert seen == [0, 1, 1], seen
+    c.close()
+
+
+def test_tiled_path_point_outside_the_box(capi, oracle):
+    """A frame with a point beyond the box of the earlier frames: the batch is re-run on the streaming path, the box grows."""
+    p = synth.params_of("C3")
+    a = [synth.make_cloud("C3", n=80_000, seed=320 + i) for i in range(2)]
+    b = [a[0].copy(), a[1].copy()]
+    b[1][12345] = (7.25, -3.5, 2.0)
+    ra = [oracle.process_xyz(c, **p) for c in a]
+    rb = [oracle.process_xyz(c, **p) for c in b]
+    c = capi.Context(80_000, max_frames=2)
+    c.set_params(publish_clouds=1, **p)
+    assert run(c, a, ra).vt == 0
+    assert run(c, a, ra).vt == 1
+    assert run(c, b, rb).vt == 0      # refused, re-run
+    # the box holds the far point now; it is also sixteen times the cells, and whether the tiled path still fits such a
+    # sparse grid (coarse bins wider, buckets limited by the keys they may span) is its own business: same bytes either way
+    run(c, b, rb)
+    run(c, a, ra)
+    c.close()
+
+
+@pytest.mark.parametrize("cap", ["256", "8192"])
+def test_tiled_path_any_plan_same_result(capi, oracle, monkeypatch, cap):
+    """The sample's plan only divides the work: tiny buckets or buckets far above the estimate give the same bytes."""
+    monkeypatch.setenv("PCOP_VT_CAP", cap)
+    p = synth.params_of("C3")
+    clouds = [synth.make_cloud("C3", n=90_000, seed=330 + i) for i in range(2)]
+    refs = [oracle.process_xyz(c, **p) for c in clouds]
+    c = capi.Context(90_000, max_frames=2)
+    c.set_params(publish_clouds=1, **p)
+    run(c, clouds, refs)
+    for _ in range(2):
+        assert run(c, clouds, refs).vt == 1
+    c.close()
+
+
+def test_tiled_path_nan_points_and_organised_order(capi, oracle):
+    """is_dense = false with NaN holes; a cloud sorted along x (every tile falls into a few buckets: long pieces)."""
+    p = synth.params_of("C3")
+    a = synth.make_cloud("C3", n=120_000, seed=340)
+    a[::97] = np.nan
+    a[5::1001, 1] = np.inf
+    b = synth.make_cloud("C3", n=120_000, seed=341)
+    b = b[np.argsort(b[:, 0], kind="stable")]
+    clouds = [a, b]
+    refs = [oracle.process_xyz(c, is_dense=False, **p) for c in clouds]
+    c = capi.Context(120_000, max_frames=2)
+    c.set_params(publish_clouds=1, **p)
+    assert run(c, clouds, refs, is_dense=False).vt == 0
+    for _ in range(2):
+        st = run(c, clouds, refs, is_dense=False)
+        assert st.vt == 1 and st.n_valid == int(np.isfinite(a).all(axis=1).sum())
+    # the same cloud declared dense: the reference is undefined there, the ABI says so on every path
+    with pytest.raises(capi.PcopError):
+        run(c, clouds, refs, is_dense=True)
+    c.close()
+
+
+@pytest.mark.parametrize("config,n", [("C2", 100_000), ("C1", 40_000)])
+def test_tiled_path_other_shapes(capi, oracle, config, n):
+    """Clouds with about one point per voxel (wide buckets: ids through the occupancy map) on the tiled path."""
+    p = synth.params_of(config)
+    clouds = [synth.make_cloud(config, n=n, seed=350 + i) for i in range(3)]
+    refs = [oracle.process_xyz(c, **p) for c in clouds]
+    c = capi.Context(n, max_frames=3)
+    c.set_params(publish_clouds=1, **p)
+    run(c, clouds, refs)
+    for _ in range(2):
+        assert run(c, clouds, refs).vt == 1
+    c.close()
+
+
+def test_tiled_path_switched_off(capi, oracle, monkeypatch):
+    monkeypatch.setenv("PCOP_VOXEL_TILED", "0")
+    p = synth.params_of("C3")
+    clouds = [synth.make_cloud("C3", n=70_000, seed=360 + i) for i in range(2)]
+    refs = [oracle.process_xyz(c, **p) for c in clouds]
+    c = capi.Context(70_000, max_frames=2)
+    c.set_params(publish_clouds=1, **p)
+    for _ in range(3):
+        assert run(c, clouds, refs).vt == 0
+    c.close()
