@@ -1448,9 +1448,8 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     static_assert(kHeavyGroups <= 128u, "k_heavy_split matches groups on 7 bits");
     static_assert(kPlane * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPlane * 12u];   // occupancy bits + running counts, then the staged records (three planes)
-    __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kBucketCap];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3
-    __shared__ __attribute__((aligned(16))) uint16_t s_run[kBucketCap + 8u];   // per voxel id: its points, then the start of its run in the staged bucket
-    __shared__ __attribute__((aligned(16))) uint16_t s_vr[kBucketCap + 8u];    // per voxel id: occupied ids before it = its rank in the bucket
+    __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kBucketCap];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3; then the waves' places
+    __shared__ __attribute__((aligned(16))) uint16_t s_vs[kBucketCap + 8u];   // per occupied voxel id, in order: where its run starts in the staged bucket; then the end of the last run
     __shared__ unsigned long long s_match[ORDERED ? 1u : NW * 96u];   // per wave: 64 + 32 peer-mask words (voxel ids below 2048)
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     Frame& F = frames[blockIdx.y];
@@ -1583,81 +1582,72 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     }
     __syncthreads();
     PCOP_STAMP(F, 2, 5, 150);
-    // points per id (a thread takes ids t, t + 256, ...: neighbouring words), then run starts and ranks of the occupied ids
-    // (thread t owns ids t * 8 .. t * 8 + 7: one 16-byte access each way)
-#pragma unroll
-    for (uint32_t k = 0; k < kItemsB; ++k) {
-        if (k * kBlock >= nidr) break;
-        const uint32_t v = k * kBlock + threadIdx.x;
-        const uint32_t a = s_wc[v], q = s_wc[kBucketCap + v];
-        s_run[v] = (uint16_t)((a & 0xFFFFu) + (a >> 16) + (q & 0xFFFFu) + (q >> 16));
-    }
-    __syncthreads();
-    PCOP_STAMP(F, 2, 6, 150);
-    uint4* run4 = reinterpret_cast<uint4*>(s_run) + threadIdx.x;
-    uint4* vr4 = reinterpret_cast<uint4*>(s_vr) + threadIdx.x;
-    const uint4 t4 = threadIdx.x * kItemsB < nidr ? *run4 : make_uint4(0u, 0u, 0u, 0u);   // (beyond nidr: no ids, stale words)
-    const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
-    uint32_t tsum = 0u;   // low half: points, high half: occupied ids
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t lo = tw[q] & 0xFFFFu, hi = tw[q] >> 16;
-        tsum += lo + hi + (lo ? 0x10000u : 0u) + (hi ? 0x10000u : 0u);
-    }
-    uint32_t ttot;
-    uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
-    const uint32_t nvox = ttot >> 16;
+    // Thread t owns ids 8 t .. 8 t + 7 (two 16-byte reads per count plane): points per id, then - after one scan over the
+    // block that carries the points in its low half and the occupied ids in its high half - every wave's place for every
+    // id (written back over the counts: the staging step then needs one word per record), and the run starts of the
+    // OCCUPIED ids in order (s_vs), so that the sums below give every lane a voxel.
+    uint32_t nvox = 0u;
     {
-        uint32_t ro[4], vo[4];
+        const bool mine = threadIdx.x * kItemsB < nidr;
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+        const uint4* wc4 = reinterpret_cast<const uint4*>(s_wc);
+        const uint4 a0 = mine ? wc4[threadIdx.x * 2u] : z4, a1 = mine ? wc4[threadIdx.x * 2u + 1u] : z4;
+        const uint4 q0 = mine ? wc4[kBucketCap / 4u + threadIdx.x * 2u] : z4, q1 = mine ? wc4[kBucketCap / 4u + threadIdx.x * 2u + 1u] : z4;
+        // cw[2 q] = the word of waves 0, 1 for id 8 t + q, cw[2 q + 1] = that of waves 2, 3
+        uint32_t cw[16] = {a0.x, q0.x, a0.y, q0.y, a0.z, q0.z, a0.w, q0.w, a1.x, q1.x, a1.y, q1.y, a1.z, q1.z, a1.w, q1.w};
+        uint32_t tsum = 0u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t lo = tw[q] & 0xFFFFu, hi = tw[q] >> 16;
-            const uint32_t r0 = srun & 0xFFFFu, v0 = srun >> 16; srun += lo + (lo ? 0x10000u : 0u);
-            const uint32_t r1 = srun & 0xFFFFu, v1 = srun >> 16; srun += hi + (hi ? 0x10000u : 0u);
-            ro[q] = r0 | (r1 << 16); vo[q] = v0 | (v1 << 16);
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t c = (cw[2 * q] & 0xFFFFu) + (cw[2 * q] >> 16) + (cw[2 * q + 1] & 0xFFFFu) + (cw[2 * q + 1] >> 16);
+            tsum += c + (c ? 0x10000u : 0u);
         }
-        *run4 = make_uint4(ro[0], ro[1], ro[2], ro[3]);
-        *vr4 = make_uint4(vo[0], vo[1], vo[2], vo[3]);
+        uint32_t ttot;
+        uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
+        nvox = ttot >> 16;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t c0 = cw[2 * q] & 0xFFFFu, c1 = cw[2 * q] >> 16, c2 = cw[2 * q + 1] & 0xFFFFu, c3 = cw[2 * q + 1] >> 16;
+            const uint32_t c = c0 + c1 + c2 + c3;
+            const uint32_t r = srun & 0xFFFFu;
+            if (c) s_vs[srun >> 16] = (uint16_t)r;
+            cw[2 * q] = r | ((r + c0) << 16);
+            cw[2 * q + 1] = (r + c0 + c1) | ((r + c0 + c1 + c2) << 16);
+            srun += c + (c ? 0x10000u : 0u);
+        }
+        if (mine) {
+            uint4* wo4 = reinterpret_cast<uint4*>(s_wc);
+            wo4[threadIdx.x * 2u] = make_uint4(cw[0], cw[2], cw[4], cw[6]); wo4[threadIdx.x * 2u + 1u] = make_uint4(cw[8], cw[10], cw[12], cw[14]);
+            wo4[kBucketCap / 4u + threadIdx.x * 2u] = make_uint4(cw[1], cw[3], cw[5], cw[7]); wo4[kBucketCap / 4u + threadIdx.x * 2u + 1u] = make_uint4(cw[9], cw[11], cw[13], cw[15]);
+        }
+        if (threadIdx.x == 0) s_vs[nvox] = (uint16_t)(ttot & 0xFFFFu);
     }
-    if (threadIdx.x == 0) s_run[kBucketCap] = (uint16_t)(ttot & 0xFFFFu);
     __syncthreads();
     PCOP_STAMP(F, 2, 7, 150);
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
         if (act[j]) {
-            const uint32_t d = id[j];
-            const uint32_t a = s_wc[d], q = s_wc[kBucketCap + d];
-            uint32_t woff = 0u;   // points of the lower waves with this id
-            if (w >= 1u) woff += a & 0xFFFFu;
-            if (w >= 2u) woff += a >> 16;
-            if (w >= 3u) woff += q & 0xFFFFu;
-            const uint32_t slot = (uint32_t)s_run[d] + woff + rank[j];
+            const uint32_t slot = ((s_wc[wword * kBucketCap + id[j]] >> wshift) & 0xFFFFu) + rank[j];
             const uint32_t ps = slot + (slot >> 5);
             stage_x[ps] = rec[j].x; stage_y[ps] = rec[j].y; stage_z[ps] = rec[j].z;
         }
     }
     __syncthreads();
     PCOP_STAMP(F, 2, 8, 150);
-    // one lane per id: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count).  The centroid
+    // one lane per VOXEL: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count).  The centroid
     // of the bucket's v-th voxel goes to place (first record of the bucket + v) of the scratch records: a bucket has at
     // least as many records as voxels, so the places of different buckets do not meet; k_voxel_gather moves them to their ranks.
+    for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
+        const uint32_t s0 = s_vs[v], e0 = s_vs[v + 1u];
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (uint32_t q = s0; q < e0; q += 4u) {   // four records requested at a time (clamped), added in order
+            float vx[4], vy[4], vz[4];
 #pragma unroll
-    for (uint32_t k = 0; k < kItemsB; ++k) {
-        if (k * kBlock >= nidr) break;
-        const uint32_t v = k * kBlock + threadIdx.x;
-        const uint32_t s0 = s_run[v], e0 = s_run[v + 1u];
-        if (e0 > s0) {
-            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-            for (uint32_t q = s0; q < e0; q += 4u) {   // four records requested at a time (clamped), added in order
-                float vx[4], vy[4], vz[4];
+            for (uint32_t u = 0; u < 4u; ++u) { const uint32_t qq = min(q + u, e0 - 1u), ps = qq + (qq >> 5); vx[u] = stage_x[ps]; vy[u] = stage_y[ps]; vz[u] = stage_z[ps]; }
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) { const uint32_t qq = min(q + u, e0 - 1u), ps = qq + (qq >> 5); vx[u] = stage_x[ps]; vy[u] = stage_y[ps]; vz[u] = stage_z[ps]; }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
-            }
-            const float fc = (float)(e0 - s0);
-            scratch[info_b.x + nv_acc + s_vr[v]] = make_float4(sx / fc, sy / fc, sz / fc, 0.0f);
+            for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
         }
+        const float fc = (float)(e0 - s0);
+        scratch[info_b.x + nv_acc + v] = make_float4(sx / fc, sy / fc, sz / fc, 0.0f);
     }
     nv_acc += nvox;
     PCOP_STAMP(F, 2, 20, 150);
