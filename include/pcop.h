@@ -276,6 +276,9 @@ int pcop_device_count(void);
  * ("cen_x", "rec_a", "cell_key", "parent", "label", ... ; "state" = the frame's DevState).
  * Used by the stage-wise parity tests only; not part of the drop-in surface. */
 int pcop_debug_buffer(pcop_ctx* ctx, const char* name, void** dev_ptr, size_t* bytes);
+/* Test hook: a named host-side counter of the context ("internal_retries": batches queued a second time after a bounded
+ * device-side wait ran out; "replans": batches re-run with larger launch parameters or on another path). */
+int pcop_debug_counter(pcop_ctx* ctx, const char* name, uint64_t* value);
 
 #ifdef __cplusplus
 }

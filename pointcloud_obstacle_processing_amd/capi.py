@@ -20,7 +20,7 @@ EXPORTS = [
     "pcop_set_profiling", "pcop_get_stage_times", "pcop_stream", "pcop_voxel_downsample", "pcop_euclidean_clusters",
     "pcop_process_pointcloud2", "pcop_process_xyz", "pcop_submit_xyz", "pcop_wait", "pcop_cluster_summaries",
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
-    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_segment_planes", "pcop_debug_buffer", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
+    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_segment_planes", "pcop_debug_buffer", "pcop_debug_counter", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
     "pcop_cluster_summaries_frame", "pcop_occupancy_grid_dims", "pcop_occupancy_filter", "pcop_process_filtered",
     "pcop_statistical_outlier_removal",
 ]
@@ -87,7 +87,7 @@ class DevState(C.Structure):
                 ("vpath", C.c_uint32), ("gbits", C.c_uint32), ("cshift", C.c_uint32), ("nbuckets", C.c_uint32), ("nb_cap", C.c_uint32),
                 ("cgrid_req", C.c_uint32), ("cpath", C.c_uint32), ("cmap_words", C.c_uint32), ("c_rowbits", C.c_uint32),
                 ("c_plane", C.c_uint32), ("c0", C.c_int32 * 3), ("c_dim", C.c_uint32 * 3), ("maxbin", C.c_uint32),
-                ("vt", C.c_uint32), ("plan_cap", C.c_uint32), ("vt_nonfinite", C.c_uint32), ("sbox", C.c_uint32)]
+                ("vt", C.c_uint32), ("plan_cap", C.c_uint32), ("vt_nonfinite", C.c_uint32), ("spin_limit", C.c_uint32), ("pad0", C.c_uint32), ("sbox", C.c_uint32)]
 
 
 _lib = None
@@ -181,6 +181,8 @@ def load_library():
     L.pcop_dev_download.argtypes = [vp, C.c_void_p, vp, C.c_size_t]
     L.pcop_device_count.restype = C.c_int
     L.pcop_device_count.argtypes = []
+    L.pcop_debug_counter.restype = C.c_int
+    L.pcop_debug_counter.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
     L.pcop_debug_buffer.restype = C.c_int
     L.pcop_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     _lib = L
@@ -473,6 +475,11 @@ class Context:
         if out.nbytes:
             self._chk(self.lib.pcop_dev_download(self.h, out.ctypes.data, p, out.nbytes))
         return out
+
+    def debug_counter(self, name):
+        v = C.c_uint64(0)
+        self._chk(self.lib.pcop_debug_counter(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def debug_state(self):
         p, b = C.c_void_p(), C.c_size_t()

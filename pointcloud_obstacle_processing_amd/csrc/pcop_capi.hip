@@ -137,6 +137,13 @@ struct pcop_ctx {
     uint32_t vt_strikes = 0;                 // batches refused for a bucket above its LDS (three: off for this leaf size)
     uint32_t vt_plan_cap = kVtPlanCap;       // points per bucket the plan aims at (PCOP_VT_CAP)
     uint32_t vt_reduce_blocks = 1792;        // blocks of k_vt_accum over the whole batch (PCOP_VT_REDUCE_BLOCKS): seven to a CU
+    // A bounded device-side wait that runs out (kErrInternal: a block polled a lower block's publish word too long - only
+    // possible when the GPU is shared so heavily that blocks of one launch are kept apart) costs a re-run, not the frame: the batch is
+    // queued once more, by eager launches.  PCOP_DEBUG_SPIN0=1 makes the first batch of a context give up at its first poll (tests).
+    bool internal_retry = false;             // the batch in flight is such a re-run
+    bool debug_spin0 = false;                // the next batch runs with a spin limit of zero
+    uint32_t internal_retries = 0;           // re-runs so far (diagnostics)
+    uint64_t replans = 0;                    // batches re-run with other launch parameters / on another path (diagnostics)
     bool box_valid = false;
     int32_t box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};   // voxel coordinates, inclusive
     std::vector<float> sor_sq;               // outlier removal: the squares of the mean distances
@@ -495,6 +502,7 @@ uint32_t fill_frame_args(pcop_ctx* c) {
         a.tile = 0u; a.heavy_ok = c->heavy_ok ? 1u : 0u;   // (tile: set below, once the launch bucket is known)
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         a.n_dev = f == 0 ? c->cur_n_dev : nullptr; a.sor_thr = 0.0;
+        a.spin_limit = (c->debug_spin0 && !c->internal_retry) ? 0u : kSpinLimit; a.pad1 = 0u;
         a.vt_on = c->vt_batch ? 1u : (c->sbox_batch ? 2u : 0u); a.plan_cap = c->vt_batch ? std::max(1u, c->vt_plan_cap / kVtSampleRows) : 0u;
         for (int k = 0; k < 3; ++k) { a.box_lo[k] = c->box_lo[k]; a.box_dim[k] = (uint32_t)(c->box_hi[k] - c->box_lo[k] + 1); }
         nmax = std::max(nmax, sl.n);
@@ -510,7 +518,7 @@ int enqueue_batch(pcop_ctx* c) {
     c->sbox_batch = !c->vt_batch && sbox_on(c);
     const uint32_t nb = fill_frame_args(c);
     c->ev_used = 0;
-    if (c->profiling || !c->use_graph) {
+    if (c->profiling || !c->use_graph || c->internal_retry) {
         mark(c, "start");
         enqueue_launches(c, c->kind, nb, c->nframes);
         HIPCHK(c, hipGetLastError());
@@ -624,12 +632,22 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         // beyond the tiles its scan was launched with)
         if (e & kErrNonFinite) { c->in_flight = false; scrub_flags(c); c->err = "non-finite coordinates where the reference is undefined"; return PCOP_ERR_NONFINITE; }
         if (e & kErrRange) { c->in_flight = false; scrub_flags(c); c->err = "a neighbour-grid cell coordinate exceeds +-2^20 (|coordinate| / tolerance too large)"; return PCOP_ERR_RANGE; }
-        if (e & kErrInternal) { c->in_flight = false; scrub_flags(c); c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE; }
+        if (e & kErrInternal) {
+            if (!c->internal_retry && !c->retry_to_caller) {   // once more, by eager launches (the flags a frame given up half-way left behind are cleared first)
+                c->internal_retry = true; ++c->internal_retries;
+                scrub_flags(c);
+                int rc = enqueue_batch(c);
+                if (rc) { c->internal_retry = false; return rc; }
+                continue;
+            }
+            c->in_flight = false; c->internal_retry = false; scrub_flags(c); c->err = "internal: a bounded device-side wait ran out"; return PCOP_ERR_STATE;
+        }
         if (e & kErrSorFew) { c->in_flight = false; scrub_flags(c); c->err = "fewer points than mean_k + 1"; return PCOP_ERR_STATE; }
         if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanBins | kErrReplanCpath | kErrReplanCtiles |
                  kErrReplanBox | kErrReplanVt | kErrOrder)) {
             // (every adaptive piece may have to move once for a cloud unlike the last: bins, buckets, heavy bins, voxel path,
             //  pass counts, occupancy tiles, cell path, CSR form - each moves towards "larger" only, so the loop ends)
+            ++c->replans;
             if (getenv("PCOP_DEBUG_REPLAN")) {
                 fprintf(stderr, "pcop: replan, attempt %d, bits 0x%x, vt %d;", attempt, e, c->vt_batch ? 1 : 0);
                 for (uint32_t f = 0; f < c->nframes; ++f) {
@@ -694,6 +712,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
     }
     collect_times(c);
     c->in_flight = false;
+    c->internal_retry = false; c->debug_spin0 = false;
     if (c->vt_batch) c->vt_checked = true;   // (its tiles were verified, or an earlier batch's were)
     c->vt_skip = false;
     // the voxel box of the next batches: the union of the frames' own grids (every path leaves PCL's min_b / div_b in DevState),
@@ -1220,6 +1239,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_CSR_ONEPASS")) c->csr_onepass = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VOXEL_TILED")) c->vt_enabled = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VOXEL_BOX")) c->sbox_enabled = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_DEBUG_SPIN0")) c->debug_spin0 = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VT_CAP")) c->vt_plan_cap = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_VT_REDUCE_BLOCKS")) c->vt_reduce_blocks = (uint32_t)std::max(16, atoi(e));
     if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
@@ -1988,6 +2008,13 @@ int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* byt
     for (const Ent& e : tab) {
         if (std::strcmp(e.nm, name) == 0) { *dev_ptr = e.p; *bytes = e.b; return PCOP_OK; }
     }
+    return PCOP_ERR_ARG;
+}
+
+int pcop_debug_counter(pcop_ctx* c, const char* name, uint64_t* value) {
+    if (!c || !name || !value) return PCOP_ERR_ARG;
+    if (std::strcmp(name, "internal_retries") == 0) { *value = c->internal_retries; return PCOP_OK; }
+    if (std::strcmp(name, "replans") == 0) { *value = c->replans; return PCOP_OK; }
     return PCOP_ERR_ARG;
 }
 

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames) {
     for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
         uint32_t q = ld_agent(tile_pub + t), spins = 0;
         while (q == 0u) {
-            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); q = 1u; break; }
+            if (++spins > st->spin_limit) { atomicOr(&st->err, (uint32_t)kErrInternal); q = 1u; break; }
             __builtin_amdgcn_s_sleep(2);
             q = ld_agent(tile_pub + t);
         }

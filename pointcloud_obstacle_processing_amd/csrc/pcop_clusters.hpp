@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void k_kept_apply(Frame* frames, uint32_t n
         unsigned long long q = __hip_atomic_load(tile_pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t spins = 0;
         while ((q >> 32) == 0ull) {
-            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); q = 1ull << 32; break; }
+            if (++spins > st->spin_limit) { atomicOr(&st->err, (uint32_t)kErrInternal); q = 1ull << 32; break; }
             __builtin_amdgcn_s_sleep(2);
             q = __hip_atomic_load(tile_pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_onepass(const Frame* frames) {
     for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
         uint32_t spins = 0;
         while (ld_agent(flags + t) == 0u) {
-            if (++spins > kSpinLimit) { atomicOr(const_cast<uint32_t*>(&st->err), (uint32_t)kErrInternal); break; }
+            if (++spins > st->spin_limit) { atomicOr(const_cast<uint32_t*>(&st->err), (uint32_t)kErrInternal); break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }

@@ -156,6 +156,7 @@ struct FrameArgs {
     uint32_t vt_on, plan_cap;                 // vt_on: 1 tiled path, 2 streaming path on the host's box (no k_minmax)
     int32_t box_lo[3];
     uint32_t box_dim[3];
+    uint32_t spin_limit, pad1;                // bounded waits of the publish / look-back kernels: polls before a block gives up
 };
 
 // Device-resident frame state; k_emit copies it to pinned host memory at the end of a frame.
@@ -206,6 +207,8 @@ struct DevState {
     uint32_t vt;            // 1: this frame's voxel stage runs the tiled path (keys relative to the host's box until k_voxel_gather puts PCL's own grid here)
     uint32_t plan_cap;      // k_bin_plan: points per bucket (in the units of the histogram it is given); 0: kBucketCap
     uint32_t vt_nonfinite;  // non-finite points k_vt_sort / k_bin_hist dropped
+    uint32_t spin_limit;    // polls a block may make on a lower block's publish word before it gives the frame up (kErrInternal)
+    uint32_t pad0;
     uint32_t sbox;          // 1: the voxel keys of this frame are formed against the host's box (tiled path, or the streaming path without its
                             // bounds pass); k_voxel_gather / k_vt_scan put PCL's own grid here when the keys are done with
 };

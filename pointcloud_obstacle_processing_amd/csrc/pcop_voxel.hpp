@@ -72,7 +72,7 @@ __device__ __forceinline__ void frame_init(Frame& F) {   // one thread: the mail
         s.inv_leaf = a.inv_leaf; s.r2 = a.r2; s.inv_cell = a.inv_cell;
         s.min_cluster = a.min_cluster; s.max_cluster = a.max_cluster;
         s.src_x = a.src_x; s.src_y = a.src_y; s.src_z = a.src_z;
-        s.debug_skip_union = a.debug_skip_union;
+        s.debug_skip_union = a.debug_skip_union; s.spin_limit = a.spin_limit;
         s.nb_cap = a.nb_cap; s.gbits = a.gbits; s.tile = a.tile ? a.tile : kBinTile; s.cgrid_req = a.cell_grid;
         if (a.kind == kFrameClusterOnly) {   // no voxel stage: cluster the input cloud as it is
             s.c_from_input = 1; s.c_n = s.n_in; s.n_valid = s.n_in;
@@ -572,7 +572,7 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 // publishes its own count (plus one) as soon as it knows it and reads the counts of the lower tiles
 // after its sums are done; a lower tile never waits for a higher one and blocks are dispatched in
 // index order, so the lower tiles are always running or finished (the wait is bounded anyway).
-constexpr uint32_t kSpinLimit = 1u << 24;
+constexpr uint32_t kSpinLimit = 1u << 24;   // (the host's default for FrameArgs::spin_limit; the kernels next to the path keep it as a constant)
 constexpr uint32_t kReduceBucketsPerBlock = 2u;   // k_bucket_reduce: consecutive buckets per block
 
 // mark_cells: a chain frame on the dense cell grid (set up by k_voxel_setup): every centroid marks its grid cell as it is
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
     for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
         uint32_t v = ld_agent(tile_heads + t), spins = 0;
         while (v == 0u) {
-            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
+            if (++spins > st->spin_limit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
             __builtin_amdgcn_s_sleep(2);
             v = ld_agent(tile_heads + t);
         }
@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(kBlock) void k_occ_scan(Frame* frames) {
     for (uint32_t t = threadIdx.x; t < blockIdx.x; t += kBlock) {
         uint32_t v = ld_agent(otile + t), spins = 0;
         while (v == 0u) {
-            if (++spins > kSpinLimit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
+            if (++spins > st->spin_limit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
             __builtin_amdgcn_s_sleep(2);
             v = ld_agent(otile + t);
         }

@@ -131,3 +131,24 @@ def test_box_path_switched_off(capi, oracle, monkeypatch):
     for _ in range(3):
         assert run(c, clouds, refs).sbox == 0
     c.close()
+
+
+def test_bounded_wait_that_runs_out_costs_a_rerun_not_the_frame(capi, oracle, monkeypatch):
+    """PCOP_DEBUG_SPIN0=1: the first batch of the context gives up at the first poll of a lower block's publish word
+    (kErrInternal); the host queues it once more by eager launches and the results are the oracle's."""
+    monkeypatch.setenv("PCOP_DEBUG_SPIN0", "1")
+    p = synth.params_of("C3")
+    clouds = [synth.make_cloud("C3", n=120_000, seed=470 + i) for i in range(3)]
+    refs = [oracle.process_xyz(c, **p) for c in clouds]
+    c = capi.Context(120_000, max_frames=3)
+    c.set_params(publish_clouds=1, **p)
+    for _ in range(2):
+        run(c, clouds, refs)
+    assert c.debug_counter("internal_retries") == 1
+    single = capi.Context(120_000)            # and a single frame (sort path, one-pass CSR: more look-back kernels)
+    single.set_params(publish_clouds=1, **p)
+    same(single.process_xyz(clouds[0]), refs[0])
+    same(single.process_xyz(clouds[1]), refs[1])
+    assert single.debug_counter("internal_retries") == 1
+    single.close()
+    c.close()
