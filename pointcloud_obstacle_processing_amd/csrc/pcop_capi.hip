@@ -502,7 +502,7 @@ uint32_t fill_frame_args(pcop_ctx* c) {
         a.tile = 0u; a.heavy_ok = c->heavy_ok ? 1u : 0u;   // (tile: set below, once the launch bucket is known)
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         a.n_dev = f == 0 ? c->cur_n_dev : nullptr; a.sor_thr = 0.0;
-        a.spin_limit = (c->debug_spin0 && !c->internal_retry) ? 0u : kSpinLimit; a.pad1 = 0u;
+        a.spin_limit = (c->debug_spin0 && !c->internal_retry) ? 1u : kSpinLimit; a.pad1 = 0u;   // (PCOP_DEBUG_SPIN0: give up at the second poll)
         a.vt_on = c->vt_batch ? 1u : (c->sbox_batch ? 2u : 0u); a.plan_cap = c->vt_batch ? std::max(1u, c->vt_plan_cap / kVtSampleRows) : 0u;
         for (int k = 0; k < 3; ++k) { a.box_lo[k] = c->box_lo[k]; a.box_dim[k] = (uint32_t)(c->box_hi[k] - c->box_lo[k] + 1); }
         nmax = std::max(nmax, sl.n);

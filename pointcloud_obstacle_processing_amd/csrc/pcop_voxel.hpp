@@ -61,6 +61,8 @@ struct VoxelKey {
 // ------------------------------------------------------------------------------------------
 // frame init + layout conversion
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kSpinLimit = 1u << 24;   // polls of a bounded wait (the default of FrameArgs::spin_limit; the kernels next to the path keep it as a constant)
+
 __device__ __forceinline__ void frame_init(Frame& F) {   // one thread: the mailbox -> DevState
     DevState* st = &F.st;
     {
@@ -72,7 +74,7 @@ __device__ __forceinline__ void frame_init(Frame& F) {   // one thread: the mail
         s.inv_leaf = a.inv_leaf; s.r2 = a.r2; s.inv_cell = a.inv_cell;
         s.min_cluster = a.min_cluster; s.max_cluster = a.max_cluster;
         s.src_x = a.src_x; s.src_y = a.src_y; s.src_z = a.src_z;
-        s.debug_skip_union = a.debug_skip_union; s.spin_limit = a.spin_limit;
+        s.debug_skip_union = a.debug_skip_union; s.spin_limit = a.spin_limit ? a.spin_limit : kSpinLimit;   // (0: a caller that leaves the field alone gets the default)
         s.nb_cap = a.nb_cap; s.gbits = a.gbits; s.tile = a.tile ? a.tile : kBinTile; s.cgrid_req = a.cell_grid;
         if (a.kind == kFrameClusterOnly) {   // no voxel stage: cluster the input cloud as it is
             s.c_from_input = 1; s.c_n = s.n_in; s.n_valid = s.n_in;
@@ -572,7 +574,6 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 // publishes its own count (plus one) as soon as it knows it and reads the counts of the lower tiles
 // after its sums are done; a lower tile never waits for a higher one and blocks are dispatched in
 // index order, so the lower tiles are always running or finished (the wait is bounded anyway).
-constexpr uint32_t kSpinLimit = 1u << 24;   // (the host's default for FrameArgs::spin_limit; the kernels next to the path keep it as a constant)
 constexpr uint32_t kReduceBucketsPerBlock = 2u;   // k_bucket_reduce: consecutive buckets per block
 
 // mark_cells: a chain frame on the dense cell grid (set up by k_voxel_setup): every centroid marks its grid cell as it is

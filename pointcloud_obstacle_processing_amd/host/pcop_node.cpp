@@ -3,6 +3,12 @@
 // publish on "voxel_grid", "centroids" and "euc_clusters", plus the cluster indices.
 //
 //   pcop_node --params params.yaml --cloud in.pc2 --out outdir [--device 0] [--stage-api] [--occupancy] [--sor] [--node-order]
+//   pcop_node --params params.yaml --cloud in.pc2 --out outdir --gpus G [--same-gpu] [--frames F] [--batch B]
+//
+// --gpus G runs F frames (frame i = the cloud without its last i * (N / 4F) points, so that no two are alike) through the
+// C++ pool of host/pcop_pool.hpp: one feeder thread and one context per GPU, frame f on GPU f mod G, the parameters broadcast
+// from rank 0 (RCCL), results in frame order; writes pool_frame_<i>.txt (cluster indices) and pool_frame_<i>.vox (float32
+// xyz of the voxel cloud).  --same-gpu maps every worker to device 0 (rehearsal of G > 1 on a one-GPU box).
 //
 // --node-order (frame mode) runs the node's own order in one call that keeps every intermediate cloud on the GPU:
 // bounds filter + occupancy binning -> voxel grid -> statistical outlier removal -> RANSAC plane removal -> clusters
@@ -22,7 +28,10 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
+
 #include "obstacle_path.hpp"
+#include "pcop_pool.hpp"
 
 using namespace pcop_host;
 
@@ -38,7 +47,8 @@ static void write_indices(const std::string& path, const std::vector<PointIndice
 
 int main(int argc, char** argv) {
     std::string params_path, cloud_path, out_dir = ".";
-    int device = 0;
+    int device = 0, gpus = 0, frames = 8, batch = 4;
+    bool same_gpu = false;
     bool stage_api = false, occupancy = false, sor = false, node_order = false, planes = true;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -46,6 +56,10 @@ int main(int argc, char** argv) {
         else if (a == "--cloud" && i + 1 < argc) cloud_path = argv[++i];
         else if (a == "--out" && i + 1 < argc) out_dir = argv[++i];
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (a == "--gpus" && i + 1 < argc) gpus = std::atoi(argv[++i]);
+        else if (a == "--frames" && i + 1 < argc) frames = std::atoi(argv[++i]);
+        else if (a == "--batch" && i + 1 < argc) batch = std::atoi(argv[++i]);
+        else if (a == "--same-gpu") same_gpu = true;
         else if (a == "--stage-api") stage_api = true;
         else if (a == "--occupancy") occupancy = true;
         else if (a == "--sor") sor = true;
@@ -63,6 +77,50 @@ int main(int argc, char** argv) {
     PointCloud2 msg;
     if (!read_pointcloud2_file(cloud_path, &msg, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
     try {
+        if (gpus > 0) {   // the frame-sharded pool
+            PointCloudXYZ cloud;
+            if (!from_pointcloud2(msg, &cloud, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            const size_t n = cloud.size();
+            pcop_params pp{};
+            pp.leaf = prm.downsample_size; pp.tol = prm.euc_cluster_tolerance; pp.min_cluster = prm.euc_min_cluster_size;
+            pp.max_cluster = prm.euc_max_cluster_size; pp.publish_clouds = 1;
+            GpuPool pool(gpus, std::max<size_t>(n, 1024), batch, pp, same_gpu);
+            if (!pool.ok()) { std::fprintf(stderr, "pool: %s\n", pool.error().c_str()); return 1; }
+            for (int g = 0; g < pool.gpus(); ++g) {   // every worker must hold rank 0's struct, bit for bit
+                const pcop_params q = pool.params_of(g);
+                if (std::memcmp(&q, &pp, sizeof(pcop_params)) != 0) { std::fprintf(stderr, "pool: worker %d did not receive the parameters\n", g); return 1; }
+            }
+            frames = std::max(1, frames);
+            const size_t cut = n / (4u * (size_t)frames);
+            std::vector<float> soa;
+            const auto t0 = std::chrono::steady_clock::now();
+            size_t done = 0;
+            auto drain_one = [&]() -> bool {
+                PoolResult r;
+                if (!pool.next(&r)) return false;
+                if (r.status) { std::fprintf(stderr, "frame %llu on worker %d: %s (%s)\n", (unsigned long long)r.frame, r.gpu, pcop_status_string(r.status), r.error.c_str()); std::exit(1); }
+                if (r.gpu != (int)(r.frame % (uint64_t)pool.gpus())) { std::fprintf(stderr, "frame %llu ran on worker %d\n", (unsigned long long)r.frame, r.gpu); std::exit(1); }
+                std::vector<PointIndices> clusters(r.offsets.size() - 1);
+                for (size_t c = 0; c + 1 < r.offsets.size(); ++c) clusters[c].indices.assign(r.indices.begin() + r.offsets[c], r.indices.begin() + r.offsets[c + 1]);
+                write_indices(out_dir + "/pool_frame_" + std::to_string(r.frame) + ".txt", clusters);
+                std::ofstream f(out_dir + "/pool_frame_" + std::to_string(r.frame) + ".vox", std::ios::binary);
+                f.write(reinterpret_cast<const char*>(r.voxel_xyz.data()), (std::streamsize)(r.voxel_xyz.size() * sizeof(float)));
+                ++done;
+                return true;
+            };
+            for (int i = 0; i < frames; ++i) {
+                const size_t ni = n - (size_t)i * cut;
+                soa.resize(3 * ni);
+                for (size_t k = 0; k < ni; ++k) { soa[k] = cloud.points[k].x; soa[ni + k] = cloud.points[k].y; soa[2 * ni + k] = cloud.points[k].z; }
+                if (!pool.submit(soa.data(), ni)) { std::fprintf(stderr, "pool: submit failed (%s)\n", pool.error().c_str()); return 1; }
+                while ((size_t)i + 1 - done > (size_t)(2 * batch * pool.gpus())) drain_one();   // (results are taken as they come, so that the staging never fills)
+            }
+            while (drain_one()) {}
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("pool: %d worker(s)%s, batch %d, %zu frames in %.3f s (%.1f frames/s, host-memory input), parameters by %s\n", pool.gpus(),
+                        same_gpu ? " on one device" : "", batch, done, dt, done / dt, pool.broadcast_kind());
+            return 0;
+        }
         if (stage_api) {
             PointCloudXYZ::Ptr in(new PointCloudXYZ);
             if (!from_pointcloud2(msg, in.get(), &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }

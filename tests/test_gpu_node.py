@@ -160,3 +160,31 @@ def test_node_harness_node_order(oracle, tmp_path):
         assert np.array_equal(ci, idx[off[c]:off[c + 1]])
     ec = pc2io.read_pointcloud2(str(tmp_path / "euc_clusters.pc2"))
     assert ec["xyz"].tobytes() == s["xyz"][idx].tobytes()
+
+
+@pytest.mark.parametrize("gpus,same", [(1, False), (3, True)])
+def test_node_harness_pool(oracle, tmp_path, gpus, same):
+    """pcop_node --gpus G: the C++ pool of host/pcop_pool.hpp (a feeder thread and a context per GPU, frame f on GPU f mod G,
+    the 32-byte parameter struct broadcast from rank 0 - by RCCL when the workers sit on different devices or there is one;
+    --same-gpu rehearses G = 3 on this box's one device).  Every frame's voxel cloud and cluster indices are the oracle's."""
+    exe = os.path.join(HOST, "pcop_node")
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    pts = synth.make_cloud("C1")
+    cloud = str(tmp_path / "c1.pc2")
+    pc2io.write_pointcloud2(cloud, pts, point_step=16, offsets=(0, 4, 8), width=len(pts), height=1)
+    frames = 7
+    args = [exe, "--params", os.path.join(ROOT, "tests", "golden", "params_c1.yaml"), "--cloud", cloud, "--out", str(tmp_path),
+            "--gpus", str(gpus), "--frames", str(frames), "--batch", "2"] + (["--same-gpu"] if same else [])
+    out = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert ("ncclBroadcast" in out.stdout) == (not same), out.stdout
+    p = synth.params_of("C1")
+    cut = len(pts) // (4 * frames)
+    for i in range(frames):
+        ref = oracle.process_xyz(pts[: len(pts) - i * cut], **p)
+        vox = np.fromfile(str(tmp_path / ("pool_frame_%d.vox" % i)), dtype=np.float32).reshape(-1, 3)
+        assert vox.tobytes() == ref["voxel_xyz"].tobytes(), i
+        clusters = read_indices(str(tmp_path / ("pool_frame_%d.txt" % i)))
+        assert len(clusters) == len(ref["offsets"]) - 1
+        for c, idx in enumerate(clusters):
+            assert np.array_equal(idx, ref["indices"][ref["offsets"][c]:ref["offsets"][c + 1]])

@@ -21,6 +21,7 @@ menu = [
     ("C3", dict(leaf=0.05, tol=0.4), 1.0),             # crowded cells
     ("C2", dict(leaf=0.05, tol=0.2), 1.0),
     ("C2", dict(leaf=0.05, tol=0.01), 30.0),           # huge extent / tiny tolerance: cell grid too large -> hash table
+    ("C2", dict(leaf=0.2, tol=0.01), 30.0),            # the voxel grid streams, the cell grid is far too large: streaming path + hash table of cells
     ("C1", dict(leaf=0.0005, tol=0.05), 1.0),          # voxel grid beyond 2^26 cells -> sort path
     ("C3", dict(leaf=0.02, tol=0.1), 1.0),
     ("SHEET", dict(leaf=0.01, tol=0.05), 1.0),         # a dense sheet in a tall box: coarse bins above a bucket -> k_heavy_split
@@ -38,6 +39,7 @@ def sheet(n, seed):
 fails = 0
 t0 = time.time()
 paths = set()
+boxed = 0
 for it in range(steps):
     cfg, prm, stretch = menu[int(rng.integers(0, len(menu)))]
     n = int(rng.choice([5_000, 150_000, 600_000, 1_000_000] if big else [5_000, 40_000, 150_000, 400_000]))
@@ -58,6 +60,24 @@ for it in range(steps):
     if not ok:
         fails += 1
         print("MISMATCH step", it, cfg, n, stretch, p, flush=True)
+    if it % 3 == 2:   # the same cloud and a smaller one as ONE BATCH on the same context (the box of the streaming path, the batch-only kernels)
+        other = pts[: max(1, n // 3)][::-1].copy()
+        try:
+            ctx.submit_batch_host([pts, other])
+            rb = ctx.wait_batch()
+            st = ctx.debug_state()
+            paths.add((st.vpath, st.cpath))
+            boxed = boxed + (1 if st.sbox else 0)
+            okb = True
+            for fr, srcp in zip(rb, (pts, other)):
+                rr = ref if srcp is pts else O.process_xyz(srcp, **p)
+                okb = okb and fr["voxel_xyz"].tobytes() == rr["voxel_xyz"].tobytes() and np.array_equal(fr["offsets"], rr["offsets"]) and np.array_equal(fr["indices"], rr["indices"])
+        except capi.PcopError as e:
+            okb = False
+            print("ERROR (batch)", e, flush=True)
+        if not okb:
+            fails += 1
+            print("BATCH MISMATCH step", it, cfg, n, stretch, p, flush=True)
     if it % 4 == 1 and n <= 150_000 and stretch == 1.0 and os.environ.get("PCOP_CELL_PATH") != "hash":   # the node's chain on the same context, in between
         mk = int(rng.choice([0, 15])); use_plane = bool(rng.integers(0, 2)); thr = 0.04
         try:
@@ -77,6 +97,7 @@ for it in range(steps):
             print("NODE CHAIN MISMATCH step", it, cfg, n, p, mk, use_plane, flush=True)
     if it % 10 == 9:
         print("  ... %d steps, %d mismatches, %.0f s, (voxel, cell) paths seen %s" % (it + 1, fails, time.time() - t0, sorted(paths)), flush=True)
-print("steps %d, mismatches %d, paths %s, %.1f s" % (steps, fails, sorted(paths), time.time() - t0))
+print("steps %d, mismatches %d, (voxel, cell) paths %s, batches keyed on the context's box %d, replans %d, %.1f s" %
+      (steps, fails, sorted(paths), boxed, ctx.debug_counter("replans"), time.time() - t0))
 ctx.close()
 sys.exit(1 if fails else 0)
