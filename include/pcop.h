@@ -234,6 +234,14 @@ typedef struct pcop_plane_params {
 int pcop_segment_planes(pcop_ctx* ctx, const float* xyz, int layout, size_t n, const pcop_plane_params* p,
                         float* out_xyz, size_t* n_out, float* last_plane_xyz, size_t* n_last_plane,
                         float* coeffs, int32_t cap_planes, int32_t* n_planes, int32_t* found_all);
+/* The same with the reference's third cloud: before_last_xyz (may be NULL; same layout, room for n points) receives the cloud
+ * the last plane was cut from - "cloud_f" after the loop's planar_cloud.swap(cloud_f) (od.cpp:389-392), which is what the node
+ * publishes on `cloud_f` - and last_coeffs (may be NULL, 4 floats) the coefficients of the last plane whatever cap_planes is.
+ * *n_planes is the number of planes removed and may exceed cap_planes; only min(*n_planes, cap_planes) sets are in coeffs. */
+int pcop_segment_planes_clouds(pcop_ctx* ctx, const float* xyz, int layout, size_t n, const pcop_plane_params* p,
+                               float* out_xyz, size_t* n_out, float* last_plane_xyz, size_t* n_last_plane,
+                               float* before_last_xyz, size_t* n_before_last,
+                               float* coeffs, int32_t cap_planes, int32_t* n_planes, int32_t* found_all, float* last_coeffs);
 
 /* ---- the node's chain in one call, nothing but results leaving HBM (od.cpp:727-797) -----------------------------
  * build_initial_occupancy_grid_dataset (od.cpp:727-731) -> downsample_cloud (740-741) -> remove_statistical_outliers
@@ -263,6 +271,28 @@ typedef struct pcop_node_stats {
 int pcop_process_node(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int is_dense, int mem,
                       const pcop_occ_params* occ, int64_t* counts, int64_t* row_avg, int8_t* grid,
                       int mean_k, float stddev_mul, const pcop_plane_params* plane, pcop_result* out, pcop_node_stats* stats);
+
+/* The same call with the clouds the node publishes on its way (od.cpp:1004-1008), so that one fused call feeds every topic:
+ *   voxel_grid            the voxel cloud BEFORE the outlier removal          (downsample_cloud's publish, od.cpp:288-295)
+ *   statistical_outliers  what the outlier removal kept                       (od.cpp:331-338; only with mean_k != 0)
+ *   planar_cloud          what the plane removal left                         (od.cpp:401-408; only with plane != NULL)
+ *   indices_cloud         the points of the LAST plane removed                (od.cpp:410-417)
+ *   cloud_f               the cloud before the last plane was removed: the reference's loop ends every round with
+ *                         planar_cloud.swap(cloud_f) (od.cpp:389-392), so this - not what is left - is what
+ *                         filtered_cloud_publisher sends (od.cpp:419-426)
+ * Every buffer may be NULL; one that is not receives 16-byte records {x, y, z, 1.0f} (pcl::PointXYZ, what pcl::toROSMsg lays
+ * out) and needs room for n points; n_* report the point counts (a cloud the call did not produce: -1; with no plane removed,
+ * indices_cloud and cloud_f are -1: the reference leaves the caller's clouds as they were). */
+typedef struct pcop_node_clouds {
+    float* voxel_grid;           int32_t n_voxel_grid;
+    float* statistical_outliers; int32_t n_statistical_outliers;
+    float* planar_cloud;         int32_t n_planar_cloud;
+    float* indices_cloud;        int32_t n_indices_cloud;
+    float* cloud_f;              int32_t n_cloud_f;
+} pcop_node_clouds;
+int pcop_process_node_clouds(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int is_dense, int mem,
+                      const pcop_occ_params* occ, int64_t* counts, int64_t* row_avg, int8_t* grid,
+                      int mean_k, float stddev_mul, const pcop_plane_params* plane, pcop_result* out, pcop_node_stats* stats, pcop_node_clouds* clouds);
 
 /* Device-side allocation helpers so a host program without its own HIP code
  * (e.g. a ctypes caller) can keep clouds resident in HBM. */

@@ -20,7 +20,7 @@ EXPORTS = [
     "pcop_set_profiling", "pcop_get_stage_times", "pcop_stream", "pcop_voxel_downsample", "pcop_euclidean_clusters",
     "pcop_process_pointcloud2", "pcop_process_xyz", "pcop_submit_xyz", "pcop_wait", "pcop_cluster_summaries",
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
-    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_segment_planes", "pcop_debug_buffer", "pcop_debug_counter", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
+    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_process_node_clouds", "pcop_segment_planes", "pcop_segment_planes_clouds", "pcop_debug_buffer", "pcop_debug_counter", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
     "pcop_cluster_summaries_frame", "pcop_occupancy_grid_dims", "pcop_occupancy_filter", "pcop_process_filtered",
     "pcop_statistical_outlier_removal",
 ]

@@ -953,7 +953,8 @@ void plane_refit(const HostCloud& h, const float c_in[4], const pcop_plane_param
 struct PlaneScratch { float* p[3]; };
 int plane_removal_loop(pcop_ctx* c, Slot& sl, const float* in_x, const float* in_y, const float* in_z, uint32_t n, float* hbuf,
                        const pcop_plane_params& prm, PlaneScratch sa, PlaneScratch sb, const float** ox, const float** oy, const float** oz,
-                       uint32_t* n_left, std::vector<float>* coeffs, int32_t* found_all, std::vector<float>* last_plane = nullptr) {
+                       uint32_t* n_left, std::vector<float>* coeffs, int32_t* found_all, std::vector<float>* last_plane = nullptr,
+                       std::vector<float>* before_last = nullptr, const float** left_hx = nullptr) {
     const double thr = (double)prm.dist_thresh;   // setDistanceThreshold(double) from the node's float
     const uint32_t nr_points = n;
     const float *dx = in_x, *dy = in_y, *dz = in_z;
@@ -1045,10 +1046,12 @@ int plane_removal_loop(pcop_ctx* c, Slot& sl, const float* in_x, const float* in
                                                                       dst.p[0], dst.p[1], dst.p[2], d_tiles, d_counts, d_counts + 1);
         HIPCHK(c, hipGetLastError());
         uint32_t kept = 0;
-        if (last_plane) last_plane->clear();
+        std::vector<float> cur_plane;   // (a round that removes nothing leaves the last plane of the round before standing, as the reference's break does: od.cpp:379-383)
+        std::vector<float> snapshot;   // the cloud this round starts from: the reference's cloud_f after planar_cloud.swap(cloud_f) (od.cpp:389-392)
+        if (before_last) { snapshot.reserve(3 * (size_t)n); for (uint32_t i = 0; i < n; ++i) { snapshot.push_back(hx[i]); snapshot.push_back(hy[i]); snapshot.push_back(hz[i]); } }
         for (uint32_t i = 0; i < n; ++i) {
             if (host_plane_within(refined, hx[i], hy[i], hz[i], thr)) {
-                if (last_plane) { last_plane->push_back(hx[i]); last_plane->push_back(hy[i]); last_plane->push_back(hz[i]); }
+                if (last_plane) { cur_plane.push_back(hx[i]); cur_plane.push_back(hy[i]); cur_plane.push_back(hz[i]); }
                 continue;
             }
             hx[kept] = hx[i]; hy[kept] = hy[i]; hz[kept] = hz[i];   // (in place: kept <= i)
@@ -1058,13 +1061,16 @@ int plane_removal_loop(pcop_ctx* c, Slot& sl, const float* in_x, const float* in
         HIPCHK(c, hipMemcpyAsync(dev, d_counts, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (dev[1] || dev[0] != kept) { c->err = "internal: the plane split disagrees with the host's selection"; return PCOP_ERR_STATE; }
-        if (kept == n) { *found_all = 0; if (last_plane) last_plane->clear(); break; }   // inliers->indices.size() == 0
+        if (kept == n) { *found_all = 0; break; }   // inliers->indices.size() == 0
         if (coeffs) coeffs->insert(coeffs->end(), refined, refined + 4);
+        if (last_plane) last_plane->swap(cur_plane);
+        if (before_last) before_last->swap(snapshot);
         dx = dst.p[0]; dy = dst.p[1]; dz = dst.p[2];
         n = kept;
         ++round;
     }
     *ox = dx; *oy = dy; *oz = dz; *n_left = n;
+    if (left_hx) *left_hx = hx;   // (the host's copy of what is left: planes hx, hx + n0, hx + 2 n0 of the buffer handed in)
     return PCOP_OK;
 }
 
@@ -1719,6 +1725,12 @@ static double sor_threshold(const float* dist, size_t n, float stddev_mul, std::
 
 int pcop_segment_planes(pcop_ctx* c, const float* xyz, int layout, size_t n, const pcop_plane_params* p, float* out_xyz, size_t* n_out,
                         float* last_plane_xyz, size_t* n_last_plane, float* coeffs, int32_t cap_planes, int32_t* n_planes, int32_t* found_all) {
+    return pcop_segment_planes_clouds(c, xyz, layout, n, p, out_xyz, n_out, last_plane_xyz, n_last_plane, nullptr, nullptr, coeffs, cap_planes, n_planes, found_all, nullptr);
+}
+
+int pcop_segment_planes_clouds(pcop_ctx* c, const float* xyz, int layout, size_t n, const pcop_plane_params* p, float* out_xyz, size_t* n_out,
+                               float* last_plane_xyz, size_t* n_last_plane, float* before_last_xyz, size_t* n_before_last,
+                               float* coeffs, int32_t cap_planes, int32_t* n_planes, int32_t* found_all, float* last_coeffs) {
     if (!c || !p || !n_out || !n_planes || !found_all || (!out_xyz && n) || (!xyz && n) || cap_planes < 0) return PCOP_ERR_ARG;
     int rc = busy(c);
     if (rc) return rc;
@@ -1732,9 +1744,9 @@ int pcop_segment_planes(pcop_ctx* c, const float* xyz, int layout, size_t n, con
     const PlaneScratch sa{{rb, rb + c->cap, rb + 2 * c->cap}}, sb{{ra, ra + c->cap, ra + 2 * c->cap}};   // rec_a / rec_b: 16 bytes per point each
     const float *ox, *oy, *oz;
     uint32_t left = 0;
-    std::vector<float> cf, lastp;
+    std::vector<float> cf, lastp, beforep;
     if ((rc = plane_removal_loop(c, sl, sl.src_x, sl.src_y, sl.src_z, (uint32_t)n, sl.h_vox, *p, sa, sb, &ox, &oy, &oz, &left, &cf, found_all,
-                                 last_plane_xyz ? &lastp : nullptr))) return rc;
+                                 last_plane_xyz ? &lastp : nullptr, before_last_xyz ? &beforep : nullptr))) return rc;
     // what is left is on the host already (the loop keeps its copy in step): three planes in h_vox
     const float *hx = sl.h_vox, *hy = hx + n, *hz = hy + n;
     const size_t fl = layout == PCOP_LAYOUT_AOS16 ? 4 : 3;
@@ -1753,15 +1765,33 @@ int pcop_segment_planes(pcop_ctx* c, const float* xyz, int layout, size_t n, con
     } else if (n_last_plane) {
         *n_last_plane = 0;
     }
+    if (before_last_xyz) {
+        const size_t nbl = beforep.size() / 3;
+        for (size_t i = 0; i < nbl; ++i) {
+            if (layout == PCOP_LAYOUT_SOA) { before_last_xyz[i] = beforep[3 * i]; before_last_xyz[n + i] = beforep[3 * i + 1]; before_last_xyz[2 * n + i] = beforep[3 * i + 2]; }
+            else { before_last_xyz[fl * i] = beforep[3 * i]; before_last_xyz[fl * i + 1] = beforep[3 * i + 1]; before_last_xyz[fl * i + 2] = beforep[3 * i + 2]; if (fl == 4) before_last_xyz[fl * i + 3] = 1.0f; }
+        }
+        if (n_before_last) *n_before_last = nbl;
+    } else if (n_before_last) {
+        *n_before_last = 0;
+    }
     *n_planes = (int32_t)(cf.size() / 4);
     if (coeffs) std::memcpy(coeffs, cf.data(), std::min<size_t>(cf.size(), (size_t)cap_planes * 4) * sizeof(float));
+    if (last_coeffs && cf.size() >= 4) std::memcpy(last_coeffs, cf.data() + cf.size() - 4, 4 * sizeof(float));
     return PCOP_OK;
 }
 
 int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem, const pcop_occ_params* occ,
                       int64_t* counts, int64_t* row_avg, int8_t* grid, int mean_k, float stddev_mul, const pcop_plane_params* plane,
                       pcop_result* out, pcop_node_stats* stats) {
+    return pcop_process_node_clouds(c, xyz, layout, n, is_dense, mem, occ, counts, row_avg, grid, mean_k, stddev_mul, plane, out, stats, nullptr);
+}
+
+int pcop_process_node_clouds(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem, const pcop_occ_params* occ,
+                             int64_t* counts, int64_t* row_avg, int8_t* grid, int mean_k, float stddev_mul, const pcop_plane_params* plane,
+                             pcop_result* out, pcop_node_stats* stats, pcop_node_clouds* clouds) {
     if (!c || !out) return PCOP_ERR_ARG;
+    if (clouds) clouds->n_voxel_grid = clouds->n_statistical_outliers = clouds->n_planar_cloud = clouds->n_indices_cloud = clouds->n_cloud_f = -1;
     int rc = busy(c);
     if (rc) return rc;
     if ((rc = check_params(c, true, true))) return rc;
@@ -1802,7 +1832,13 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
     double thr = 0.0;
     uint32_t n_vox = 0, n_inl = 0, n_clu = 0;
     int32_t found_all = 1;
-    std::vector<float> plane_coeffs;
+    std::vector<float> plane_coeffs, last_plane, before_last;
+    const float* left_host = nullptr;
+    uint32_t left_n0 = 0, left_n = 0;
+    // a cloud between two steps -> the caller's 16-byte records: written by the GPU into pinned memory, copied after the next sync
+    float4* pin16 = reinterpret_cast<float4*>(sl.h_clu);
+    auto queue_cloud16 = [&](Frame* fr) { k_cloud16<<<stride_grid((uint32_t)std::max<size_t>(n, 1)), kBlock, 0, c->stream>>>(fr, pin16); };
+    auto take_cloud16 = [&](float* dst, int32_t* cnt, uint32_t count) { if (count) std::memcpy(dst, pin16, (size_t)count * 16); *cnt = (int32_t)count; };
     auto mid_state = [&](Frame* fr) -> int {   // DevState to the host in the middle of the call
         k_state_out<<<dim3(1, 1), 64, 0, c->stream>>>(fr);
         HIPCHK(c, hipGetLastError());
@@ -1828,6 +1864,8 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
         mark(c, "start");
         enqueue_launches(c, kFrameChain, nb, 1, kPartVoxel | kPartOwnGridSetup);
         const dim3 tg(stride_grid(nb), 1), sg(std::max(1u, div_up(nb, kScanTile)), 1);
+        const bool want_vg = clouds && clouds->voxel_grid, want_so = clouds && clouds->statistical_outliers && sor;
+        if (want_vg) queue_cloud16(fr);   // the voxel cloud as downsample_cloud publishes it (od.cpp:288-295): before any filter
         if (sor) {   // outlier removal, first half: bounds of the voxel cloud, a cell grid sized for it, mean distance to the mean_k nearest neighbours
             k_minmax<<<dim3(kReduceBlocks, 1), kBlock, 0, s>>>(fr, 1u);
             k_sor_setup<<<dim3(1, 1), kBlock, 0, s>>>(fr, kReduceBlocks, (uint32_t)mean_k);
@@ -1854,14 +1892,19 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
         n_vox = hs->m;
         uint32_t npts = hs->c_n;   // the voxel cloud (or the input after a pass-through)
         n_inl = npts;
+        if (want_vg) take_cloud16(clouds->voxel_grid, &clouds->n_voxel_grid, npts);
         if (sor) {   // second half: the points within the threshold
             thr = npts ? sor_threshold(sl.h_xyzr, npts, stddev_mul, c->sor_sq) : 0.0;
             sl.h_args->sor_thr = thr;
             k_sor_select<<<sg, kBlock, 0, s>>>(fr);
             mark(c, "k_sor_select");
-            if (plane) {
+            if (want_so) queue_cloud16(fr);   // what remove_statistical_outliers publishes (od.cpp:331-338)
+            if (plane || want_so) {
                 if ((rc = mid_state(fr))) break;
+                c->in_flight = false;
+                if (hs->err) { c->in_flight = true; rc = finish_batch(c, nullptr, 0); if (rc == 1) continue; if (rc == PCOP_OK) { c->err = "internal: error bits without a status"; rc = PCOP_ERR_STATE; } break; }
                 npts = hs->c_n;
+                if (want_so) take_cloud16(clouds->statistical_outliers, &clouds->n_statistical_outliers, npts);
             }
             n_inl = plane ? npts : 0u;   // (without plane removal: read from the final state below)
         }
@@ -1881,8 +1924,15 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
             uint32_t left = 0;
             plane_coeffs.clear();
             c->in_flight = false;
-            rc = plane_removal_loop(c, sl, px, py, pz, npts, sl.h_vox, *plane, first, second, &ox, &oy, &oz, &left, &plane_coeffs, &found_all);
+            last_plane.clear(); before_last.clear();
+            rc = plane_removal_loop(c, sl, px, py, pz, npts, sl.h_vox, *plane, first, second, &ox, &oy, &oz, &left, &plane_coeffs, &found_all,
+                                    clouds ? &last_plane : nullptr, clouds ? &before_last : nullptr, &left_host);
             if (rc) break;
+            left_n0 = npts; left_n = left;
+            if (clouds && clouds->planar_cloud) {   // (before the final stage overwrites the pinned buffer the host copy lives in)
+                for (uint32_t i = 0; i < left; ++i) { float* q = clouds->planar_cloud + 4 * (size_t)i; q[0] = left_host[i]; q[1] = left_host[left_n0 + i]; q[2] = left_host[2 * (size_t)left_n0 + i]; q[3] = 1.0f; }
+                clouds->n_planar_cloud = (int32_t)left;
+            }
             if (ox == ra && left) {   // the cell stage sorts its records into rec_a: what is left moves to rec_b's planes (free by now)
                 HIPCHK(c, hipMemcpyAsync(rb, ox, (size_t)left * 4, hipMemcpyDeviceToDevice, s));
                 HIPCHK(c, hipMemcpyAsync(rb + c->cap, oy, (size_t)left * 4, hipMemcpyDeviceToDevice, s));
@@ -1906,6 +1956,16 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
         if (rc == PCOP_ERR_STATE && (sl.h_state->err & kErrSorFew)) { c->err = "fewer voxels than mean_k + 1: the reference reads past its k-NN result"; return PCOP_ERR_PARAM; }
         return rc;
     }
+    if (clouds && plane && !plane_coeffs.empty()) {   // at least one plane went: its points, and the cloud it was cut from
+        auto put = [](const std::vector<float>& v, float* dst, int32_t* cnt) {
+            const size_t m = v.size() / 3;
+            if (dst) for (size_t i = 0; i < m; ++i) { dst[4 * i] = v[3 * i]; dst[4 * i + 1] = v[3 * i + 1]; dst[4 * i + 2] = v[3 * i + 2]; dst[4 * i + 3] = 1.0f; }
+            if (dst) *cnt = (int32_t)m;
+        };
+        put(last_plane, clouds->indices_cloud, &clouds->n_indices_cloud);
+        put(before_last, clouds->cloud_f, &clouds->n_cloud_f);
+    }
+    (void)left_n;
     const DevState* hs = sl.h_state;
     // the cloud the cluster indices refer to: what the last filter step kept (also of a pass-through frame's input), else the voxel cloud
     if (c->emit_cloud) out->num_voxels = (int32_t)((sor || plane) ? hs->c_n : (hs->c_from_input && !hs->passthrough ? hs->c_n : hs->m));

@@ -94,6 +94,21 @@ __global__ __launch_bounds__(kBlock) void k_plane_split(const float* __restrict_
 }
 
 // The cloud the cluster stage will see, set from outside a frame's own kernels (after the plane removal of the node chain).
+// The cloud the cell stage would see right now (the voxel centroids, or the planes a filter step left in DevState) as 16-byte
+// {x, y, z, 1.0f} records (pcl::PointXYZ, the layout of pcl::toROSMsg) into pinned host memory: the topics between the steps of
+// the node's chain (od.cpp:288-295, 331-338).
+__global__ __launch_bounds__(kBlock) void k_cloud16(const Frame* frames, float4* __restrict__ out) {
+    const Frame& F = frames[0];
+    const DevState* st = &F.st;
+    if (st->err) return;
+    const bool sel = st->c_from_input != 0;
+    const float* __restrict__ x = sel ? st->src_x.get() : F.cen_x.get();
+    const float* __restrict__ y = sel ? st->src_y.get() : F.cen_y.get();
+    const float* __restrict__ z = sel ? st->src_z.get() : F.cen_z.get();
+    const uint32_t n = st->c_n;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = make_float4(x[i], y[i], z[i], 1.0f);
+}
+
 __global__ void k_set_cloud(Frame* frames, const float* x, const float* y, const float* z, uint32_t n) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     DevState* st = &frames[0].st;

@@ -149,13 +149,13 @@ bool segment_plane_and_extract_indices(PointCloudXYZ::Ptr& planar_cloud, PointCl
     pcop_plane_params p{};
     p.dist_thresh = dist_thresh; p.axis[0] = axis[0]; p.axis[1] = axis[1]; p.axis[2] = axis[2];
     p.eps_angle = (double)eps_angle;                     // seg.setEpsAngle(eps_angle): the int goes in as radians (od.cpp:371)
-    std::vector<PointXYZ> rest(n ? n : 1), last(n ? n : 1);
-    std::vector<float> coeffs(4 * 64);
-    size_t n_rest = 0, n_last = 0;
+    std::vector<PointXYZ> rest(n ? n : 1), last(n ? n : 1), before(n ? n : 1);
+    float last_coeffs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    size_t n_rest = 0, n_last = 0, n_before = 0;
     int32_t n_planes = 0, found_all = 0;
-    check(c, pcop_segment_planes(c, n ? &planar_cloud->points[0].x : nullptr, PCOP_LAYOUT_AOS16, n, &p, &rest[0].x, &n_rest, &last[0].x, &n_last,
-                                 coeffs.data(), 64, &n_planes, &found_all), "pcop_segment_planes");
-    rest.resize(n_rest); last.resize(n_last);
+    check(c, pcop_segment_planes_clouds(c, n ? &planar_cloud->points[0].x : nullptr, PCOP_LAYOUT_AOS16, n, &p, &rest[0].x, &n_rest, &last[0].x, &n_last,
+                                        &before[0].x, &n_before, nullptr, 0, &n_planes, &found_all, last_coeffs), "pcop_segment_planes_clouds");
+    rest.resize(n_rest); last.resize(n_last); before.resize(n_before);
     const Header hdr = planar_cloud->header;
     auto fill = [&](PointCloudXYZ::Ptr& dst, const std::vector<PointXYZ>& pts) {
         if (!dst) dst.reset(new PointCloudXYZ);
@@ -164,8 +164,8 @@ bool segment_plane_and_extract_indices(PointCloudXYZ::Ptr& planar_cloud, PointCl
     if (n_planes) {                                      // (with no plane found the reference leaves all three clouds as they were)
         fill(planar_cloud, rest);
         fill(indices_cloud, last);
-        fill(cloud_f, rest);
-        if (coefficients) coefficients->values.assign(coeffs.begin() + 4 * (std::min(n_planes, 64) - 1), coeffs.begin() + 4 * std::min(n_planes, 64));
+        fill(cloud_f, before);                           // extract.filter(*cloud_f); planar_cloud.swap(cloud_f): the cloud the last plane was cut from (od.cpp:389-392)
+        if (coefficients) coefficients->values.assign(last_coeffs, last_coeffs + 4);
     }
     if (inliers) inliers->indices.clear();
     if (outliers) outliers->indices.clear();
@@ -207,6 +207,7 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
     rc = pcop_set_cloud_layout(ctx_, PCOP_LAYOUT_AOS16);
     if (rc) { error_ = pcop_last_error(ctx_); return rc; }
     pcop_result r{};
+    node_voxel_grid_sent_ = false;
     if (node_order) {
         PointCloudXYZ in;                                   // pcl::fromPCLPointCloud2 (od.cpp:688-689), on the host as there
         if (!from_pointcloud2(cloud_msg, &in, &error_)) return PCOP_ERR_ARG;
@@ -220,10 +221,35 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
         const size_t cells = (size_t)std::max(occ.grid_width, 0) * (size_t)std::max(occ.grid_height, 0);
         occupancy_grid.assign(cells, 0); occupancy_counts.assign(cells, 0); occupancy_row_averages.assign((size_t)std::max(occ.grid_height, 0), 0);
         static_assert(sizeof(long long) == sizeof(int64_t), "counts are 64-bit");
-        rc = pcop_process_node(ctx_, in.points.empty() ? nullptr : &in.points[0].x, PCOP_LAYOUT_AOS16, in.points.size(), 1, PCOP_MEM_HOST,
-                               &occ, reinterpret_cast<int64_t*>(occupancy_counts.data()), reinterpret_cast<int64_t*>(occupancy_row_averages.data()),
-                               reinterpret_cast<int8_t*>(occupancy_grid.data()), params.statistical_outlier_meanK,
-                               params.statistical_outlier_stdDevThres, remove_planes ? &plane : nullptr, &r, &stats);
+        // one fused call feeds every topic of the node's order: the clouds between the steps come back as pcl::PointXYZ records
+        const size_t room = std::max<size_t>(in.points.size(), 1);
+        std::vector<PointXYZ> c_vg(room), c_so(room), c_pl(room), c_ix(room), c_cf(room);
+        pcop_node_clouds clouds{};
+        clouds.voxel_grid = &c_vg[0].x; clouds.statistical_outliers = &c_so[0].x; clouds.planar_cloud = &c_pl[0].x;
+        clouds.indices_cloud = &c_ix[0].x; clouds.cloud_f = &c_cf[0].x;
+        rc = pcop_process_node_clouds(ctx_, in.points.empty() ? nullptr : &in.points[0].x, PCOP_LAYOUT_AOS16, in.points.size(), 1, PCOP_MEM_HOST,
+                                      &occ, reinterpret_cast<int64_t*>(occupancy_counts.data()), reinterpret_cast<int64_t*>(occupancy_row_averages.data()),
+                                      reinterpret_cast<int8_t*>(occupancy_grid.data()), params.statistical_outlier_meanK,
+                                      params.statistical_outlier_stdDevThres, remove_planes ? &plane : nullptr, &r, &stats, &clouds);
+        if (rc == PCOP_OK && params.publish_point_clouds) {
+            auto send = [&](Publisher<PointCloud2>& pub, std::vector<PointXYZ>& pts, int32_t cnt) {   // pcl::toROSMsg + frame_id "world" (od.cpp:288-295, 331-338, 401-426)
+                if (cnt < 0) return;
+                PointCloudXYZ cl;
+                pts.resize((size_t)cnt);
+                cl.points.swap(pts);
+                cl.width = (uint32_t)cnt; cl.height = 1; cl.is_dense = true;
+                PointCloud2 m;
+                to_pointcloud2(cl, &m);
+                m.header.frame_id = "world";
+                pub.publish(m);
+            };
+            if (clouds.n_voxel_grid >= 0) node_voxel_grid_sent_ = true;
+            send(downsample_publisher, c_vg, clouds.n_voxel_grid);
+            send(statistical_outlier_publisher, c_so, clouds.n_statistical_outliers);
+            send(planar_cloud_publisher, c_pl, clouds.n_planar_cloud);
+            send(indices_cloud_publisher, c_ix, clouds.n_indices_cloud);
+            send(filtered_cloud_publisher, c_cf, clouds.n_cloud_f);
+        }
     } else {
         rc = pcop_process_pointcloud2(ctx_, cloud_msg.data.data(), cloud_msg.width, cloud_msg.height, cloud_msg.point_step,
                                       cloud_msg.row_step, ox, oy, oz, cloud_msg.is_bigendian ? 1 : 0, cloud_msg.is_dense ? 1 : 0, &r);
@@ -236,7 +262,7 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
     voxel_cloud.points.resize((size_t)r.num_voxels);
     if (r.num_voxels) std::memcpy(static_cast<void*>(&voxel_cloud.points[0]), r.voxel_xyz, (size_t)r.num_voxels * sizeof(PointXYZ));
     voxel_cloud.width = (uint32_t)r.num_voxels; voxel_cloud.height = 1; voxel_cloud.is_dense = true;
-    if (params.publish_point_clouds) {               // od.cpp:288-295
+    if (params.publish_point_clouds && !node_voxel_grid_sent_) {   // od.cpp:288-295 (node order: sent above, the cloud before the filters)
         PointCloud2 msg;
         to_pointcloud2(voxel_cloud, &msg);
         msg.header.frame_id = "world";

@@ -88,7 +88,11 @@ public:
     std::vector<signed char> occupancy_grid;            // occupancy_grid_data (od.cpp:725)
     std::vector<long long> occupancy_counts, occupancy_row_averages;
     pcop_node_stats stats{};
-    Publisher<PointCloud2> downsample_publisher;        // "voxel_grid",   queue 1   (od.cpp:1004)
+    Publisher<PointCloud2> downsample_publisher;        // "voxel_grid",   queue 1   (od.cpp:1004): in node order the cloud BEFORE the outlier removal, as downsample_cloud publishes it
+    Publisher<PointCloud2> statistical_outlier_publisher;   // "statistical_outliers", queue 1    (od.cpp:1005) - node order
+    Publisher<PointCloud2> indices_cloud_publisher;          // "indices_cloud",        queue 1000 (od.cpp:1006) - node order, once a plane was removed
+    Publisher<PointCloud2> planar_cloud_publisher;           // "planar_cloud",         queue 1000 (od.cpp:1007) - node order
+    Publisher<PointCloud2> filtered_cloud_publisher;         // "cloud_f",              queue 1000 (od.cpp:1008) - node order, once a plane was removed
     Publisher<PointIndicesArray> centroid_publisher;    // "centroids",    queue 1   (od.cpp:1009)
     Publisher<PointCloud2> euc_cluster_publisher;       // "euc_clusters", queue 5   (od.cpp:1010)
     std::vector<PointIndices> euc_cluster_indices;      // od.cpp:793
@@ -98,6 +102,7 @@ public:
 private:
     pcop_ctx* ctx_ = nullptr;
     std::string error_;
+    bool node_voxel_grid_sent_ = false;
 };
 
 }  // namespace pcop_host

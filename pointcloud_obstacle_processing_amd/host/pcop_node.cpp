@@ -177,6 +177,18 @@ int main(int argc, char** argv) {
         if (node.downsample_publisher.published &&
             !write_pointcloud2_file(out_dir + "/voxel_grid.pc2", node.downsample_publisher.last, &err)) throw std::runtime_error(err);
         if (!write_pointcloud2_file(out_dir + "/euc_clusters.pc2", node.euc_cluster_publisher.last, &err)) throw std::runtime_error(err);
+        if (node_order) {   // the topics between the steps (od.cpp:1005-1008), from the same fused call; clustered.pc2 = the cloud the cluster indices refer to
+            auto put = [&](const char* name, const Publisher<PointCloud2>& pub) {
+                if (pub.published && !write_pointcloud2_file(out_dir + "/" + name + ".pc2", pub.last, &err)) throw std::runtime_error(err);
+            };
+            put("statistical_outliers", node.statistical_outlier_publisher);
+            put("planar_cloud", node.planar_cloud_publisher);
+            put("indices_cloud", node.indices_cloud_publisher);
+            put("cloud_f", node.filtered_cloud_publisher);
+            PointCloud2 m;
+            to_pointcloud2(node.voxel_cloud, &m);
+            if (!write_pointcloud2_file(out_dir + "/clustered.pc2", m, &err)) throw std::runtime_error(err);
+        }
         {
             std::ofstream f(out_dir + "/centroids.txt");   // PointIndicesArray: one "x y z r" line per PointWithRad
             f.precision(9);

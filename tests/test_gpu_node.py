@@ -123,8 +123,9 @@ def test_node_harness_sor_between_voxel_grid_and_clusters(oracle, tmp_path):
 
 
 def test_node_harness_node_order(oracle, tmp_path):
-    """--node-order: the node's own order (od.cpp:727-797 without the plane removal) through one pcop_process_node call:
-    bounds filter + occupancy binning -> voxel grid -> statistical outlier removal -> clusters, parameters from the yaml."""
+    """--node-order: the node's own order (od.cpp:727-797) through one pcop_process_node_clouds call: bounds filter + occupancy
+    binning -> voxel grid -> statistical outlier removal -> plane removal -> clusters, parameters from the yaml; the clouds of
+    the topics voxel_grid, statistical_outliers, planar_cloud, indices_cloud and cloud_f come out of the same call."""
     exe = os.path.join(HOST, "pcop_node")
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     pts = synth.make_cloud("C3", n=90_000, seed=31)
@@ -152,7 +153,29 @@ def test_node_harness_node_order(oracle, tmp_path):
     s = dict(xyz=pl["xyz"], n_inl=len(s["xyz"]))
     off, idx = oracle.euclidean_clusters(s["xyz"], 0.1, 5, 20000)
     assert "inside the box %d, voxels %d, inliers %d, planes %d, clustered %d" % (kept["n_out"], len(vox), s["n_inl"], pl["n_planes"], len(pl["xyz"])) in out.stdout
-    got = pc2io.read_pointcloud2(str(tmp_path / "voxel_grid.pc2"))
+    # the five clouds the node publishes on its way (od.cpp:1004-1008), all from the one fused call
+    def cloud_of(name):
+        m = pc2io.read_pointcloud2(str(tmp_path / (name + ".pc2")))
+        assert m["frame_id"] == "world" and m["point_step"] == 16 and m["height"] == 1
+        return m["xyz"]
+    sor_kept = oracle.sor(vox, 12, 1.5)["xyz"]
+    assert cloud_of("voxel_grid").tobytes() == vox.tobytes()                    # before the outlier removal (od.cpp:288-295)
+    assert cloud_of("statistical_outliers").tobytes() == sor_kept.tobytes()     # od.cpp:331-338
+    assert cloud_of("planar_cloud").tobytes() == pl["xyz"].tobytes()            # what the planes left (od.cpp:401-408)
+    assert cloud_of("indices_cloud").tobytes() == pl["last_plane"].tobytes()    # the last plane removed (od.cpp:410-417)
+    # cloud_f: the cloud the last plane was cut from = what is left and the last plane, in their original order
+    # (planar_cloud.swap(cloud_f), od.cpp:389-392): rebuilt here by walking the outlier removal's output
+    rest, last = pl["xyz"], pl["last_plane"]
+    i = j = 0
+    want = []
+    for q in sor_kept:
+        if i < len(rest) and q.tobytes() == rest[i].tobytes():
+            want.append(q); i += 1
+        elif j < len(last) and q.tobytes() == last[j].tobytes():
+            want.append(q); j += 1
+    assert i == len(rest) and j == len(last)
+    assert cloud_of("cloud_f").tobytes() == np.array(want, dtype=np.float32).reshape(-1, 3).tobytes()
+    got = pc2io.read_pointcloud2(str(tmp_path / "clustered.pc2"))              # the cloud the cluster indices refer to
     assert got["xyz"].tobytes() == s["xyz"].tobytes()
     clusters = read_indices(str(tmp_path / "cluster_indices.txt"))
     assert len(clusters) == len(off) - 1 and len(clusters) > 0
