@@ -126,7 +126,7 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr& cloud_msg) {
 int main(int argc, char** argv) {
     ros::init(argc, argv, "pointcloud_obstacle_detection");          // od.cpp:933
     ros::NodeHandle nh("~");
-    ros::NodeHandle nh_pub("pointcloud_obstacle_processing");        // (the reference's namespace-level handle for the field limits, od.cpp:934)
+    ros::NodeHandle nh_pub;                                          // the reference's namespace-level handle for the field limits (od.cpp:935)
     nh.param("publish_point_clouds", publish_point_clouds, true);    // od.cpp:945
     nh.param("downsample_size", downsample_leaf_size, (float)0.015); // od.cpp:964
     nh.param("euc_cluster_tolerance", euc_cluster_tolerance, (float)0.4);
