@@ -126,6 +126,9 @@ def load_library():
     L.pcop_process_node.restype = C.c_int
     L.pcop_process_node.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.POINTER(Result), C.POINTER(NodeStats)]
+    L.pcop_segment_planes_clouds.restype = C.c_int
+    L.pcop_segment_planes_clouds.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(PlaneParams), C.c_void_p, C.POINTER(C.c_size_t),
+                                             C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_int32, ip, ip, C.c_void_p]
     L.pcop_segment_planes.restype = C.c_int
     L.pcop_segment_planes.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(PlaneParams), C.c_void_p, C.POINTER(C.c_size_t),
                                       C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_int32, ip, ip]
@@ -345,11 +348,14 @@ class Context:
         out = np.zeros_like(flat) if n else np.zeros(3, dtype=np.float32)
         last = np.zeros_like(out)
         coeffs = np.zeros((cap_planes, 4), dtype=np.float32)
-        n_out, n_last, n_planes, found = C.c_size_t(0), C.c_size_t(0), C.c_int32(0), C.c_int32(0)
-        self._chk(self.lib.pcop_segment_planes(self.h, flat.ctypes.data, layout, n, C.byref(plane), out.ctypes.data, C.byref(n_out),
-                                               last.ctypes.data, C.byref(n_last), coeffs.ctypes.data, cap_planes, C.byref(n_planes),
-                                               C.byref(found)))
+        before = np.zeros_like(out)
+        last_c = np.zeros(4, dtype=np.float32)
+        n_out, n_last, n_before, n_planes, found = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.pcop_segment_planes_clouds(self.h, flat.ctypes.data, layout, n, C.byref(plane), out.ctypes.data, C.byref(n_out),
+                                                      last.ctypes.data, C.byref(n_last), before.ctypes.data, C.byref(n_before),
+                                                      coeffs.ctypes.data, cap_planes, C.byref(n_planes), C.byref(found), last_c.ctypes.data))
         return dict(xyz=unpack_points(out, layout, n_out.value, n), last_plane=unpack_points(last, layout, n_last.value, n),
+                    cloud_f=unpack_points(before, layout, n_before.value, n), last_coeffs=last_c,
                     coeffs=coeffs[:min(n_planes.value, cap_planes)].copy(), n_planes=n_planes.value, found_all=bool(found.value))
 
     def process_node(self, xyz, occ=None, mean_k=0, stddev_mul=1.0, plane=None, is_dense=True, layout=LAYOUT_AOS12, dev_ptr=None,

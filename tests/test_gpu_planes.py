@@ -77,3 +77,26 @@ def test_edge_cases(ctx, capi, oracle):
     ctx.set_params(publish_clouds=1, **p)
     pts = synth.make_cloud("C1")
     assert ctx.process_xyz(pts)["voxel_xyz"].tobytes() == oracle.process_xyz(pts, **p)["voxel_xyz"].tobytes()
+
+
+def test_product_against_the_numpy_formulation(capi):
+    """The product against tests/np_planes.py directly (not through the C++ oracle its host half shares its text with): what is left,
+    the last plane, the cloud the last plane was cut from (cloud_f after planar_cloud.swap(cloud_f), od.cpp:389-392) and the
+    coefficients, bit for bit; cap_planes below the planes removed still hands back the LAST model."""
+    from tests import np_planes as NP
+    rng = np.random.default_rng(12)
+    def sheet(n, z, tilt):
+        xy = rng.uniform(-2, 2, (n, 2))
+        return np.stack([xy[:, 0], xy[:, 1], z + tilt * xy[:, 0] + rng.normal(0, 0.003, n)], axis=1).astype(np.float32)
+    pts = np.concatenate([sheet(1500, 0.0, 0.02), sheet(900, 0.8, -0.05), sheet(500, 1.6, 0.0), rng.uniform(-2, 2, (300, 3)).astype(np.float32)])
+    pts = pts[rng.permutation(len(pts))]
+    c = capi.Context(len(pts))
+    got = c.segment_planes(pts, capi.plane_params(0.015), cap_planes=1)
+    want = NP.segment_planes(pts, 0.015)
+    assert want["n_planes"] >= 2 and got["n_planes"] == want["n_planes"] and got["found_all"] == want["found_all"]
+    assert got["xyz"].tobytes() == want["xyz"].tobytes()
+    assert got["last_plane"].tobytes() == want["last_plane"].tobytes()
+    assert got["cloud_f"].tobytes() == want["cloud_f"].tobytes()
+    assert got["last_coeffs"].tobytes() == want["coeffs"][-1].tobytes()
+    assert got["coeffs"].tobytes() == want["coeffs"][:1].tobytes()
+    c.close()

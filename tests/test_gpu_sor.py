@@ -111,3 +111,19 @@ def test_refusals(ctx, capi):
     ctx.set_params(publish_clouds=1, **synth.params_of("C1"))
     r = ctx.process_xyz(synth.make_cloud("C1"))
     assert r["num_voxels"] > 0
+
+
+def test_product_against_the_numpy_formulation(capi):
+    """The product against the brute-force NumPy formulation of tests/test_oracle_sor.py directly (the host's two sequential
+    double sums share their text with the C++ oracle): mean distances, threshold and kept points bit for bit."""
+    from tests.test_oracle_sor import brute
+    rng = np.random.default_rng(21)
+    pts = np.concatenate([rng.normal(0, 0.3, (1200, 3)), rng.uniform(-3, 3, (90, 3))]).astype(np.float32)
+    c = capi.Context(len(pts))
+    for k, mul in ((15, 1.0), (4, 0.25)):
+        g = c.statistical_outlier_removal(pts, k, mul)
+        dist, thr, keep = brute(pts, k, mul)
+        assert g["distances"].tobytes() == dist.tobytes()
+        assert g["threshold"] == thr
+        assert g["xyz"].tobytes() == pts[keep].tobytes()
+    c.close()
