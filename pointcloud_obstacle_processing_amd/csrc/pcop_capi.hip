@@ -142,6 +142,7 @@ struct pcop_ctx {
     // queued once more, by eager launches.  PCOP_DEBUG_SPIN0=1 makes the first batch of a context give up at its first poll (tests).
     bool internal_retry = false;             // the batch in flight is such a re-run
     bool debug_spin0 = false;                // the next batch runs with a spin limit of zero
+    bool debug_plane_mismatch = false;       // PCOP_DEBUG_PLANE_MISMATCH=1: the next plane split "disagrees" with the host's selection (tests of the error path)
     uint32_t internal_retries = 0;           // re-runs so far (diagnostics)
     uint64_t replans = 0;                    // batches re-run with other launch parameters / on another path (diagnostics)
     bool box_valid = false;
@@ -278,6 +279,15 @@ bool sbox_on(const pcop_ctx* c) {
     return cells <= (1ull << 30);
 }
 
+// The sort path without its bounds pass (single frames, and whatever the streaming path does not take), once there is a box.
+bool sbox_sort_on(const pcop_ctx* c) {
+    if (!(c->sbox_enabled && c->box_valid && !c->vt_skip && !stream_on(c) && c->kind != kFrameClusterOnly)) return false;
+    if (c->retry_to_caller || c->cur_n_dev) return false;
+    uint64_t cells = 1;
+    for (int a = 0; a < 3; ++a) cells *= (uint64_t)((int64_t)c->box_hi[a] - c->box_lo[a] + 1);
+    return cells <= (1ull << 30);
+}
+
 // The launch sequence of one batch.  nb = launch-size bucket (>= every frame's point count), nf =
 // frames; all real counts are read on the device.  Everything here is capturable into a hipGraph.
 enum LaunchParts : uint32_t { kPartVoxel = 1u, kPartCluster = 2u, kPartEmit = 4u, kPartAll = 7u,
@@ -340,9 +350,8 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
         mark(c, "k_voxel_gather");
     } else if (kind != kFrameClusterOnly && (parts & kPartVoxel)) {
         const bool stream = stream_on(c);
-        if (c->sbox_batch) {   // keys against the host's box: no bounds pass, k_bin_hist takes the bounds on its way
-            if (getenv("PCOP_DEBUG_KEEP_MINMAX")) { k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, 0u); mark(c, "k_minmax"); }
-            k_vt_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, c->npass_voxel, (uint32_t)MAXB, fold_grid, 2u);
+        if (c->sbox_batch) {   // keys against the host's box: no bounds pass, k_bin_hist / k_radix_hist of pass 0 takes the bounds on its way
+            k_vt_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, c->npass_voxel, (uint32_t)MAXB, fold_grid, stream ? 2u : 3u);
             mark(c, "k_vt_setup");
         } else {
             k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, 0u);
@@ -515,7 +524,7 @@ uint32_t fill_frame_args(pcop_ctx* c) {
 
 int enqueue_batch(pcop_ctx* c) {
     c->vt_batch = vt_on(c);
-    c->sbox_batch = !c->vt_batch && sbox_on(c);
+    c->sbox_batch = !c->vt_batch && (sbox_on(c) || sbox_sort_on(c));
     const uint32_t nb = fill_frame_args(c);
     c->ev_used = 0;
     if (c->profiling || !c->use_graph || c->internal_retry) {
@@ -1060,6 +1069,7 @@ int plane_removal_loop(pcop_ctx* c, Slot& sl, const float* in_x, const float* in
         uint32_t dev[2] = {0, 0};
         HIPCHK(c, hipMemcpyAsync(dev, d_counts, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->debug_plane_mismatch) { c->debug_plane_mismatch = false; dev[0] = kept + 1u; }   // (PCOP_DEBUG_PLANE_MISMATCH: the branch below, once)
         if (dev[1] || dev[0] != kept) { c->err = "internal: the plane split disagrees with the host's selection"; return PCOP_ERR_STATE; }
         if (kept == n) { *found_all = 0; break; }   // inliers->indices.size() == 0
         if (coeffs) coeffs->insert(coeffs->end(), refined, refined + 4);
@@ -1141,7 +1151,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
     TRY(dev_alloc(c, &f.table, ntiles * kMaxBins)); TRY(dev_alloc(c, &f.table_x, ntiles * kMaxBins));
     TRY(dev_alloc(c, &f.bin_total, (size_t)kMaxBins));
     TRY(dev_alloc(c, &f.tile_a, nscan)); TRY(dev_alloc(c, &f.tile_b, nscan));
-    TRY(dev_alloc(c, &f.partials, std::max<size_t>(kReduceBlocks, n / kBinTileSmall + 2)));   // (keys on the host's box: one per tile of k_bin_hist / k_vt_sort)
+    TRY(dev_alloc(c, &f.partials, std::max<size_t>(kReduceBlocks, n / kTile + 2)));   // (keys on the host's box: one per tile of k_bin_hist / k_radix_hist / k_vt_sort)
     TRY(dev_alloc(c, &f.hkey, hcap)); TRY(dev_alloc(c, &f.hcount, hcap)); TRY(dev_alloc(c, &f.hmin, hcap));
     TRY(dev_alloc(c, &f.cell_start, hcap)); TRY(dev_alloc(c, &f.parent, hcap));
     TRY(dev_alloc(c, &f.comp_size, hcap)); TRY(dev_alloc(c, &f.comp_rank, hcap)); TRY(dev_alloc(c, &f.cell_list, n + 1));
@@ -1246,6 +1256,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_VOXEL_TILED")) c->vt_enabled = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VOXEL_BOX")) c->sbox_enabled = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_SPIN0")) c->debug_spin0 = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_DEBUG_PLANE_MISMATCH")) c->debug_plane_mismatch = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VT_CAP")) c->vt_plan_cap = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_VT_REDUCE_BLOCKS")) c->vt_reduce_blocks = (uint32_t)std::max(16, atoi(e));
     if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
@@ -1953,6 +1964,10 @@ int pcop_process_node_clouds(pcop_ctx* c, const float* xyz, int layout, size_t n
     }
     c->cur_n_dev = nullptr; c->retry_to_caller = false;
     if (rc) {
+        // one way out for every error of the call, wherever in the frame it happened: nothing in flight, the occupancy flags all
+        // zero again (the streaming voxel path and the cell grid rely on that), the stream drained
+        c->in_flight = false;
+        scrub_flags(c);
         if (rc == PCOP_ERR_STATE && (sl.h_state->err & kErrSorFew)) { c->err = "fewer voxels than mean_k + 1: the reference reads past its k-NN result"; return PCOP_ERR_PARAM; }
         return rc;
     }

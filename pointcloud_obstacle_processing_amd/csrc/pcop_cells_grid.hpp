@@ -81,11 +81,9 @@ __global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
 // so the chain has no k_cell_mark launch.  One block per bucket.  A frame the voxel grid passed through (or gave no voxels)
 // has no buckets: its cell stage sees the input cloud, marked here by all blocks together.
 constexpr uint32_t kGatherPer = 8;   // tiled voxel path: buckets per block of k_voxel_gather
-__device__ __forceinline__ void vt_true_grid(Frame& F, MinMaxPartial* s_p, uint32_t tile);
 
 __global__ __launch_bounds__(kBlock) void k_voxel_gather(Frame* frames) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    __shared__ MinMaxPartial s_p[kBlock];   // (keys on the host's box: the last block reduces the tiles' bounds)
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
@@ -119,11 +117,6 @@ __global__ __launch_bounds__(kBlock) void k_voxel_gather(Frame* frames) {
         const float4* __restrict__ scratch = F.rec_b;
         const uint32_t first = F.binfo[b].x, nvox = bucket_pub[b];
         if (b == nb - 1u && threadIdx.x == 0) finish_voxel(st, base + nvox);
-        if (b == nb - 1u && st->sbox) {   // (every bucket's records were keyed before this kernel started: PCL's own grid may go into DevState now)
-            const uint32_t tile = st->tile;
-            __syncthreads();
-            vt_true_grid(F, s_p, tile);
-        }
         for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
             const float4 p = scratch[first + v];
             const uint32_t i = base + v;

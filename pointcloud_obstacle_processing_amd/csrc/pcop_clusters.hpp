@@ -351,7 +351,10 @@ struct HostOut {
     float* cloud;          // voxel cloud in st->out_layout
 };
 
+__device__ __forceinline__ void vt_true_grid(Frame& F, MinMaxPartial* s_p);
+
 __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t npass_csr) {
+    __shared__ MinMaxPartial s_p[kBlock];   // (keys on the host's box: the first block reduces the tiles' bounds)
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const HostOut out{F.h_state, F.h_offsets, F.h_indices, F.h_cloud};
@@ -379,7 +382,11 @@ __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t n
             }
         }
     }
-    if (tid == 0) *out.state = *st;
+    if (blockIdx.x == 0) {
+        // a frame keyed against the host's box: every kernel that forms voxel keys is through, PCL's own min_b / div_b go into DevState
+        if (st->sbox && !st->err && !st->passthrough) { vt_true_grid(const_cast<Frame&>(F), s_p); __syncthreads(); }
+        if (threadIdx.x == 0) *out.state = *st;
+    }
     if (st->err) return;
     if (st->kind != kFrameVoxelOnly && !st->trivial) {
         const uint32_t k = st->n_kept, np = st->n_kept_pts;

@@ -208,7 +208,7 @@ struct DevState {
     uint32_t plan_cap;      // k_bin_plan: points per bucket (in the units of the histogram it is given); 0: kBucketCap
     uint32_t vt_nonfinite;  // non-finite points k_vt_sort / k_bin_hist dropped
     uint32_t spin_limit;    // polls a block may make on a lower block's publish word before it gives the frame up (kErrInternal)
-    uint32_t pad0;
+    uint32_t box_tile;      // keys on the host's box: points per tile of the pass that took the bounds (one MinMaxPartial each)
     uint32_t sbox;          // 1: the voxel keys of this frame are formed against the host's box (tiled path, or the streaming path without its
                             // bounds pass); k_voxel_gather / k_vt_scan put PCL's own grid here when the keys are done with
 };

@@ -321,6 +321,9 @@ __device__ __forceinline__ PassInfo pass_info(const DevState* st, int pass) {
 }
 
 template <int MAXB>
+__device__ __forceinline__ void radix_hist_on_box(const Frame& F, uint32_t* s_h, uint32_t tile_base, const PassInfo& pi, const RecSrc& src);
+
+template <int MAXB>
 __global__ __launch_bounds__(kBlock) void k_radix_hist(const Frame* frames, int pass) {
     __shared__ uint32_t s_h[(1 << MAXB) + 1];
     const Frame& F = frames[blockIdx.y];
@@ -336,6 +339,9 @@ __global__ __launch_bounds__(kBlock) void k_radix_hist(const Frame* frames, int 
     __syncthreads();
     const uint32_t mask = (1u << pi.bits) - 1u;
     const uint32_t wbase = tile_base + (threadIdx.x / kWave) * (kItems * kWave) + lane_id();
+    if (pass == 0 && st->sbox) {   // keys on the host's box: this pass takes the bounds too
+        radix_hist_on_box<MAXB>(F, s_h, tile_base, pi, src);
+    } else {
     Rec3 rec[kItems];
     load_records(src, wbase, pi.count, rec);
 #pragma unroll
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_radix_hist(const Frame* frames, int 
             else d = (key(r) >> pi.shift) & mask;
             atomicAdd(&s_h[d], 1u);
         }
+    }
     }
     __syncthreads();
     // bin-major table (table[bin * ntiles + tile]): the scan kernel then reads and writes whole rows

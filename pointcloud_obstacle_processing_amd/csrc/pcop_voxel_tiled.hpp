@@ -80,14 +80,16 @@ __device__ __forceinline__ void box_partial(MinMaxPartial* p, const uint32_t* mn
 }
 
 // One block per frame: DevState from the mailbox, the host's box as the voxel grid, the coarse bins, the cell grid.
-// mode 1: the tiled path; 2: the streaming path (k_bin_hist takes the bounds on its way).
+// mode 1: the tiled path (k_vt_sort takes the bounds on its way); 2: the streaming path (k_bin_hist does); 3: the sort path (k_radix_hist of
+// pass 0 does).
 __global__ __launch_bounds__(kBlock) void k_vt_setup(Frame* frames, uint32_t npass, uint32_t maxbits, uint32_t fold_grid, uint32_t mode) {
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     if (threadIdx.x == 0) {
         frame_init(F);
         const FrameArgs a = *F.args;
-        st->sbox = 1u; st->vpath = 1u;
+        st->sbox = 1u; st->vpath = mode == 3u ? 0u : 1u;
+        st->box_tile = mode == 1u ? kVtTile : (mode == 2u ? st->tile : (uint32_t)kTile);
         if (mode == 1u) { st->vt = 1u; st->plan_cap = a.plan_cap; st->tile = kBinTile; }
         uint64_t cells = 1;
         for (int k = 0; k < 3; ++k) {
@@ -99,13 +101,80 @@ __global__ __launch_bounds__(kBlock) void k_vt_setup(Frame* frames, uint32_t npa
         }
         st->mul[0] = 1u; st->mul[1] = a.box_dim[0]; st->mul[2] = a.box_dim[0] * a.box_dim[1];
         const uint32_t kb = bits_for(cells);   // (the host keeps the box below 2^30 cells)
-        make_plan(&st->plan_voxel, kb, npass, maxbits);
-        st->gbits = min(kb, st->gbits);
-        st->cshift = kb - st->gbits;
-        if (((mode == 1u ? kVtSpanMax : kBucketCells) >> st->cshift) == 0u) atomicOr(&st->err, (uint32_t)kErrReplanBins);   // a coarse bin spans more voxels than a bucket may
+        const bool fits = make_plan(&st->plan_voxel, kb, npass, maxbits);
+        if (mode == 3u) {
+            if (!fits) atomicOr(&st->err, (uint32_t)kErrReplanVoxel);
+        } else {
+            st->gbits = min(kb, st->gbits);
+            st->cshift = kb - st->gbits;
+            if (((mode == 1u ? kVtSpanMax : kBucketCells) >> st->cshift) == 0u) atomicOr(&st->err, (uint32_t)kErrReplanBins);   // a coarse bin spans more voxels than a bucket may
+        }
         if (mode == 1u && (st->n_in == 0u || st->n_in > (kVtMaxTiles - 1u) * kVtTile)) atomicOr(&st->err, (uint32_t)kErrReplanVt);
     }
     if (fold_grid) { __syncthreads(); cgrid_setup_block(F, st->n_in, st->n_in == 0u); }
+    if (mode == 3u) {   // k_voxel_reduce publishes "heads of tile t, plus one" here; zero = not yet published
+        __syncthreads();
+        uint32_t* __restrict__ tile_heads = F.tile_a;
+        const uint32_t ntiles = (st->n_in + kScanTile - 1) / kScanTile;
+        for (uint32_t t = threadIdx.x; t < ntiles; t += kBlock) tile_heads[t] = 0u;
+    }
+}
+
+// Pass 0 of the sort path with the keys on the host's box: the digit counts as k_radix_hist makes them, and on the way the tile's
+// bounds (voxel coordinates: box_partial), its valid points and the box check.  The block's 256 threads call; s_h is zeroed.
+template <int MAXB>
+__device__ __forceinline__ void radix_hist_on_box(const Frame& F, uint32_t* s_h, uint32_t tile_base, const PassInfo& pi, const RecSrc& src) {
+    __shared__ uint32_t s_red[kWavesPerBlock * 8u];
+    DevState* st = const_cast<DevState*>(&F.st);
+    BoxKey key; key.init(st);
+    const uint32_t mask = (1u << pi.bits) - 1u;
+    const uint32_t wbase = tile_base + (threadIdx.x / kWave) * (kItems * kWave) + lane_id();
+    Rec3 rec[kItems];
+    load_records(src, wbase, pi.count, rec);
+    uint32_t mn0 = 0xFFFFFFFFu, mn1 = 0xFFFFFFFFu, mn2 = 0xFFFFFFFFu, mx0 = 0u, mx1 = 0u, mx2 = 0u, nbad = 0u, nok = 0u;
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+        const uint32_t i = wbase + j * kWave;
+        if (i < pi.count) {
+            const Rec3 r = rec[j];
+            uint32_t d;
+            if (!finite3(r.x, r.y, r.z)) { d = pi.nb - 1; ++nbad; }   // (a cloud declared dense: the frame is given up below)
+            else {
+                uint32_t i0, i1, i2;
+                d = (key.coords(r, &i0, &i1, &i2) >> pi.shift) & mask;
+                mn0 = min(mn0, i0); mx0 = max(mx0, i0); mn1 = min(mn1, i1); mx1 = max(mx1, i1); mn2 = min(mn2, i2); mx2 = max(mx2, i2);
+                ++nok;
+            }
+            atomicAdd(&s_h[d], 1u);
+        }
+    }
+    uint32_t v[6] = {mn0, mn1, mn2, mx0, mx1, mx2};
+#pragma unroll
+    for (int dd = kWave / 2; dd > 0; dd >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { v[q] = min(v[q], (uint32_t)__shfl_xor(v[q], dd, kWave)); v[3 + q] = max(v[3 + q], (uint32_t)__shfl_xor(v[3 + q], dd, kWave)); }
+    }
+    nbad = wave_sum(nbad); nok = wave_sum(nok);
+    const uint32_t w = threadIdx.x / kWave;
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s_red[w * 8u + q] = v[q];
+        s_red[w * 8u + 6u] = nbad; s_red[w * 8u + 7u] = nok;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u}, bad = 0u, ok = 0u;
+        for (uint32_t q = 0; q < (uint32_t)kWavesPerBlock; ++q) {
+            for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], s_red[q * 8u + a]); mx[a] = max(mx[a], s_red[q * 8u + 3 + a]); }
+            bad += s_red[q * 8u + 6u]; ok += s_red[q * 8u + 7u];
+        }
+        MinMaxPartial p;
+        box_partial(&p, mn, mx, ok, bad);
+        F.partials.get()[blockIdx.x] = p;
+        if (ok) atomicAdd(&st->n_valid, ok);
+        if (bad) { if (st->is_dense == 0) atomicAdd(&st->vt_nonfinite, bad); else atomicOr(&st->err, (uint32_t)kErrNonFinite); }
+        if (ok && (mx[0] >= key.d0 || mx[1] >= key.d1 || mx[2] >= key.d2)) atomicOr(&st->err, (uint32_t)kErrReplanBox);   // a point outside the box
+    }
 }
 
 __device__ __forceinline__ void bin_hist_on_box(Frame& F, uint32_t* s_hist, uint32_t tile_base, uint32_t tile, uint32_t n, uint32_t G, uint32_t cs) {
@@ -693,12 +762,10 @@ __global__ __launch_bounds__(kBlock, 7) void k_vt_accum(Frame* frames) {
 #endif
 }
 
-// Output rank of every bucket's first voxel (its voxels follow): one block per frame scans the buckets' voxel counts; M; and,
-// nothing forming voxel keys any more, PCL's own grid goes into DevState.  k_voxel_gather then moves the centroids.
-__device__ __forceinline__ void vt_true_grid(Frame& F, MinMaxPartial* s_p, uint32_t tile);
+// Output rank of every bucket's first voxel (its voxels follow): one block per frame scans the buckets' voxel counts; M.
+// k_voxel_gather then moves the centroids.
 __global__ __launch_bounds__(kBlock) void k_vt_scan(Frame* frames) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    __shared__ MinMaxPartial s_p[kBlock];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     if (vt_off(st)) return;
@@ -717,16 +784,15 @@ __global__ __launch_bounds__(kBlock) void k_vt_scan(Frame* frames) {
         carry += tot;
     }
     if (threadIdx.x == 0) finish_voxel(st, carry);
-    __syncthreads();
-    vt_true_grid(F, s_p, kVtTile);
 }
 
-// PCL's own grid into DevState, once nothing forms keys any more (k_vt_scan; k_voxel_gather's last block on the streaming path):
-// the true bounds from the partials of the tiles of `tile` points, min_b / div_b / divb_mul as VoxelGrid::applyFilter derives
-// them (voxel_setup does the same where a bounds pass comes first).  The whole block calls.
-__device__ __forceinline__ void vt_true_grid(Frame& F, MinMaxPartial* s_p, uint32_t tile) {
+// PCL's own grid into DevState, once nothing forms keys any more (k_emit's first block, before it hands DevState to the host):
+// the true bounds from the partials of the tiles of DevState::box_tile points, min_b / div_b / divb_mul as
+// VoxelGrid::applyFilter derives them (voxel_setup does the same where a bounds pass comes first).  The whole block calls.
+__device__ __forceinline__ void vt_true_grid(Frame& F, MinMaxPartial* s_p) {
     DevState* st = &F.st;
     const MinMaxPartial* __restrict__ partials = F.partials;
+    const uint32_t tile = max(st->box_tile, 1u);
     const uint32_t ntiles = (st->n_in + tile - 1u) / tile;
     uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
     for (uint32_t i = threadIdx.x; i < ntiles; i += kBlock) {

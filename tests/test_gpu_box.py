@@ -152,3 +152,38 @@ def test_bounded_wait_that_runs_out_costs_a_rerun_not_the_frame(capi, oracle, mo
     assert single.debug_counter("internal_retries") == 1
     single.close()
     c.close()
+
+
+def test_box_path_single_frames_on_the_sort_path(capi, oracle):
+    """One frame at a time (the node's own mode): the sort path; from the second frame on its pass-0 histogram takes the
+    bounds (no k_minmax).  The frame API, the stage API (voxel grid alone), NaN holes, a point outside the box."""
+    p = synth.params_of("C3")
+    a = synth.make_cloud("C3", n=140_000, seed=480)
+    b = synth.make_cloud("C3", n=90_000, seed=481)
+    c = capi.Context(140_000)
+    c.set_params(publish_clouds=1, **p)
+    seen = []
+    for pts in (a, b, a):
+        same(c.process_xyz(pts), oracle.process_xyz(pts, **p))
+        st = c.debug_state()
+        seen.append(int(st.sbox))
+        lo, div = grid_of(pts, p["leaf"])
+        assert list(st.min_b) == lo and list(st.div_b) == div and st.vpath == 0
+    assert seen == [0, 1, 1], seen
+    vox, pt = c.voxel_downsample(b)                     # downsample_cloud alone (od.cpp:271-296)
+    want, wpt = oracle.voxel_downsample(b, p["leaf"])
+    assert vox.tobytes() == want.tobytes() and pt == wpt and c.debug_state().sbox == 1
+    q = a.copy(); q[::61] = np.nan                       # is_dense = false
+    same(c.process_xyz(q, is_dense=False), oracle.process_xyz(q, is_dense=False, **p))
+    assert c.debug_state().sbox == 1 and c.debug_state().n_valid == int(np.isfinite(q).all(axis=1).sum())
+    with pytest.raises(capi.PcopError):
+        c.process_xyz(q, is_dense=True)
+    far = b.copy(); far[5] = (9.0, 9.0, 3.0)
+    same(c.process_xyz(far), oracle.process_xyz(far, **p))
+    assert c.debug_state().sbox == 0                     # re-run with the bounds pass
+    same(c.process_xyz(far), oracle.process_xyz(far, **p))
+    assert c.debug_state().sbox == 1
+    empty = np.zeros((0, 3), dtype=f32)
+    same(c.process_xyz(empty), oracle.process_xyz(empty, **p))
+    same(c.process_xyz(a[:3]), oracle.process_xyz(a[:3], **p))
+    c.close()

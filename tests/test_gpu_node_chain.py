@@ -184,3 +184,29 @@ def test_node_chain_on_a_pass_through_frame(capi, oracle, mean_k, use_plane):
         assert np.array_equal(got["offsets"], ro) and np.array_equal(got["indices"], ri)
         assert got["n_clustered"] == len(cur)
     c.close()
+
+
+def test_node_chain_error_in_the_middle_leaves_a_usable_context(capi, oracle, monkeypatch):
+    """PCOP_DEBUG_PLANE_MISMATCH=1 makes the first plane split of the context "disagree" with the host's selection: the call
+    returns an error from the middle of the frame - and the same context then runs the node chain and a plain batch correctly
+    (nothing left in flight, the occupancy flags clean)."""
+    monkeypatch.setenv("PCOP_DEBUG_PLANE_MISMATCH", "1")
+    p = synth.params_of("C3")
+    pts = synth.make_cloud("C3", n=60_000, seed=77)
+    c = capi.Context(60_000, max_frames=2)
+    c.set_params(publish_clouds=1, **p)
+    with pytest.raises(capi.PcopError):
+        c.process_node(pts, mean_k=8, stddev_mul=1.0, plane=capi.plane_params(0.03))
+    vox, _ = oracle.voxel_downsample(pts, p["leaf"])
+    cur = oracle.sor(vox, 8, 1.0)["xyz"]
+    cur = oracle.segment_planes(cur, 0.03)["xyz"]
+    ro, ri = oracle.euclidean_clusters(cur, p["tol"], p["min_cluster"], p["max_cluster"])
+    g = c.process_node(pts, mean_k=8, stddev_mul=1.0, plane=capi.plane_params(0.03))
+    gv = g["voxel_xyz"] if g["voxel_xyz"] is not None else np.zeros((0, 3), dtype=np.float32)
+    assert gv.tobytes() == cur.tobytes() and np.array_equal(g["offsets"], ro) and np.array_equal(g["indices"], ri)
+    ref = oracle.process_xyz(pts, **p)
+    for _ in range(2):
+        c.submit_batch_host([pts, pts[::2].copy()])
+        got = c.wait_batch()
+        assert got[0]["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes() and np.array_equal(got[0]["indices"], ref["indices"])
+    c.close()

@@ -13,4 +13,6 @@ cp $O/configs.txt profiles/${tag}_configs.txt
 cp $O/occupancy.json profiles/${tag}_occupancy.json
 cp $O/sor.json profiles/${tag}_sor.json
 cp $O/node_chain.json profiles/${tag}_node_chain.json
+cp $O/sq_lds.txt profiles/${tag}_sq_lds.txt
+cp $O/fuzz_stateful.txt profiles/${tag}_fuzz_stateful.txt
 ls -la profiles/${tag}_*

@@ -15,6 +15,8 @@ echo "trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --rounds 3 --no-cpu-baseline --no-end-to-end --contexts 1 > $O/pmc_$c.log 2>&1
 done
+# the "why" of the LDS-heavy kernels: bank conflicts against LDS-active cycles, LDS issue stalls, wave cycles (one pass: 8 SQ counters fit)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --rounds 3 --no-cpu-baseline --no-end-to-end --contexts 1 > $O/pmc_sq.log 2>&1
 echo "pmc done"
 # single-frame latency: the kernel trace of one-frame calls
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -o trace -- python3 $R/tools/single_frame.py > $O/trace1.log 2>&1
@@ -28,11 +30,13 @@ python3 tools/prof_summary.py $T1 1 > $O/kernel_summary_single_frame.txt
 F=$(dirname $(find $O/pmc_FETCH_SIZE -name pmc_counter_collection.csv | head -1))
 W=$(dirname $(find $O/pmc_WRITE_SIZE -name pmc_counter_collection.csv | head -1))
 python3 tools/pmc_summary.py $F $W $B $O/pmc_traffic.json > $O/pmc_summary.txt
+python3 tools/pmc_table.py $O/pmc_sq > $O/sq_lds.txt
 head -14 $O/kernel_summary_batch$B.txt; head -10 $O/pmc_summary.txt; tail -3 $O/kernel_summary_single_frame.txt
 python3 tests/tools/config_report.py > $O/configs.txt 2> $O/configs.err
 python3 tests/tools/occ_bench.py > $O/occupancy.json
 python3 tests/tools/sor_bench.py > $O/sor.json
 python3 tests/tools/node_bench.py > $O/node_chain.json
+python3 tests/tools/fuzz_stateful.py 90 5 2>&1 | grep -v "^  \.\.\." | tail -3 > $O/fuzz_stateful.txt
 echo "configs / occupancy / sor / node chain done"
 python3 - <<PY
 import json; d=json.load(open("$O/bench.json")); print(d["value"], d["latency_ms_single_frame"], d["roofline"], d.get("cpu_baseline"), d.get("end_to_end"), d.get("parity"))
