@@ -136,6 +136,7 @@ struct pcop_ctx {
     bool vt_batch = false;                   // the batch in flight runs the tiled path
     uint32_t vt_strikes = 0;                 // batches refused for a bucket above its LDS (three: off for this leaf size)
     uint32_t vt_plan_cap = kVtPlanCap;       // points per bucket the plan aims at (PCOP_VT_CAP)
+    bool vt_accum = false;                   // PCOP_VT_REDUCE=accum: k_vt_accum instead of the gathering k_bucket_reduce
     uint32_t vt_reduce_blocks = 1792;        // blocks of k_vt_accum over the whole batch (PCOP_VT_REDUCE_BLOCKS): seven to a CU
     // A bounded device-side wait that runs out (kErrInternal: a block polled a lower block's publish word too long - only
     // possible when the GPU is shared so heavily that blocks of one launch are kept apart) costs a re-run, not the frame: the batch is
@@ -341,9 +342,13 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             else k_vt_sort<8, false><<<vtg, kVtThreads, vt_sort_lds_bytes(8u * kVtThreads, 2048u), s>>>(fr);
         }
         mark(c, "k_vt_sort");
-        // persistent waves, sixteen to a CU over the whole batch: each takes every grid-th bucket
-        k_vt_accum<<<dim3(std::max(1u, std::min(div_up(c->nb_cap, kWavesPerBlock), std::max(4u, c->vt_reduce_blocks / nf))), nf), kBlock, 0, s>>>(fr);
-        mark(c, "k_vt_accum");
+        if (c->vt_accum) {   // PCOP_VT_REDUCE=accum: a wave per bucket, lane-ordered float adds to LDS (persistent waves: each takes every grid-th bucket)
+            k_vt_accum<<<dim3((std::max(8u, std::min(div_up(c->nb_cap, kWavesPerBlock), std::max(8u, c->vt_reduce_blocks / nf))) + 7u) / 8u * 8u, nf), kBlock, 0, s>>>(fr);
+            mark(c, "k_vt_accum");
+        } else {             // the streaming path's bucket kernel, its records gathered piece by piece
+            k_bucket_reduce<true, true><<<dim3((div_up(c->nb_cap, kReduceBucketsPerBlock) + 7u) / 8u * 8u, nf), kBlock, 0, s>>>(fr);   // (a multiple of eight blocks: the XCD mapping)
+            mark(c, "k_bucket_reduce");
+        }
         k_vt_scan<<<dim3(1, nf), kBlock, 0, s>>>(fr);
         mark(c, "k_vt_scan");
         k_voxel_gather<<<dim3(div_up(c->nb_cap, kGatherPer), nf), kBlock, 0, s>>>(fr);
@@ -1258,6 +1263,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_DEBUG_SPIN0")) c->debug_spin0 = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_PLANE_MISMATCH")) c->debug_plane_mismatch = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VT_CAP")) c->vt_plan_cap = (uint32_t)std::max(64, atoi(e));
+    if (const char* e = getenv("PCOP_VT_REDUCE")) c->vt_accum = std::string(e) == "accum";
     if (const char* e = getenv("PCOP_VT_REDUCE_BLOCKS")) c->vt_reduce_blocks = (uint32_t)std::max(16, atoi(e));
     if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
     if (const char* e = getenv("PCOP_BIN_BITS")) { c->gbits = (uint32_t)std::min<int>(kBinBitsMax, std::max<int>(kBinBitsMin, atoi(e))); c->gbits_fixed = true; }

@@ -1445,8 +1445,14 @@ __global__ __launch_bounds__(kBlock) void k_heavy_split(Frame* frames) {
     if (threadIdx.x == 0) F.hparts[b] = ng;
 }
 
-template <bool ORDERED>   // as in k_bin_scatter
-__global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
+// TILED (the tiled voxel path, pcop_voxel_tiled.hpp): the bucket's records are not one run of rec_a but one PIECE per tile of
+// k_vt_sort, in tile order (= index order): pre[b][t] .. pre[b + 1][t] of tile t's output.  The block builds the piece table
+// (first record and first position of every piece: one scan), every thread finds the piece of each of its eight
+// positions - eight binary searches side by side, one LDS read each per round - and from there on the bucket is in
+// registers as on the streaming path.  The kernel publishes {first, records} in binfo[b] itself (first = the records of the
+// lower buckets over all tiles); a bucket above kBucketCap points (the sample's plan is an estimate) raises kErrReplanVt.
+template <bool ORDERED, bool TILED = false>   // ORDERED: as in k_bin_scatter
+__global__ __launch_bounds__(kBlock, TILED ? 3 : 1) void k_bucket_reduce(Frame* frames) {   // (TILED: three blocks to a CU, as its LDS allows)
     constexpr uint32_t NW = kBlock / kWave;                    // 4 waves; a wave ranks 512 consecutive points of the bucket
     constexpr uint32_t kItemsB = kBucketCap / kBlock;          // 8
     constexpr uint32_t kBucketsPerBlock = kReduceBucketsPerBlock;
@@ -1460,15 +1466,20 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     __shared__ __attribute__((aligned(16))) uint16_t s_vs[kBucketCap + 8u];   // per occupied voxel id, in order: where its run starts in the staged bucket; then the end of the last run
     __shared__ unsigned long long s_match[ORDERED ? 1u : NW * 96u];   // per wave: 64 + 32 peer-mask words (voxel ids below 2048)
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    __shared__ uint32_t s_src[TILED ? kVtMaxTiles : 1u];          // TILED, per piece: its first record in rec_a
+    __shared__ uint16_t s_dst[TILED ? kVtMaxTiles + 2u : 2u];     //                   its first position in the bucket (0xFFFF beyond the tiles)
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
-    const uint4* __restrict__ binfo = F.binfo;
+    uint4* __restrict__ binfo = F.binfo;
     const Rec3* __restrict__ recs = reinterpret_cast<const Rec3*>(F.rec_a.get());
     uint32_t* __restrict__ bucket_pub = F.bucket_pub;
     float4* __restrict__ scratch = F.rec_b;
-    if (stream_off(st)) return;
+    if (TILED ? (voxel_stage_off(st) || !st->vt) : stream_off(st)) return;
     const uint32_t nb = st->nbuckets;
-    if (blockIdx.x * kBucketsPerBlock >= nb) return;
+    // (TILED, measured: handing every XCD one contiguous eighth of the buckets - so that the cache lines neighbouring pieces share are
+    //  fetched by one L2 only - is slower, not faster: the buckets' costs fall along the key order and the XCDs end up unevenly loaded)
+    const uint32_t blk = blockIdx.x;
+    if (blk * kBucketsPerBlock >= nb) return;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(s_mem);
     uint16_t* wpre = reinterpret_cast<uint16_t*>(s_mem + kMapWords * 4u);
     float* stage_x = reinterpret_cast<float*>(s_mem); float* stage_y = stage_x + kPlane; float* stage_z = stage_y + kPlane;
@@ -1478,26 +1489,93 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     // A block takes kBucketsPerBlock consecutive buckets, one after the other; the records of the next one are requested
     // before the current one is worked on, so only the first bucket's load latency is exposed.
     Rec3 rec[kItemsB], recn[kItemsB];
-    uint4 info_n = binfo[blockIdx.x * kBucketsPerBlock];
+    uint4 info_n = binfo[blk * kBucketsPerBlock];
+    // TILED: the rows of `pre` of a bucket (clamped, unconditional), then its piece table and {first, records} into info_n
+    constexpr uint32_t kPieces = TILED ? kVtMaxTiles / kBlock + 1u : 1u;
+    uint32_t ra[kPieces], re[kPieces];
+    uint32_t ntiles = 1u, tpad = 2u;
+    if constexpr (TILED) {
+        ntiles = (st->n_in + kVtTile - 1u) / kVtTile;
+        while (tpad < ntiles + 1u) tpad <<= 1;   // (<= kVtMaxTiles: the host keeps ntiles below it)
+    }
+    auto rows = [&](uint32_t bb) {
+        if constexpr (TILED) {
+            const uint16_t* __restrict__ pre = F.tcnt;
+            const uint32_t ts = F.tstride;
+#pragma unroll
+            for (uint32_t q = 0; q < kPieces; ++q) {
+                const uint32_t tc = min(threadIdx.x + q * kBlock, ntiles - 1u);
+                ra[q] = pre[(size_t)bb * ts + tc]; re[q] = pre[(size_t)(bb + 1u) * ts + tc];
+            }
+        }
+    };
+    auto table = [&]() {   // (every thread calls: two block scans)
+        if constexpr (TILED) {
+            uint32_t lsum = 0u, asum = 0u, len[kPieces];
+#pragma unroll
+            for (uint32_t q = 0; q < kPieces; ++q) {
+                const bool there = threadIdx.x + q * kBlock < ntiles;
+                len[q] = there ? re[q] - ra[q] : 0u;
+                lsum += len[q]; asum += there ? ra[q] : 0u;
+            }
+            // (pieces are numbered t = thread + q * 256: a thread's pieces are not neighbours, so the scan runs per q)
+            uint32_t cnt_b = 0u, first_b = 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < kPieces; ++q) {
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan(len[q], s_w, &tot);
+                const uint32_t t = threadIdx.x + q * kBlock;
+                if (t < tpad) { s_src[t] = t * kVtTile + ra[q]; s_dst[t] = t < ntiles ? (uint16_t)min(cnt_b + ex, 0xFFFEu) : (uint16_t)0xFFFFu; }
+                cnt_b += tot;
+                __syncthreads();
+                first_b += block_sum(t < ntiles ? ra[q] : 0u, s_w);
+            }
+            (void)lsum; (void)asum;
+            info_n.x = first_b; info_n.y = cnt_b;
+            __syncthreads();
+        }
+    };
     auto request = [&](Rec3* r, const uint4& inf) {
         const uint32_t lastr = inf.y ? min(inf.y, kBucketCap) - 1u : 0u;
+        if constexpr (TILED) {
+            uint32_t lo[kItemsB], p[kItemsB];
 #pragma unroll
-        for (uint32_t j = 0; j < kItemsB; ++j) r[j] = recs[inf.x + min(pbase + j * kWave, lastr)];   // clamped, unconditional
+            for (uint32_t j = 0; j < kItemsB; ++j) { p[j] = min(pbase + j * kWave, lastr); lo[j] = 0u; }
+            for (uint32_t h = tpad >> 1; h; h >>= 1) {
+#pragma unroll
+                for (uint32_t j = 0; j < kItemsB; ++j) lo[j] += ((uint32_t)s_dst[lo[j] + h] <= p[j]) ? h : 0u;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kItemsB; ++j) r[j] = recs[s_src[lo[j]] + (p[j] - (uint32_t)s_dst[lo[j]])];
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < kItemsB; ++j) r[j] = recs[inf.x + min(pbase + j * kWave, lastr)];   // clamped, unconditional
+        }
     };
+    if constexpr (TILED) { rows(blk * kBucketsPerBlock); table(); }
     request(recn, info_n);
+    if constexpr (TILED) { if (blk * kBucketsPerBlock + 1u < nb) rows(blk * kBucketsPerBlock + 1u); }
     for (uint32_t it = 0; it < kBucketsPerBlock; ++it) {
-    const uint32_t b = blockIdx.x * kBucketsPerBlock + it;
+    const uint32_t b = blk * kBucketsPerBlock + it;
     if (b >= nb) break;
     const uint4 info_b = info_n;   // {first record, records, first key, keys spanned}
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) rec[j] = recn[j];
-    if (it + 1u < kBucketsPerBlock && b + 1u < nb) { info_n = binfo[b + 1u]; request(recn, info_n); }
+    if (it + 1u < kBucketsPerBlock && b + 1u < nb) {
+        info_n = binfo[b + 1u];
+        if constexpr (TILED) table();   // (its rows came in while the bucket before was being set up)
+        request(recn, info_n);
+    }
     // a heavy bucket comes as the buckets k_heavy_split cut it into, taken one after the other; their voxels follow each
     // other in the bucket's part of the scratch records
-    const bool heavy = info_b.y > kBucketCap;
+    const bool heavy = !TILED && info_b.y > kBucketCap;
     const uint32_t nparts = heavy ? min(F.hparts[b], kHeavyGroups) : 1u;
     uint32_t nv_acc = 0u;
     bool failed = heavy && nparts == 0u;
+    if (TILED && info_b.y == 0u) {   // (a bucket the sample planned and the cloud left empty)
+        if (threadIdx.x == 0) { binfo[b] = make_uint4(info_b.x, 0u, info_b.z, info_b.w); bucket_pub[b] = 0u; }
+        continue;
+    }
     for (uint32_t part = 0; part < nparts && !failed; ++part) {
     uint4 info = info_b;
     if (heavy) {
@@ -1662,8 +1740,9 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     __syncthreads();   // the next bucket clears and fills the same LDS
     }
     if (threadIdx.x == 0) {   // k_voxel_gather adds the counts up to output ranks
-        if (failed) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)kErrInternal); bucket_pub[b] = 0u; }
+        if (failed) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)(TILED ? kErrReplanVt : kErrInternal)); bucket_pub[b] = 0u; }   // (TILED: more points than the sample promised)
         else bucket_pub[b] = nv_acc;
+        if (TILED) binfo[b] = make_uint4(info_b.x, failed ? 0u : info_b.y, info_b.z, info_b.w);   // where k_voxel_gather finds the bucket's centroids
     }
     }
 }

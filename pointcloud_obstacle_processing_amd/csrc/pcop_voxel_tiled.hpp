@@ -588,8 +588,9 @@ __global__ __launch_bounds__(kBlock, 7) void k_vt_accum(Frame* frames) {
     while (tpad < ntiles + 1u) tpad <<= 1;                // search range: a power of two above the tiles (<= T: the host keeps ntiles < T)
     VoxelKey key; key.init(st);                           // (k_vt_sort has checked every record against the box)
     const uint32_t step = gridDim.x * kWavesPerBlock;
+    const uint32_t b_end = nb;
     uint32_t b = blockIdx.x * kWavesPerBlock + w;
-    if (b >= nb) return;
+    if (b >= b_end) return;
     // rows of bucket b (clamped, unconditional): where it starts and ends in every tile's output
     uint32_t ra[kRows], re[kRows];
     uint4 rinfo;
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(kBlock, 7) void k_vt_accum(Frame* frames) {
 #else
 #define ACC_T(i) do { } while (0)
 #endif
-    for (; b < nb; b += step) {
+    for (; b < b_end; b += step) {
         ACC_T(5);
         const uint32_t key_lo = rinfo.z, span = rinfo.w;
         // the piece table: per tile (in order) the first record and the first position; the bucket's points and its place
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(kBlock, 7) void k_vt_accum(Frame* frames) {
             cnt += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
             first += wave_sum(there ? ra[q] : 0u);
         }
-        if (b + step < nb) rows(b + step);   // in flight while this bucket is summed
+        if (b + step < b_end) rows(b + step);   // in flight while this bucket is summed
         ACC_T(0);
         const bool bad = span > kVtSpanMax || span == 0u || cnt > 0xFFFEu;   // never: k_bin_plan keeps the span, a tile holds 8192 points
         if (bad || cnt == 0u) {
