@@ -38,7 +38,7 @@ struct GraphKey {
     uint32_t stream, nb_cap, gbits;  // streaming voxel path: on?, buckets provided for (LDS, grids), log2 of the coarse bins (LDS)
     // (lds_ordered is fixed for the life of a context: not part of the key)
     uint32_t cgrid, ctiles;          // dense cell grid: on?, occupancy tiles (grid)
-    uint32_t vt;                     // tiled voxel path: 0 off, 1 on, 2 on with the order check
+    uint32_t vt;                     // tiled voxel path: 0 off, 1 on, 2 on with the order check; 3: keys against the host's box; + 16: streaming path with its order check
     bool operator<(const GraphKey& o) const {
         if (vt != o.vt) return vt < o.vt;
         if (cgrid != o.cgrid) return cgrid < o.cgrid;
@@ -132,6 +132,8 @@ struct pcop_ctx {
     bool sbox_enabled = true;
     bool sbox_batch = false;                 // the batch in flight runs the streaming path on the box
     bool vt_skip = false;                    // the batch in flight was refused: its re-run takes the streaming path
+    bool stream_checked = false, stream_chk = false;   // the streaming path's partition was verified once against the peer-mask ranks / this batch does it
+    bool debug_order_mismatch = false;       // PCOP_DEBUG_ORDER_MISMATCH=1: that check fails once
     bool vt_checked = false;                 // the first tiled batch ran the build that verifies the order of every tile
     bool vt_batch = false;                   // the batch in flight runs the tiled path
     uint32_t vt_strikes = 0;                 // batches refused for a bucket above its LDS (three: off for this leaf size)
@@ -379,15 +381,22 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             k_bin_colscan<<<dim3(div_up(c->nb_cap, kWavesPerBlock), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_bin_colscan");
             if (c->lds_ordered) {
-                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, true><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr);
-                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, true><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr);
-                else k_bin_scatter<8, true><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr);
+                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, true><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr, 0u);
+                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, true><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr, 0u);
+                else k_bin_scatter<8, true><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr, 0u);
             } else {
-                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, false><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr);
-                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, false><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr);
-                else k_bin_scatter<8, false><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr);
+                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, false><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr, 0u);
+                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, false><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr, 0u);
+                else k_bin_scatter<8, false><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr, 0u);
             }
             mark(c, "k_bin_scatter");
+            if (c->stream_chk) {   // first streamed batch: the same partition once more with ranks from peer masks, byte for byte
+                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, false><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr, 1u);
+                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, false><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr, 1u);
+                else k_bin_scatter<8, false><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr, 1u);
+                k_rec_compare<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, c->debug_order_mismatch ? 1u : 0u);
+                mark(c, "k_rec_compare");
+            }
             if (c->heavy_ok) {   // (only once a frame needed it: an ordinary cloud has no bin above a bucket)
                 k_heavy_split<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
                 mark(c, "k_heavy_split");
@@ -530,6 +539,7 @@ uint32_t fill_frame_args(pcop_ctx* c) {
 int enqueue_batch(pcop_ctx* c) {
     c->vt_batch = vt_on(c);
     c->sbox_batch = !c->vt_batch && (sbox_on(c) || sbox_sort_on(c));
+    c->stream_chk = !c->vt_batch && c->kind != kFrameClusterOnly && stream_on(c) && c->lds_ordered && !c->stream_checked;
     const uint32_t nb = fill_frame_args(c);
     c->ev_used = 0;
     if (c->profiling || !c->use_graph || c->internal_retry) {
@@ -539,7 +549,7 @@ int enqueue_batch(pcop_ctx* c) {
     } else {
         const bool st_on = stream_on(c);
         const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr | ((c->csr_onepass && c->csr_small) ? 0x100u : 0u), c->nframes, st_on ? tile_for(nb, c->nframes) : 0u, st_on ? (c->heavy_ok ? 2u : 1u) : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
-                           grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u, c->vt_batch ? (c->vt_checked ? 1u : 2u) : (c->sbox_batch ? 3u : 0u)};
+                           grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u, (c->vt_batch ? (c->vt_checked ? 1u : 2u) : (c->sbox_batch ? 3u : 0u)) | (c->stream_chk ? 16u : 0u)};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -673,6 +683,9 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             if ((c->sbox_batch || c->vt_batch) && (e & kErrReplanBox)) {   // a point outside the box: this batch is re-run with the bounds pass
                 c->vt_skip = true;   // (whatever else a frame keyed against the wrong box reported says nothing about the cloud)
                 e &= ~(uint32_t)(kErrReplanPath | kErrReplanBins | kErrReplanVt | kErrReplanVcap);
+            } else if (c->stream_chk && (e & kErrOrder)) {
+                c->lds_ordered = false;          // the streamed partition differs between the two ways of ranking: peer masks from here on
+                c->debug_order_mismatch = false;
             } else if (c->vt_batch) {   // what the tiled voxel path refuses goes to the streaming path: this batch, or from here on
                 if (e & kErrOrder) c->lds_ordered = false;       // a tile came out in the wrong order: ranks from peer masks from here on
                 if ((e & kErrReplanVt) && ++c->vt_strikes >= 3u) c->vt_ok = false;
@@ -728,6 +741,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
     c->in_flight = false;
     c->internal_retry = false; c->debug_spin0 = false;
     if (c->vt_batch) c->vt_checked = true;   // (its tiles were verified, or an earlier batch's were)
+    if (c->stream_chk) c->stream_checked = true;
     c->vt_skip = false;
     // the voxel box of the next batches: the union of the frames' own grids (every path leaves PCL's min_b / div_b in DevState),
     // widened to multiples of eight voxels with a margin, so that it settles after a few batches of a steady source
@@ -1262,6 +1276,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_VOXEL_BOX")) c->sbox_enabled = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_SPIN0")) c->debug_spin0 = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_PLANE_MISMATCH")) c->debug_plane_mismatch = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_DEBUG_ORDER_MISMATCH")) c->debug_order_mismatch = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VT_CAP")) c->vt_plan_cap = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_VT_REDUCE")) c->vt_accum = std::string(e) == "accum";
     if (const char* e = getenv("PCOP_VT_REDUCE_BLOCKS")) c->vt_reduce_blocks = (uint32_t)std::max(16, atoi(e));
@@ -2096,6 +2111,8 @@ int pcop_debug_counter(pcop_ctx* c, const char* name, uint64_t* value) {
     if (!c || !name || !value) return PCOP_ERR_ARG;
     if (std::strcmp(name, "internal_retries") == 0) { *value = c->internal_retries; return PCOP_OK; }
     if (std::strcmp(name, "replans") == 0) { *value = c->replans; return PCOP_OK; }
+    if (std::strcmp(name, "lds_ordered") == 0) { *value = c->lds_ordered ? 1u : 0u; return PCOP_OK; }
+    if (std::strcmp(name, "stream_checked") == 0) { *value = c->stream_checked ? 1u : 0u; return PCOP_OK; }
     return PCOP_ERR_ARG;
 }
 

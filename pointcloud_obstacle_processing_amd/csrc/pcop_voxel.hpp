@@ -1162,7 +1162,7 @@ __host__ __device__ constexpr size_t scatter_lds_bytes(uint32_t nbc) {
 // instruction that hit the same word (k_lds_order_probe checked it when the context was made): the rank of a point
 // inside (wave, bucket) is then the value one atomic returns.  Otherwise the ranks come from peer masks.
 template <uint32_t PB, bool ORDERED>   // PB: buckets per thread in the per-bucket steps: the launch provides for PB * 512 buckets
-__global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
+__global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames, uint32_t alt) {   // alt: write to rec_b (the order self-check's second opinion)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     constexpr uint32_t NW = kScatThreads / kWave;   // 8 waves; a wave ranks 512 consecutive points of a chunk
     constexpr uint32_t kMatchWords = 128u;          // per wave: 64 words for the low 6 bits of the bucket, 64 for the high 6
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
     const uint16_t* __restrict__ bin2bucket = F.bin2bucket;
     const uint4* __restrict__ binfo = F.binfo;
     const uint32_t* __restrict__ tbase = F.tbase;
-    Rec3* __restrict__ out = reinterpret_cast<Rec3*>(F.rec_a.get());
+    Rec3* __restrict__ out = reinterpret_cast<Rec3*>(alt ? F.rec_b.get() : F.rec_a.get());
     if (stream_off(st)) return;
     const uint32_t n = st->n_in, nchunks = st->tile / kScatChunk;
     const uint32_t tile_base = blockIdx.x * st->tile;
@@ -1308,6 +1308,22 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames) {
         for (uint32_t k = 0; k < PB; ++k)   // back to "where the tile's next point goes"
             if (k < pb) cur[threadIdx.x * pb + k] += lstart[k] + tot[k];
     }
+}
+
+// Order self-check of the streaming path (first streamed batch of a context that ranks with lane-ordered LDS atomics): the
+// same partition was written twice, to rec_a with ranks from the atomics and to rec_b with ranks from peer masks.  Both are
+// stable, so the bytes agree; if they do not, the atomics did not hand out lane order on this part and the host falls back
+// to the peer masks for good (kErrOrder).  force: the debug knob that makes the check fail once.
+__global__ __launch_bounds__(kBlock) void k_rec_compare(Frame* frames, uint32_t force) {
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    if (stream_off(st)) return;
+    const uint32_t* __restrict__ a = reinterpret_cast<const uint32_t*>(F.rec_a.get());
+    const uint32_t* __restrict__ b = reinterpret_cast<const uint32_t*>(F.rec_b.get());
+    const size_t words = (size_t)st->n_valid * 3u;
+    bool bad = force != 0u && blockIdx.x == 0u && threadIdx.x == 0u;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock) bad |= a[i] != b[i];
+    if (__ballot(bad) && lane_id() == 0u) atomicOr(&st->err, kErrOrder);
 }
 
 // A bucket with more than kBucketCap points (a single coarse bin, k_bin_plan) is cut into buckets that fit: counts of up

@@ -154,6 +154,34 @@ def test_bounded_wait_that_runs_out_costs_a_rerun_not_the_frame(capi, oracle, mo
     c.close()
 
 
+def test_streamed_partition_checks_its_own_order_once(capi, oracle, monkeypatch):
+    """The first streamed batch of a context writes the partition twice (ranks from lane-ordered LDS atomics, ranks from peer
+    masks) and compares the bytes; they agree on this hardware, and the later batches do not pay for it.  With
+    PCOP_DEBUG_ORDER_MISMATCH=1 the comparison "fails" once: the batch is re-run with peer-mask ranks, which the context keeps
+    from then on - same bytes out either way."""
+    p = synth.params_of("C3")
+    clouds = [synth.make_cloud("C3", n=110_000, seed=475 + i) for i in range(3)]
+    refs = [oracle.process_xyz(c, **p) for c in clouds]
+    c = capi.Context(110_000, max_frames=3)
+    c.set_params(publish_clouds=1, **p)
+    assert c.debug_counter("lds_ordered") == 1 and c.debug_counter("stream_checked") == 0
+    run(c, clouds, refs)
+    assert c.debug_counter("lds_ordered") == 1 and c.debug_counter("stream_checked") == 1
+    before = c.debug_counter("replans")
+    run(c, clouds, refs)
+    assert c.debug_counter("replans") == before
+    c.close()
+    monkeypatch.setenv("PCOP_DEBUG_ORDER_MISMATCH", "1")
+    c = capi.Context(110_000, max_frames=3)
+    c.set_params(publish_clouds=1, **p)
+    run(c, clouds, refs)
+    assert c.debug_counter("lds_ordered") == 0 and c.debug_counter("replans") >= 1
+    for _ in range(2):
+        run(c, clouds, refs)
+    assert c.debug_counter("lds_ordered") == 0
+    c.close()
+
+
 def test_box_path_single_frames_on_the_sort_path(capi, oracle):
     """One frame at a time (the node's own mode): the sort path; from the second frame on its pass-0 histogram takes the
     bounds (no k_minmax).  The frame API, the stage API (voxel grid alone), NaN holes, a point outside the box."""
