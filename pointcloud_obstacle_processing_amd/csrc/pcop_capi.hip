@@ -1888,7 +1888,7 @@ int pcop_process_node_clouds(pcop_ctx* c, const float* xyz, int layout, size_t n
             break;
         }
         c->retry_to_caller = true;
-        c->vt_batch = false; c->sbox_batch = false;   // (the node chain launches by parts: the plain voxel stage with its bounds pass)
+        c->vt_batch = false; c->sbox_batch = false; c->stream_chk = false;   // (the node chain launches by parts: the plain voxel stage with its bounds pass)
         const uint32_t nb = fill_frame_args(c);
         Frame* fr = c->d_frames;
         hipStream_t s = c->stream;
