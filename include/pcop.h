@@ -303,7 +303,7 @@ int pcop_dev_download(pcop_ctx* ctx, void* host_dst, const void* dev_src, size_t
 int pcop_device_count(void);
 
 /* Test hook: device address and size of a named internal buffer of the last frame
- * ("cen_x", "rec_a", "cell_key", "parent", "label", ... ; "state" = the frame's DevState).
+ * ("cen_x", "rec_a", "cell_key", "parent", "label", ... ; "state" = the frame's DevState; "name@k": frame slot k of a batch).
  * Used by the stage-wise parity tests only; not part of the drop-in surface. */
 int pcop_debug_buffer(pcop_ctx* ctx, const char* name, void** dev_ptr, size_t* bytes);
 /* Test hook: a named host-side counter of the context ("internal_retries": batches queued a second time after a bounded

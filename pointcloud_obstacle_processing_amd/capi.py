@@ -473,9 +473,11 @@ class Context:
         self._chk(self.lib.pcop_dev_upload(self.h, C.c_void_p(ptr), flat.ctypes.data, flat.nbytes))
         return ptr, n
 
-    def debug_buffer(self, name, dtype, count):
+    def debug_buffer(self, name, dtype, count=None):
         p, b = C.c_void_p(), C.c_size_t()
         self._chk(self.lib.pcop_debug_buffer(self.h, name.encode(), C.byref(p), C.byref(b)))
+        if count is None:   # the whole buffer
+            count = b.value // np.dtype(dtype).itemsize
         out = np.zeros(count, dtype=dtype)
         assert out.nbytes <= b.value
         if out.nbytes:

@@ -133,6 +133,7 @@ struct pcop_ctx {
     bool sbox_batch = false;                 // the batch in flight runs the streaming path on the box
     bool vt_skip = false;                    // the batch in flight was refused: its re-run takes the streaming path
     bool stream_checked = false, stream_chk = false;   // the streaming path's partition was verified once against the peer-mask ranks / this batch does it
+    bool debug_sync = false;                 // PCOP_DEBUG_SYNC=1: see mark()
     bool debug_order_mismatch = false;       // PCOP_DEBUG_ORDER_MISMATCH=1: that check fails once
     bool vt_checked = false;                 // the first tiled batch ran the build that verifies the order of every tile
     bool vt_batch = false;                   // the batch in flight runs the tiled path
@@ -219,6 +220,10 @@ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // profiling: an event after every launch (eager mode only)
 void mark(pcop_ctx* c, const char* name) {
+    if (c->debug_sync) {   // PCOP_DEBUG_SYNC=1 (eager launches): drain the stream after every marked step and say which one it was
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        fprintf(stderr, "pcop: [sync] %s: %s\n", name, hipGetErrorName(e));
+    }
     if (!c->profiling) return;
     if (c->ev_used >= c->events.size()) {
         hipEvent_t e;
@@ -632,8 +637,10 @@ void order_frame(pcop_ctx* c, Slot& sl, pcop_result* out) {
 }
 
 // A batch given up half-way may leave occupancy flags set: the streaming voxel path needs them all zero.
-void scrub_flags(pcop_ctx* c) {
+void scrub_flags(pcop_ctx* c, uint32_t nslots = 0xFFFFFFFFu) {   // (nslots: the frames of the batch at hand; default: every slot)
+    uint32_t k = 0;
     for (Slot& sl : c->slots) {
+        if (k++ >= nslots) break;
         if (sl.f.cflag.get()) hipMemsetAsync(sl.f.cflag.get(), 0, (size_t)kCmapCells, c->stream);
     }
     hipStreamSynchronize(c->stream);
@@ -672,6 +679,11 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             // (every adaptive piece may have to move once for a cloud unlike the last: bins, buckets, heavy bins, voxel path,
             //  pass counts, occupancy tiles, cell path, CSR form - each moves towards "larger" only, so the loop ends)
             ++c->replans;
+            // A frame given up half-way may have marked cells beyond the tiles its occupancy scan was launched with (kErrReplanCtiles),
+            // and the re-run need not mark the same cells again: a batch that leaves the host's box for the bounds pass sets its cell
+            // grid up from other bounds.  Flags nobody consumes would sit there until some later frame's grid covers them - cells
+            // without points.  So no re-run starts on anything but clean flags.
+            scrub_flags(c, c->nframes);
             if (getenv("PCOP_DEBUG_REPLAN")) {
                 fprintf(stderr, "pcop: replan, attempt %d, bits 0x%x, vt %d;", attempt, e, c->vt_batch ? 1 : 0);
                 for (uint32_t f = 0; f < c->nframes; ++f) {
@@ -1276,6 +1288,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_VOXEL_BOX")) c->sbox_enabled = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_SPIN0")) c->debug_spin0 = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_PLANE_MISMATCH")) c->debug_plane_mismatch = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_DEBUG_SYNC")) { c->debug_sync = atoi(e) != 0; if (c->debug_sync) c->use_graph = false; }
     if (const char* e = getenv("PCOP_DEBUG_ORDER_MISMATCH")) c->debug_order_mismatch = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VT_CAP")) c->vt_plan_cap = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_VT_REDUCE")) c->vt_accum = std::string(e) == "accum";
@@ -2085,10 +2098,17 @@ int pcop_cluster_summaries(pcop_ctx* c, float* xyzr, int32_t cap_clusters) {
 int pcop_debug_buffer(pcop_ctx* c, const char* name, void** dev_ptr, size_t* bytes) {
     if (!c || !name || !dev_ptr || !bytes) return PCOP_ERR_ARG;
     const size_t n = c->cap, h = c->hash_cap;
-    const Frame& f = c->slots[0].f;
+    // "name" is slot 0's buffer, "name@k" slot k's
+    std::string base(name);
+    size_t slot = 0;
+    const size_t at = base.find('@');
+    if (at != std::string::npos) { slot = (size_t)std::strtoul(base.c_str() + at + 1, nullptr, 10); base.resize(at); }
+    if (slot >= c->slots.size()) return PCOP_ERR_ARG;
+    name = base.c_str();
+    const Frame& f = c->slots[slot].f;
     struct Ent { const char* nm; void* p; size_t b; };
     const Ent tab[] = {
-        {"state", c->d_frames, sizeof(DevState)},   // DevState is the first member of Frame
+        {"state", c->d_frames + slot, sizeof(DevState)},   // DevState is the first member of Frame
         {"cen_x", f.cen_x, n * 4}, {"cen_y", f.cen_y, n * 4}, {"cen_z", f.cen_z, n * 4},
         {"rec_a", f.rec_a, n * 16}, {"rec_b", f.rec_b, n * 16},
         {"hkey", f.hkey, h * 8}, {"hcount", f.hcount, h * 4}, {"hmin", f.hmin, h * 4},

@@ -1,5 +1,5 @@
 """Randomised parity campaign: many small and mid-sized clouds of awkward shapes through the GPU chain, the occupancy
-step, the outlier removal, the plane removal and the node's chain in one call, each compared with the CPU oracle.  usage: python tests/tools/fuzz.py [cases] [seed]"""
+step, the outlier removal, the plane removal and the node's chain in one call, each compared with the CPU oracle.  usage: python tests/tools/fuzz.py [cases] [seed]   (FUZZ_VERBOSE=1: every case and step; FUZZ_START=k: start at case k of the seed)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +11,9 @@ from pointcloud_obstacle_processing_amd import capi
 f32 = np.float32
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+kinds = ["cube", "plane", "line", "blobs", "dups", "lattice"]
 
 
 def cloud(kind, n, scale):
@@ -32,10 +35,44 @@ def cloud(kind, n, scale):
     return p.astype(f32)
 
 
+def dry(it, kind, n, scale, pts):
+    """FUZZ_START=k: the random draws of a case without its GPU / oracle calls (same draws, same order as the loop below),
+    so that a run can start at case k of a seed with the generator where the full run would have it."""
+    if it % 5 == 1 and n >= 3:
+        rng.integers(0, 3)
+    if it % 7 == 2:
+        cloud(kinds[(it + 1) % len(kinds)], max(1, n // 3), scale)
+    if it % 3 == 0 and n >= 33 and os.environ.get("PCOP_CELL_PATH") != "hash":
+        rng.choice([1, 4, 15, 31])
+    if it % 4 == 0:
+        rng.choice([0.013, 0.05, 0.15])
+    if it % 6 == 3 and n >= 3 and os.environ.get("PCOP_CELL_PATH") != "hash":
+        rng.choice([0.005, 0.02, 0.1]); rng.choice([0, 4, 15]); rng.integers(0, 2)
+
+
+start = int(os.environ.get("FUZZ_START", "0"))
 ctx = capi.Context(60_000, max_frames=2)
+dirty_seen = set()
+dirty = [0]
+
+
+def check_clean(it, tag):
+    """FUZZ_CHECK_CLEAN=1: what every call must leave behind in slot 0 - occupancy flags zero, the cell table's keys and
+    counters zero, its minima all ones - checked after every call (slow: the buffers are downloaded)."""
+    if not os.environ.get("FUZZ_CHECK_CLEAN"):
+        return
+    for name, dt, want in (("cflag", np.uint8, 0), ("hcount", np.uint32, 0), ("hmin", np.uint32, 0xFFFFFFFF), ("hkey", np.uint64, 0),
+                           ("cflag@1", np.uint8, 0), ("hcount@1", np.uint32, 0), ("hmin@1", np.uint32, 0xFFFFFFFF), ("hkey@1", np.uint64, 0)):
+        if name.endswith("@1") and tag != "batch of two":
+            continue
+        buf = ctx.debug_buffer(name, dt)
+        bad = np.flatnonzero(buf != want)
+        if len(bad) and name not in dirty_seen:
+            dirty_seen.add(name)
+            dirty[0] += 1
+            print("DIRTY after case %d %s: %s has %d entries off (first at %d, last at %d)" % (it, tag, name, len(bad), bad[0], bad[-1]), flush=True)
 t0 = time.time()
 fails = 0
-kinds = ["cube", "plane", "line", "blobs", "dups", "lattice"]
 for it in range(cases):
     kind = kinds[it % len(kinds)]
     n = int(rng.choice([1, 2, 3, 7, 33, 64, 65, 200, 1000, 5000, 20000, 50000]))
@@ -47,6 +84,9 @@ for it in range(cases):
         n = min(n, 2000)        # the CPU oracle's radius search is quadratic when everything is within the radius
     pts = cloud(kind, n, scale)
     p = dict(leaf=leaf, tol=tol, min_cluster=mn, max_cluster=mx)
+    if it < start:
+        dry(it, kind, n, scale, pts)
+        continue
     if os.environ.get("FUZZ_VERBOSE"):
         print("case", it, kind, n, scale, p, flush=True)
     ctx.set_params(publish_clouds=1, **p)
@@ -57,6 +97,7 @@ for it in range(cases):
               and np.array_equal(got["indices"], ref["indices"]) and got["passthrough"] == ref["passthrough"])
     except capi.PcopError as e:
         ok = e.status == -7 and scale / abs(tol) > 1e5     # PCOP_ERR_RANGE is the only legitimate refusal here
+    check_clean(it, "chain")
     if not ok:
         fails += 1
         print("CHAIN MISMATCH", it, kind, n, scale, p, flush=True)
@@ -80,6 +121,7 @@ for it in range(cases):
         else:
             ok = (got["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes() and np.array_equal(got["offsets"], ref["offsets"])
                   and np.array_equal(got["indices"], ref["indices"]))
+        check_clean(it, "nondense chain")
         if not ok:
             fails += 1
             print("NONDENSE MISMATCH", it, kind, n, scale, p, flush=True)
@@ -87,12 +129,14 @@ for it in range(cases):
         vg, ptg = ctx.voxel_downsample(pts)
         vr, ptr_ = O.voxel_downsample(pts, leaf)
         okv = vg.tobytes() == vr.tobytes() and ptg == ptr_
+        check_clean(it, "voxel stage")
         try:
             cg = ctx.euclidean_clusters(pts)
             cr = O.euclidean_clusters(pts, tol, mn, mx)
             okc = np.array_equal(cg[0], cr[0]) and np.array_equal(cg[1], cr[1])
         except capi.PcopError as e:
             okc = e.status == -7
+        check_clean(it, "cluster stage")
         other = cloud(kinds[(it + 1) % len(kinds)], max(1, n // 3), scale)
         try:
             ctx.submit_batch_host([pts, other])
@@ -103,6 +147,7 @@ for it in range(cases):
                 okb = okb and fr["voxel_xyz"].tobytes() == rr["voxel_xyz"].tobytes() and np.array_equal(fr["offsets"], rr["offsets"]) and np.array_equal(fr["indices"], rr["indices"])
         except capi.PcopError as e:
             okb = e.status == -7
+        check_clean(it, "batch of two")
         if not (okv and okc and okb):
             fails += 1
             print("STAGE/BATCH MISMATCH", it, kind, n, scale, p, okv, okc, okb, flush=True)
@@ -112,6 +157,7 @@ for it in range(cases):
             if os.environ.get("FUZZ_VERBOSE"):
                 print("  sor k", k, flush=True)
             g = ctx.statistical_outlier_removal(pts, k, 1.0)
+            check_clean(it, "sor")
             r = O.sor(pts, k, 1.0)
             if not (g["distances"].tobytes() == r["distances"].tobytes() and g["threshold"] == r["threshold"] and g["xyz"].tobytes() == r["xyz"].tobytes()):
                 fails += 1
@@ -125,6 +171,7 @@ for it in range(cases):
             if n > 10:
                 q[::7, 1] = np.nan; q[::11, 0] = np.nan
             g = ctx.occupancy_filter(q, capi.OccParams(po.x_min, po.x_max, po.y_min, po.y_max, po.z_min, po.z_max, po.block_size, po.dev_percent, po.grid_width, po.grid_height))
+            check_clean(it, "occupancy")
             r = O.occupancy(q, po)
             if not (g["xyz"].tobytes() == r["xyz"].tobytes() and np.array_equal(g["counts"], r["counts"]) and np.array_equal(g["grid"], r["grid"])
                     and np.array_equal(g["row_avg"], r["row_avg"]) and g["index_errors"] == r["index_errors"]):
@@ -133,6 +180,7 @@ for it in range(cases):
     if it % 6 == 3 and n >= 3 and os.environ.get("PCOP_CELL_PATH") != "hash":   # plane removal, and the node's chain in one call
         thr = float(rng.choice([0.005, 0.02, 0.1])) * max(scale, 0.1)
         g = ctx.segment_planes(pts, capi.plane_params(thr))
+        check_clean(it, "planes")
         r = O.segment_planes(pts, thr)
         if not (g["xyz"].tobytes() == r["xyz"].tobytes() and g["n_planes"] == r["n_planes"] and g["coeffs"].tobytes() == r["coeffs"].tobytes()
                 and g["found_all"] == r["found_all"]):
@@ -164,6 +212,7 @@ for it in range(cases):
                 okn = gv.tobytes() == cur.tobytes() and np.array_equal(gn["offsets"], ro) and np.array_equal(gn["indices"], ri)
         except capi.PcopError as e:
             okn = (refuse and e.status == -2) or e.status == -7
+        check_clean(it, "node chain")
         if not okn:
             fails += 1
             print("NODE CHAIN MISMATCH", it, kind, n, scale, p, mk, use_plane, thr, flush=True)
@@ -173,5 +222,7 @@ for it in range(cases):
     if it % 20 == 19:
         print("  ... %d cases, %d mismatches, %.0f s" % (it + 1, fails, time.time() - t0), flush=True)
 print("cases %d, mismatches %d, %.1f s" % (cases, fails, time.time() - t0))
+if dirty[0]:
+    print("buffers left dirty: %s" % sorted(dirty_seen))
 ctx.close()
-sys.exit(1 if fails else 0)
+sys.exit(1 if fails or dirty[0] else 0)

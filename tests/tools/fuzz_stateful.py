@@ -37,6 +37,23 @@ def sheet(n, seed):
 
 
 fails = 0
+dirty = set()
+
+
+def check_clean(it, tag, slots=(0,)):
+    """FUZZ_CHECK_CLEAN=1: after every call the occupancy flags are zero and the cell table is empty, in every slot the call used."""
+    global fails
+    if not os.environ.get("FUZZ_CHECK_CLEAN"):
+        return
+    for sl in slots:
+        for name, dt, want in (("cflag", np.uint8, 0), ("hcount", np.uint32, 0), ("hmin", np.uint32, 0xFFFFFFFF), ("hkey", np.uint64, 0)):
+            nm = name if sl == 0 else "%s@%d" % (name, sl)
+            bad = np.flatnonzero(ctx.debug_buffer(nm, dt) != want)
+            if len(bad) and nm not in dirty:
+                dirty.add(nm); fails += 1
+                print("DIRTY after step %d %s: %s has %d entries off (first at %d, last at %d)" % (it, tag, nm, len(bad), bad[0], bad[-1]), flush=True)
+
+
 t0 = time.time()
 paths = set()
 boxed = 0
@@ -57,6 +74,7 @@ for it in range(steps):
     except capi.PcopError as e:
         ok = False
         print("ERROR", e, flush=True)
+    check_clean(it, "frame")
     if not ok:
         fails += 1
         print("MISMATCH step", it, cfg, n, stretch, p, flush=True)
@@ -75,6 +93,7 @@ for it in range(steps):
         except capi.PcopError as e:
             okb = False
             print("ERROR (batch)", e, flush=True)
+        check_clean(it, "batch", (0, 1))
         if not okb:
             fails += 1
             print("BATCH MISMATCH step", it, cfg, n, stretch, p, flush=True)
@@ -92,6 +111,7 @@ for it in range(steps):
         except capi.PcopError as e:
             okn = False
             print("ERROR (node chain)", e, flush=True)
+        check_clean(it, "node chain")
         if not okn:
             fails += 1
             print("NODE CHAIN MISMATCH step", it, cfg, n, p, mk, use_plane, flush=True)
