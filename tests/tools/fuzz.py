@@ -71,6 +71,7 @@ def check_clean(it, tag):
             dirty_seen.add(name)
             dirty[0] += 1
             print("DIRTY after case %d %s: %s has %d entries off (first at %d, last at %d)" % (it, tag, name, len(bad), bad[0], bad[-1]), flush=True)
+            sys.exit(2)   # (a later frame would read cells without points: stop here)
 t0 = time.time()
 fails = 0
 for it in range(cases):

@@ -52,6 +52,7 @@ def check_clean(it, tag, slots=(0,)):
             if len(bad) and nm not in dirty:
                 dirty.add(nm); fails += 1
                 print("DIRTY after step %d %s: %s has %d entries off (first at %d, last at %d)" % (it, tag, nm, len(bad), bad[0], bad[-1]), flush=True)
+                sys.exit(2)   # (a later frame would read cells without points: stop here)
 
 
 t0 = time.time()
