@@ -265,6 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
         const uint4 ma = slot_meta[c];   // {first record, points, priority, grid position}
+        if (ma.y == 0u) continue;        // (a flagged cell no point of this frame lies in has no position either: never followed)
         // rows: (dy,dz) = (-1,-1) (0,-1) (1,-1) (-1,0) with dx = -1..1, and the cell's own row with dx = -1
         uint2 e0[5];
         uint32_t e1[5], sh[5], wd[5];
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames, uin
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
         const uint4 ma = slot_meta[c];
+        if (ma.y == 0u) continue;        // (as in k_cgrid_hook)
         const uint32_t pa = ld_agent(parent + c);
         // round 1: the windows of all rows.  Every load is issued before any is used and none sits under a
         // branch (the second word of a window is fetched whether it is needed or not).
