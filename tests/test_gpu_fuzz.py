@@ -29,3 +29,14 @@ def test_campaign_segment_that_left_occupancy_flags_behind():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "mismatches 0" in out.stdout and "DIRTY" not in out.stdout
+
+
+@pytest.mark.parametrize("env", [{}, {"PCOP_VOXEL_TILED": "1"}], ids=["default", "tiled"])
+def test_batches_campaign(env):
+    """tests/tools/fuzz_batches.py: batches of two to five unlike frames on one long-lived context, parameters changing now and
+    then, frames outside the context's box, NaN holes, empty frames; flags and cell tables of every slot checked after every batch."""
+    e = dict(os.environ, FUZZ_CHECK_CLEAN="1", **env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_batches.py"), "80", "7"], env=e,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "mismatches 0" in out.stdout and "DIRTY" not in out.stdout
