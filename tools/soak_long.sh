@@ -1,5 +1,5 @@
 # The long campaign: thousands of fuzz cases and many hundred stateful steps, summary lines to gpurun_out/soak_long.txt
-# usage: tools/soak_long.sh [first fuzz seed] [first stateful seed]
+# usage: tools/soak_long.sh [first fuzz seed] [first stateful seed]   (about 17 minutes; the batch fuzzer has its own script, tools/soak_batches.sh, about 15)
 set -e
 mkdir -p gpurun_out
 export FUZZ_CHECK_CLEAN=1   # after every call: occupancy flags zero, cell table empty
@@ -17,10 +17,4 @@ PCOP_VOXEL_PATH=auto timeout -k 10 420 python tests/tools/fuzz_stateful.py 600 $
 echo "fuzz_stateful.py 600 steps seed $((S0+2)) (default path choice): $(tail -1 gpurun_out/soak_long_stateful_$((S0+2)).log)" >> gpurun_out/soak_long.txt
 PCOP_CELL_PATH=hash timeout -k 10 420 python tests/tools/fuzz_stateful.py 300 $((S0+3)) > gpurun_out/soak_long_stateful_$((S0+3)).log 2>&1 || echo "stateful seed $((S0+3)): exit $?" >> gpurun_out/soak_long.txt
 echo "fuzz_stateful.py 300 steps seed $((S0+3)) (PCOP_CELL_PATH=hash): $(tail -1 gpurun_out/soak_long_stateful_$((S0+3)).log)" >> gpurun_out/soak_long.txt
-for s in $((S0+4)) $((S0+5)); do
-  timeout -k 10 500 python tests/tools/fuzz_batches.py 1200 $s > gpurun_out/soak_long_batches_$s.log 2>&1 || echo "batches seed $s: exit $?" >> gpurun_out/soak_long.txt
-  echo "fuzz_batches.py 1200 steps seed $s: $(tail -1 gpurun_out/soak_long_batches_$s.log)" >> gpurun_out/soak_long.txt
-done
-PCOP_VOXEL_TILED=1 timeout -k 10 500 python tests/tools/fuzz_batches.py 1200 $((S0+6)) > gpurun_out/soak_long_batches_$((S0+6)).log 2>&1 || echo "batches seed $((S0+6)): exit $?" >> gpurun_out/soak_long.txt
-echo "fuzz_batches.py 1200 steps seed $((S0+6)) (PCOP_VOXEL_TILED=1): $(tail -1 gpurun_out/soak_long_batches_$((S0+6)).log)" >> gpurun_out/soak_long.txt
 cat gpurun_out/soak_long.txt
