@@ -1504,7 +1504,7 @@ int pcop_process_pointcloud2(pcop_ctx* c, const uint8_t* data, uint32_t width, u
     const size_t n = (size_t)width * height;
     if (n > c->cap) { c->err = "n exceeds max_points of the context"; return PCOP_ERR_CAPACITY; }
     if (n && !data) return PCOP_ERR_ARG;
-    if (point_step < 4 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step) return PCOP_ERR_ARG;
+    if (point_step < 4 || off_x > point_step - 4 || off_y > point_step - 4 || off_z > point_step - 4) return PCOP_ERR_ARG;   // (written so that an offset near 2^32 cannot wrap past the test)
     if (n && row_step < (size_t)width * point_step) return PCOP_ERR_ARG;
     if ((rc = set_device(c))) return rc;
     Slot& sl = c->slots[0];
