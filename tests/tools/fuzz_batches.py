@@ -95,6 +95,6 @@ for it in range(steps):
         print("MISMATCH step", it, p, [len(c) for c in clouds], dense, flush=True)
     if it % 20 == 19:
         print("  ... %d steps, %d mismatches, %.0f s, replans %d" % (it + 1, fails, time.time() - t0, ctx.debug_counter("replans")), flush=True)
-print("steps %d, mismatches %d, replans %d, %.1f s" % (steps, fails, ctx.debug_counter("replans"), time.time() - t0))
+print("steps %d, mismatches %d, replans %d, re-runs after a bounded wait %d, %.1f s" % (steps, fails, ctx.debug_counter("replans"), ctx.debug_counter("internal_retries"), time.time() - t0))
 ctx.close()
 sys.exit(1 if fails else 0)
