@@ -133,6 +133,7 @@ struct pcop_ctx {
     bool sbox_batch = false;                 // the batch in flight runs the streaming path on the box
     bool vt_skip = false;                    // the batch in flight was refused: its re-run takes the streaming path
     bool stream_checked = false, stream_chk = false;   // the streaming path's partition was verified once against the peer-mask ranks / this batch does it
+    uint32_t bin_tile_forced = 0;            // PCOP_BIN_TILE=4096|8192|16384|32768 (a multiple of the partition's chunk; the tile tables count in 16 bits)
     bool debug_sync = false;                 // PCOP_DEBUG_SYNC=1: see mark()
     bool debug_order_mismatch = false;       // PCOP_DEBUG_ORDER_MISMATCH=1: that check fails once
     bool vt_checked = false;                 // the first tiled batch ran the build that verifies the order of every tile
@@ -255,7 +256,14 @@ uint32_t hash_cap_for(uint32_t n) {
 
 // Points per tile of the streaming voxel path: large tiles keep the per-tile tables small, small ones give a single
 // frame (or a small batch) enough blocks to fill the chip.  Any value gives the same result.
-uint32_t tile_for(uint32_t nb, uint32_t nf) { return (uint64_t)nf * div_up(nb, kBinTile) >= 256u ? kBinTile : kBinTileSmall; }
+uint32_t tile_for(const pcop_ctx* c, uint32_t nb, uint32_t nf) {
+    if (c->bin_tile_forced) return c->bin_tile_forced;   // (PCOP_BIN_TILE, a tuning knob: points per block of the histogram / partition passes)
+    // the largest tile that still gives every CU a block: fewer tiles are fewer rows of the tile tables and fewer bucket
+    // cursors to set up (measured on C3, 16 frames: 2^15 against 2^14 points a tile: k_bin_scatter 108-112 against 116-117 us,
+    // k_bin_hist 56 against 60-62 us, the bench line + 1-2 %)
+    if ((uint64_t)nf * div_up(nb, kBinTileLarge) >= 256u) return kBinTileLarge;
+    return (uint64_t)nf * div_up(nb, kBinTile) >= 256u ? kBinTile : kBinTileSmall;
+}
 
 bool grid_on(const pcop_ctx* c) { return c->cell_grid && c->cgrid_ok && !c->crowded_cells && c->kind != kFrameVoxelOnly; }
 // The streaming voxel path wins by its traffic when frames share launches; a single frame is bound by launch count and
@@ -372,7 +380,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             mark(c, "k_voxel_setup");
         }
         if (stream) {
-            const uint32_t tile = tile_for(nb, nf);
+            const uint32_t tile = tile_for(c, nb, nf);
             const dim3 bt(std::max(1u, div_up(nb, tile)), nf);       // tiles of the coarse histogram and of the partition
             const size_t bins = (size_t)1 << c->gbits;
             k_bin_hist<<<bt, kBinThreads, bins * 4u, s>>>(fr);
@@ -537,7 +545,7 @@ uint32_t fill_frame_args(pcop_ctx* c) {
     }
     c->frame_npass_csr = c->npass_csr;
     const uint32_t nb = bucket_of(c, nmax);
-    for (uint32_t f = 0; f < c->nframes; ++f) c->slots[f].h_args->tile = c->vt_batch ? kBinTile : tile_for(nb, c->nframes);
+    for (uint32_t f = 0; f < c->nframes; ++f) c->slots[f].h_args->tile = c->vt_batch ? kBinTile : tile_for(c, nb, c->nframes);
     return nb;
 }
 
@@ -553,7 +561,7 @@ int enqueue_batch(pcop_ctx* c) {
         HIPCHK(c, hipGetLastError());
     } else {
         const bool st_on = stream_on(c);
-        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr | ((c->csr_onepass && c->csr_small) ? 0x100u : 0u), c->nframes, st_on ? tile_for(nb, c->nframes) : 0u, st_on ? (c->heavy_ok ? 2u : 1u) : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
+        const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr | ((c->csr_onepass && c->csr_small) ? 0x100u : 0u), c->nframes, st_on ? tile_for(c, nb, c->nframes) : 0u, st_on ? (c->heavy_ok ? 2u : 1u) : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
                            grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u, (c->vt_batch ? (c->vt_checked ? 1u : 2u) : (c->sbox_batch ? 3u : 0u)) | (c->stream_chk ? 16u : 0u)};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
@@ -1288,6 +1296,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_VOXEL_BOX")) c->sbox_enabled = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_SPIN0")) c->debug_spin0 = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_PLANE_MISMATCH")) c->debug_plane_mismatch = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_BIN_TILE")) { const uint32_t v = (uint32_t)atoi(e); if (v == 4096u || v == 8192u || v == 16384u || v == 32768u) c->bin_tile_forced = v; }
     if (const char* e = getenv("PCOP_DEBUG_SYNC")) { c->debug_sync = atoi(e) != 0; if (c->debug_sync) c->use_graph = false; }
     if (const char* e = getenv("PCOP_DEBUG_ORDER_MISMATCH")) c->debug_order_mismatch = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VT_CAP")) c->vt_plan_cap = (uint32_t)std::max(64, atoi(e));

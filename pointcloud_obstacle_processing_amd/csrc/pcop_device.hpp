@@ -69,6 +69,7 @@ constexpr uint32_t kVmapTile = 1024;            // occupancy words per block of 
 // streaming voxel path
 constexpr uint32_t kBinTile = 16384;            // points per block of k_bin_hist / k_bin_scatter: kBinTileSmall when that fills the chip better
 constexpr uint32_t kBinTileSmall = 4096;
+constexpr uint32_t kBinTileLarge = 32768;       // (the tile tables count in 16 bits: no tile above 2^15 points)
 constexpr uint32_t kBinThreads = 1024;          // threads of k_bin_hist / k_bin_plan
 constexpr uint32_t kBinBitsMin = 11, kBinBitsMax = 14;   // coarse key bins per frame: 2^11 .. 2^14 (a host hint; any value gives the same result)
 constexpr uint32_t kBucketCap = 2048;           // points per bucket (k_bucket_reduce: 256 threads x 8 records, all in LDS)

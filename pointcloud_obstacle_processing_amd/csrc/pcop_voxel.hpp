@@ -779,7 +779,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     if (bad) atomicOr(&st->err, (uint32_t)kErrInternal);   // a key beyond the grid: never (the keys are those PCL computes)
     __syncthreads();
     uint16_t* __restrict__ row = ctab + (size_t)blockIdx.x * G;
-    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has at most 16384 points: fits
+    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has at most 2^15 points (kBinTileLarge): fits
 }
 
 // Bin totals over the tiles: a block takes 64 bins (a wave reads 128 contiguous bytes of a row), its four waves

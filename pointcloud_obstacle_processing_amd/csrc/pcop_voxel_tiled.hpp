@@ -238,7 +238,7 @@ __device__ __forceinline__ void bin_hist_on_box(Frame& F, uint32_t* s_hist, uint
         if (ok && (mx[0] >= key.d0 || mx[1] >= key.d1 || mx[2] >= key.d2)) atomicOr(&st->err, (uint32_t)kErrReplanBox);   // a point outside the box
     }
     uint16_t* __restrict__ row = ctab + (size_t)blockIdx.x * G;
-    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has at most 16384 points: fits
+    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has at most 2^15 points (kBinTileLarge): fits
 }
 
 // Which of the kVtSampleRows rows of group g is the sampled one (a hash, so that no period of the input lines up with it).

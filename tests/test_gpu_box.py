@@ -182,6 +182,25 @@ def test_streamed_partition_checks_its_own_order_once(capi, oracle, monkeypatch)
     c.close()
 
 
+@pytest.mark.parametrize("tile", ["4096", "8192", "32768"])
+def test_any_tile_size_same_result(capi, oracle, monkeypatch, tile):
+    """Points per block of the histogram / partition passes (the host picks the largest that still fills the chip: 2^15 on the
+    benchmark's batches): a launch parameter, not part of the result.  Ragged sizes, NaN holes, with and without the box."""
+    monkeypatch.setenv("PCOP_BIN_TILE", tile)
+    p = synth.params_of("C3")
+    clouds = [synth.make_cloud("C3", n=150_000, seed=490), synth.make_cloud("C3", n=98_305, seed=491), synth.make_cloud("C3", n=32_769, seed=492)]
+    clouds[1][::77] = np.nan
+    refs = [oracle.process_xyz(c, is_dense=False, **p) for c in clouds]
+    c = capi.Context(150_000, max_frames=3)
+    c.set_params(publish_clouds=1, **p)
+    seen = []
+    for _ in range(3):
+        st = run(c, clouds, refs, is_dense=False)
+        seen.append((int(st.sbox), int(st.tile)))
+    assert seen == [(0, int(tile)), (1, int(tile)), (1, int(tile))], seen
+    c.close()
+
+
 def test_box_path_single_frames_on_the_sort_path(capi, oracle):
     """One frame at a time (the node's own mode): the sort path; from the second frame on its pass-0 histogram takes the
     bounds (no k_minmax).  The frame API, the stage API (voxel grid alone), NaN holes, a point outside the box."""
