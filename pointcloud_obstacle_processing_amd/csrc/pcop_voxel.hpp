@@ -581,7 +581,10 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 // publishes its own count (plus one) as soon as it knows it and reads the counts of the lower tiles
 // after its sums are done; a lower tile never waits for a higher one and blocks are dispatched in
 // index order, so the lower tiles are always running or finished (the wait is bounded anyway).
-constexpr uint32_t kReduceBucketsPerBlock = 2u;   // k_bucket_reduce: consecutive buckets per block
+#ifndef PCOP_REDUCE_BPB
+#define PCOP_REDUCE_BPB 2
+#endif
+constexpr uint32_t kReduceBucketsPerBlock = PCOP_REDUCE_BPB;   // k_bucket_reduce: consecutive buckets per block (2: measured against 1, 3 and 4, tools/ab_build.sh)
 
 // mark_cells: a chain frame on the dense cell grid (set up by k_voxel_setup): every centroid marks its grid cell as it is
 // written, so the cell stage has no k_cell_mark launch (k_voxel_gather does the same on the streaming path).
