@@ -72,6 +72,7 @@ def parse_args():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and the parity check that uses its results)")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 (uniform-random) leg")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry", action="store_true", help="no GPU work: the launcher, the rendezvous, the parameter broadcast and the frame sharding only")
@@ -93,8 +94,8 @@ def launch_workers(args):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--worker"] + ["--worker"]
-        # (rank 0's stdout carries the JSON line; the other ranks' stdout is dropped, every rank's stderr goes to ours)
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        # (rank 0's stdout carries the JSON line; whatever another rank prints on stdout joins every rank's stderr on ours)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
     out0, _ = procs[0].communicate()
     rc = procs[0].returncode
     for p in procs[1:]:
@@ -120,6 +121,52 @@ def latest_pmc_traffic():
         if mt and (best is None or int(mt.group(1)) > best[0]):
             best = (int(mt.group(1)), f)
     return best[1] if best else None
+
+
+def pmc_traffic_of(kernel, batch):
+    """HBM bytes per launch of `kernel` from the newest tracked PMC passes.  A kernel may have several template instances in the
+    file (the once-per-context order self-check launches `k_bin_scatter<2u, false>`): the one a steady batch launches is the one
+    with the most launches (`launches`; older files without the field: the one that moves the most bytes)."""
+    f = latest_pmc_traffic()
+    if not f:
+        return None, None
+    try:
+        best = None
+        for k, v in json.load(open(f)).items():
+            if k.split("::")[-1].split("<")[0].split("(")[0] != kernel or v.get("batch") != batch:
+                continue
+            rank = (v.get("launches", 0), v["hbm_bytes_per_launch"])
+            if best is None or rank > best[0]:
+                best = (rank, k, v["hbm_bytes_per_launch"])
+        if best:
+            return best[2], "profiles/%s, instance %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)" % (os.path.basename(f), best[1])
+    except Exception:
+        pass
+    return None, None
+
+
+def tracked_launch_us(kernel, batch, solo):
+    """Average launch duration of `kernel` in the newest tracked rocprofv3 kernel-trace summary (profiles/rNN_kernel_summary_batchB[_solo].txt)."""
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_summary_batch%d%s.txt" % (batch, "_solo" if solo else ""))):
+        mt = re.match(r"r(\d+)_", os.path.basename(f))
+        if mt and (best is None or int(mt.group(1)) > best[0]):
+            best = (int(mt.group(1)), f)
+    if not best:
+        return None, None
+    try:
+        for ln in open(best[1]):
+            mt = re.match(r"(?:void )?pcop::(\w+)\S*.*?\s+([0-9.]+)\s+\d+\s+[0-9.]+\s*$", ln)
+            if mt and mt.group(1) == kernel:
+                return float(mt.group(2)), "profiles/" + os.path.basename(best[1])
+    except Exception:
+        pass
+    return None, None
+
+
+def same_result(got, ref, np):
+    return (got["voxel_xyz"] is not None and got["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes()
+            and np.array_equal(got["offsets"], ref["offsets"]) and np.array_equal(got["indices"], ref["indices"]))
 
 
 def worker(args):
@@ -239,23 +286,34 @@ def worker(args):
     fps = frames / dt
     m_vox = last["num_voxels"]
 
-    # N > 1: every rank compares its first frame with the CPU restatement (outside the timed region) and the flags are
-    # reduced, so that a scaling line never stands for results nobody looked at
+    # ---- parity of the configuration that was timed: one more (untimed) round of context 0 with the voxel cloud published, the
+    #      same device-resident batch through the same launch sequence (keys on the context's box, streaming voxel path, the tile
+    #      size of the timed run), frames 0 and 1 (N > 1: frame 0 of every rank) against the CPU restatement ----
+    def timed_path_parity(nframes, refs=None):
+        from oracle import oracle as O
+        c0 = ctxs[0]
+        pub = capi.Params(params.leaf, params.tol, params.min_cluster, params.max_cluster, 1)
+        c0.set_params_struct(pub)
+        c0.submit_batch_device(*ptrs[0])
+        got = c0.wait_batch(want_arrays=True)
+        st = c0.debug_state()
+        c0.set_params_struct(params)
+        bad = []
+        for i in range(min(nframes, len(got))):
+            ref = refs[i] if refs and i < len(refs) else O.process_xyz(synth.make_cloud(args.config, seed=seeds[i]), **p)
+            if not same_result(got[i], ref, np):
+                bad.append(seeds[i])
+        return bad, {"voxel_path": "stream" if st.vpath else "sort", "keys_on_context_box": bool(st.sbox), "tile_points": int(st.tile),
+                     "frames_per_launch": len(got), "buckets_frame0": int(st.nbuckets)}
+
     parity_all = None
     if use_dist and on_gpu and not args.no_cpu_baseline:
         from oracle import oracle as O
         if rank == 0:
             O.build()
         dist.barrier()
-        cloud0 = synth.make_cloud(args.config, seed=seeds[0])
-        ref0 = O.process_xyz(cloud0, **p)
-        chk = capi.Context(n_pts, device=local_rank)
-        chk.set_params(leaf=p["leaf"], tol=p["tol"], min_cluster=p["min_cluster"], max_cluster=p["max_cluster"], publish_clouds=1)
-        got0 = chk.process_xyz(cloud0)
-        chk.close()
-        same0 = (got0["voxel_xyz"] is not None and got0["voxel_xyz"].tobytes() == ref0["voxel_xyz"].tobytes()
-                 and np.array_equal(got0["offsets"], ref0["offsets"]) and np.array_equal(got0["indices"], ref0["indices"]))
-        t = torch.tensor([1 if same0 else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        bad0, _ = timed_path_parity(1)
+        t = torch.tensor([0 if bad0 else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         parity_all = bool(int(t.item()))
 
@@ -320,18 +378,13 @@ def worker(args):
             ms, nbytes, gbs = roof(nm)
             by_kernel.append({"kernel": nm, "launches_per_batch": len(by_name[nm]), "avg_launch_ms": round(ms, 5),
                               "own_alg_bytes_per_launch": nbytes, "own_achieved_GBs": round(gbs, 1), "own_frac": round(gbs / HBM_PEAK_GBS, 4)})
-        # HBM bytes per launch of the dominant kernel: from the newest committed PMC passes of this command (a separate
+        # HBM bytes per launch of the dominant kernel: from the newest tracked PMC passes of this command (a separate
         # rocprofv3 run: counters cannot be collected inside this process), when they were taken at this batch size
-        traffic, traffic_source = None, None
-        f = latest_pmc_traffic()
-        if f:
-            try:
-                for k, v in json.load(open(f)).items():
-                    if k.split("::")[-1].split("<")[0].split("(")[0] == dom and v.get("batch") == B:
-                        traffic = v["hbm_bytes_per_launch"]
-                        traffic_source = "profiles/" + os.path.basename(f) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic_of(dom, B)
+        # the same kernel's launch duration in the tracked rocprofv3 kernel traces: one context alone, and the three contexts of
+        # the timed run sharing the GPU
+        solo_us, solo_src = tracked_launch_us(dom, B, solo=True)
+        shared_us, shared_src = tracked_launch_us(dom, B, solo=False)
 
         result = {
             "metric": "frames/sec at 1M-pt cloud, 1/2/4/8 MI355X; HBM GB/s vs roofline",
@@ -354,7 +407,15 @@ def worker(args):
                          "alg_bytes_per_frame": frame_bytes, "alg_bytes_per_launch": frame_bytes * B, "frames_per_launch": B,
                          "avg_launch_ms": dom_ms, "duration_source": "HIP events, one context alone on the GPU",
                          "kernel_own_alg_bytes_per_launch": dom_own_bytes, "kernel_own_achieved": own_achieved, "kernel_own_frac": own_achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "peak_measured_copy": 6290.0},
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_over_alg": (traffic / (frame_bytes * B)) if traffic else None,
+                         "traffic_over_kernel_own_alg": (traffic / dom_own_bytes) if traffic and dom_own_bytes else None,
+                         # the same ratio with the launch duration rocprofv3 recorded (tracked files, reproducible from profiles/)
+                         "frac_solo_tracked": (frame_bytes * B / (solo_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if solo_us else None,
+                         "avg_launch_us_solo_tracked": solo_us, "solo_tracked_source": solo_src,
+                         "frac_shared": (frame_bytes * B / (shared_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if shared_us else None,
+                         "avg_launch_us_shared_tracked": shared_us, "shared_tracked_source": shared_src,
+                         "peak_measured_copy": 6290.0},
             "roofline_by_kernel": by_kernel,
             "frame_roofline": {"alg_bytes_per_frame": frame_bytes,
                                "achieved_GBs_pipelined": frame_bytes * fps / world / 1e9,
@@ -396,6 +457,68 @@ def worker(args):
                                     "input": "XYZ SoA in pinned host memory; the H2D copy of 12 MB per frame is inside the timed region",
                                     "pcie_GBs": efps * 12.0 * n0 / 1e9}
 
+        # ---- secondary leg (north star: "uniform-random + planar-ground clouds"): C2, 100 k uniform points, leaf 0.05 / tol 0.2, the same
+        #      contexts x batch, device-resident, its own short timed region; never part of `value` ----
+        if not args.no_secondary and world == 1:
+            p2 = synth.params_of("C2")
+            par2 = capi.Params(np.float32(p2["leaf"]), np.float32(p2["tol"]), p2["min_cluster"], p2["max_cluster"], 0)
+            n2 = synth.CONFIGS["C2"]["n"]
+            seeds2 = [7000 + i for i in range(F)]
+            c2, ptr2 = [], []
+            for ci in range(NC):
+                c = capi.Context(n2, device=local_rank, max_frames=B)
+                c.set_params_struct(par2)
+                mine = [c.upload_soa(synth.make_cloud("C2", seed=sd)) for sd in seeds2[ci * B:(ci + 1) * B]]
+                c2.append(c)
+                ptr2.append(([q for q, _ in mine], [n for _, n in mine]))
+            pend2 = [False] * NC
+
+            def round2():
+                for ci, c in enumerate(c2):
+                    if pend2[ci]:
+                        c.wait_batch(want_arrays=False)
+                    c.submit_batch_device(*ptr2[ci])
+                    pend2[ci] = True
+
+            def drain2():
+                for ci, c in enumerate(c2):
+                    if pend2[ci]:
+                        c.wait_batch(want_arrays=False)
+                        pend2[ci] = False
+
+            for _ in range(20):
+                round2()
+            drain2()
+            torch.cuda.synchronize()
+            r2 = 200
+            t1 = time.perf_counter()
+            for _ in range(r2):
+                round2()
+            drain2()
+            torch.cuda.synchronize()
+            sdt = time.perf_counter() - t1
+            sec = {"workload": "C2: %d-pt uniform-random cloud in the field box, leaf %g m, tol %g m, clusters %d..%d" % (n2, p2["leaf"], p2["tol"], p2["min_cluster"], p2["max_cluster"]),
+                   "value": r2 * F / sdt, "unit": "frames/s", "frames": r2 * F, "timed_region_s": sdt, "contexts_per_gpu": NC, "batch_per_launch": B,
+                   "input": "XYZ SoA resident in HBM"}
+            if not args.no_cpu_baseline:   # parity of this leg's timed configuration: frame 0 of context 0's batch
+                from oracle import oracle as O
+                O.build()
+                c2[0].set_params_struct(capi.Params(par2.leaf, par2.tol, par2.min_cluster, par2.max_cluster, 1))
+                c2[0].submit_batch_device(*ptr2[0])
+                got2 = c2[0].wait_batch(want_arrays=True)
+                ref2 = O.process_xyz(synth.make_cloud("C2", seed=seeds2[0]), **p2)
+                ok2 = same_result(got2[0], ref2, np)
+                sec["parity"] = "bit-exact vs the CPU restatement on frame 0 of the timed batch" if ok2 else "MISMATCH"
+                sec["voxels_per_frame"] = int(got2[0]["num_voxels"])
+                sec["clusters_kept"] = int(len(got2[0]["offsets"]) - 1)
+                sec["alg_bytes_per_frame"] = 12 * n2 + 28 * sec["voxels_per_frame"]
+                sec["frac_pipelined"] = sec["alg_bytes_per_frame"] * sec["value"] / 1e9 / HBM_PEAK_GBS
+                if not ok2:
+                    rc = 1
+            for c in c2:
+                c.close()
+            result["secondary"] = sec
+
         # ---- CPU baseline: the oracle (a restatement of the PCL path, not PCL) on this box's host cores; its results for the
         #      first frames are then compared with what the GPU gives for the same clouds (outside every timed region) ----
         if not args.no_cpu_baseline and world == 1:
@@ -415,15 +538,12 @@ def worker(args):
                                       "sample": "%d frames of %s (%d pts) through oracle/pcl_restatement.cpp "
                                                 "(kd-tree built twice, sorted radius search, serial BFS), 1 thread, "
                                                 "host has %d cores" % (done, args.config, n0, os.cpu_count())}
+            # (a) the timed configuration itself (batched, device-resident, keys on the context's box)
+            bad, how = timed_path_parity(2, refs)
+            # (b) the single-frame entry point on a fresh context (the sort voxel path, with its bounds pass)
             chk = capi.Context(n_pts, device=local_rank)
             chk.set_params(leaf=p["leaf"], tol=p["tol"], min_cluster=p["min_cluster"], max_cluster=p["max_cluster"], publish_clouds=1)
-            bad = []
-            for i, ref in enumerate(refs):
-                got = chk.process_xyz(clouds[i])
-                same = (got["voxel_xyz"] is not None and got["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes()
-                        and np.array_equal(got["offsets"], ref["offsets"]) and np.array_equal(got["indices"], ref["indices"]))
-                if not same:
-                    bad.append(seeds[i])
+            bad1 = [seeds[i] for i, ref in enumerate(refs) if not same_result(chk.process_xyz(clouds[i]), ref, np)]
             chk.close()
             # SURVEY 8(d), secondary work figure of the neighbour pass: 2 E directed pair tests a frame (E = pairs within the
             # tolerance among the frame's voxel centroids; counted here with SciPy's cKDTree on the oracle's cloud, outside every timed region)
@@ -436,14 +556,19 @@ def worker(args):
                                         "pair_tests_per_s": 2.0 * e_pairs * fps / world, "counted_on": "seed %d, cKDTree.count_neighbors (d <= tol in float64)" % seeds[0]}
             except Exception as ex:   # (SciPy missing: the figure is left out, nothing else depends on it)
                 result["pair_tests"] = {"error": str(ex)}
-            result["parity_checked"] = len(refs)
-            result["parity"] = "bit-exact vs the CPU restatement (centroids, cluster offsets, indices)" if not bad else "MISMATCH on seeds %s" % bad
-            if bad:
+            result["parity_checked"] = 2
+            result["parity"] = ("bit-exact vs the CPU restatement (centroids, cluster offsets, indices) on frames 0 and 1 of the TIMED configuration: "
+                                "context 0's batch of %d device-resident frames, %s voxel path, keys on the context's box: %s, %d points per tile"
+                                % (how["frames_per_launch"], how["voxel_path"], how["keys_on_context_box"], how["tile_points"])) if not bad else "MISMATCH on seeds %s (timed configuration)" % bad
+            result["parity_timed_path"] = how
+            result["parity_single_frame_checked"] = len(refs)
+            result["parity_single_frame"] = "bit-exact vs the CPU restatement (fresh single-frame context, sort voxel path)" if not bad1 else "MISMATCH on seeds %s" % bad1
+            if bad or bad1:
                 rc = 1
 
     if rank == 0 and parity_all is not None:
         result["parity_checked"] = world
-        result["parity"] = ("bit-exact vs the CPU restatement on every rank's first frame (centroids, cluster offsets, indices)" if parity_all
+        result["parity"] = ("bit-exact vs the CPU restatement on frame 0 of every rank's TIMED configuration (batched, device-resident, keys on the context's box)" if parity_all
                             else "MISMATCH on some rank's first frame")
         if not parity_all:
             rc = 1

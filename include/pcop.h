@@ -281,8 +281,10 @@ int pcop_process_node(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int
  *                         planar_cloud.swap(cloud_f) (od.cpp:389-392), so this - not what is left - is what
  *                         filtered_cloud_publisher sends (od.cpp:419-426)
  * Every buffer may be NULL; one that is not receives 16-byte records {x, y, z, 1.0f} (pcl::PointXYZ, what pcl::toROSMsg lays
- * out) and needs room for n points; n_* report the point counts (a cloud the call did not produce: -1; with no plane removed,
- * indices_cloud and cloud_f are -1: the reference leaves the caller's clouds as they were). */
+ * out) and needs room for n points; n_* report the point counts (a cloud the call did not produce - its step was not asked
+ * for - : -1).  When the plane removal was asked for and no plane went (the first fit found no inliers, or the cloud was empty),
+ * indices_cloud and cloud_f both carry the cloud the plane stage was given: cloud_cb initialises indices_cloud_y and
+ * filtered_cloud_y as copies of the outlier removal's output (od.cpp:774-775) and publishes them whatever happened (od.cpp:410-426). */
 typedef struct pcop_node_clouds {
     float* voxel_grid;           int32_t n_voxel_grid;
     float* statistical_outliers; int32_t n_statistical_outliers;
@@ -291,6 +293,17 @@ typedef struct pcop_node_clouds {
     float* cloud_f;              int32_t n_cloud_f;
 } pcop_node_clouds;
 int pcop_process_node_clouds(pcop_ctx* ctx, const float* xyz, int layout, size_t n, int is_dense, int mem,
+                      const pcop_occ_params* occ, int64_t* counts, int64_t* row_avg, int8_t* grid,
+                      int mean_k, float stddev_mul, const pcop_plane_params* plane, pcop_result* out, pcop_node_stats* stats, pcop_node_clouds* clouds);
+
+/* The same call fed with the sensor_msgs/PointCloud2 blob itself (replaces pcl_conversions::toPCL + pcl::fromPCLPointCloud2,
+ * od.cpp:688-689, in front of the node's chain): the bytes go to the GPU as they are and k_unpack_points picks x / y / z by
+ * field offset there - any point_step, row padding, big-endian floats - so a caller has no per-point loop of its own.  The
+ * message geometry is checked before anything is read (PCOP_ERR_ARG: a field offset beyond point_step - 4, row_step below
+ * width * point_step; PCOP_ERR_CAPACITY: width * height above the context's max_points); `data` must hold
+ * height * row_step bytes (the caller checks its vector's size: the ABI sees a pointer). */
+int pcop_process_node_pointcloud2(pcop_ctx* ctx, const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step,
+                      uint32_t row_step, uint32_t off_x, uint32_t off_y, uint32_t off_z, int is_bigendian, int is_dense,
                       const pcop_occ_params* occ, int64_t* counts, int64_t* row_avg, int8_t* grid,
                       int mean_k, float stddev_mul, const pcop_plane_params* plane, pcop_result* out, pcop_node_stats* stats, pcop_node_clouds* clouds);
 

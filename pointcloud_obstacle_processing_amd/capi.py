@@ -20,7 +20,7 @@ EXPORTS = [
     "pcop_set_profiling", "pcop_get_stage_times", "pcop_stream", "pcop_voxel_downsample", "pcop_euclidean_clusters",
     "pcop_process_pointcloud2", "pcop_process_xyz", "pcop_submit_xyz", "pcop_wait", "pcop_cluster_summaries",
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
-    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_process_node_clouds", "pcop_segment_planes", "pcop_segment_planes_clouds", "pcop_debug_buffer", "pcop_debug_counter", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
+    "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_process_node_clouds", "pcop_process_node_pointcloud2", "pcop_segment_planes", "pcop_segment_planes_clouds", "pcop_debug_buffer", "pcop_debug_counter", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
     "pcop_cluster_summaries_frame", "pcop_occupancy_grid_dims", "pcop_occupancy_filter", "pcop_process_filtered",
     "pcop_statistical_outlier_removal",
 ]
@@ -54,6 +54,13 @@ class NodeStats(C.Structure):
     _fields_ = [("n_in", C.c_int32), ("n_filtered", C.c_int32), ("index_errors", C.c_int32), ("n_voxels", C.c_int32),
                 ("n_inliers", C.c_int32), ("n_planes", C.c_int32), ("n_clustered", C.c_int32), ("planes_found_all", C.c_int32),
                 ("threshold", C.c_double)]
+
+
+class NodeClouds(C.Structure):
+    """pcop_node_clouds: the clouds of the topics between the steps of the node's chain (caller's buffers + counts)."""
+    _fields_ = [("voxel_grid", C.c_void_p), ("n_voxel_grid", C.c_int32), ("statistical_outliers", C.c_void_p), ("n_statistical_outliers", C.c_int32),
+                ("planar_cloud", C.c_void_p), ("n_planar_cloud", C.c_int32), ("indices_cloud", C.c_void_p), ("n_indices_cloud", C.c_int32),
+                ("cloud_f", C.c_void_p), ("n_cloud_f", C.c_int32)]
 
 
 class PlaneParams(C.Structure):
@@ -126,6 +133,13 @@ def load_library():
     L.pcop_process_node.restype = C.c_int
     L.pcop_process_node.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.POINTER(Result), C.POINTER(NodeStats)]
+    L.pcop_process_node_clouds.restype = C.c_int
+    L.pcop_process_node_clouds.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.POINTER(Result), C.POINTER(NodeStats), C.c_void_p]
+    L.pcop_process_node_pointcloud2.restype = C.c_int
+    L.pcop_process_node_pointcloud2.argtypes = [vp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                                C.POINTER(Result), C.POINTER(NodeStats), C.c_void_p]
     L.pcop_segment_planes_clouds.restype = C.c_int
     L.pcop_segment_planes_clouds.argtypes = [vp, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(PlaneParams), C.c_void_p, C.POINTER(C.c_size_t),
                                              C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_int32, ip, ip, C.c_void_p]
@@ -388,6 +402,33 @@ class Context:
         if counts is not None:
             out.update(counts=counts[:occ.grid_width * occ.grid_height], row_avg=row_avg[:occ.grid_height],
                        grid=grid[:occ.grid_width * occ.grid_height])
+        return out
+
+    def process_node_pointcloud2(self, data, width, height, point_step, row_step, off_x, off_y, off_z, is_bigendian=False, is_dense=True,
+                                 occ=None, mean_k=0, stddev_mul=1.0, plane=None, want_clouds=False):
+        """The node's chain fed with the PointCloud2 blob itself (pcop_process_node_pointcloud2).  want_clouds: also the five clouds the
+        node publishes between the steps, each as (k, 4) float32 records or None."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        n = int(width) * int(height)
+        r, st = Result(), NodeStats()
+        cl, bufs = None, None
+        if want_clouds:
+            cl = NodeClouds()
+            bufs = [np.zeros(4 * max(n, 1), dtype=np.float32) for _ in range(5)]
+            cl.voxel_grid, cl.statistical_outliers, cl.planar_cloud, cl.indices_cloud, cl.cloud_f = [b.ctypes.data for b in bufs]
+        self._chk(self.lib.pcop_process_node_pointcloud2(self.h, buf.ctypes.data, width, height, point_step, row_step, off_x, off_y, off_z,
+                                                         int(is_bigendian), int(is_dense),
+                                                         C.cast(C.byref(occ), C.c_void_p) if occ is not None else None, None, None, None,
+                                                         int(mean_k), C.c_float(stddev_mul),
+                                                         C.cast(C.byref(plane), C.c_void_p) if plane is not None else None, C.byref(r), C.byref(st),
+                                                         C.cast(C.byref(cl), C.c_void_p) if cl is not None else None))
+        out = self._result(r)
+        out.update(n_filtered=st.n_filtered, index_errors=st.index_errors, n_voxels=st.n_voxels, n_inliers=st.n_inliers,
+                   n_planes=st.n_planes, n_clustered=st.n_clustered, planes_found_all=bool(st.planes_found_all), threshold=st.threshold)
+        if cl is not None:
+            cnt = [cl.n_voxel_grid, cl.n_statistical_outliers, cl.n_planar_cloud, cl.n_indices_cloud, cl.n_cloud_f]
+            names = ["voxel_grid", "statistical_outliers", "planar_cloud", "indices_cloud", "cloud_f"]
+            out["clouds"] = {nm: (b[:4 * k].reshape(k, 4).copy() if k >= 0 else None) for nm, b, k in zip(names, bufs, cnt)}
         return out
 
     def process_filtered(self):

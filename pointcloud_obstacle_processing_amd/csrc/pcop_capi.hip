@@ -135,6 +135,7 @@ struct pcop_ctx {
     bool stream_checked = false, stream_chk = false;   // the streaming path's partition was verified once against the peer-mask ranks / this batch does it
     uint32_t bin_tile_forced = 0;            // PCOP_BIN_TILE=4096|8192|16384|32768 (a multiple of the partition's chunk; the tile tables count in 16 bits)
     bool debug_sync = false;                 // PCOP_DEBUG_SYNC=1: see mark()
+    bool debug_replan = false;               // PCOP_DEBUG_REPLAN=1: every re-plan says on stderr what it was about (read once, when the context is made)
     bool debug_order_mismatch = false;       // PCOP_DEBUG_ORDER_MISMATCH=1: that check fails once
     bool vt_checked = false;                 // the first tiled batch ran the build that verifies the order of every tile
     bool vt_batch = false;                   // the batch in flight runs the tiled path
@@ -692,7 +693,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             // grid up from other bounds.  Flags nobody consumes would sit there until some later frame's grid covers them - cells
             // without points.  So no re-run starts on anything but clean flags.
             scrub_flags(c, c->nframes);
-            if (getenv("PCOP_DEBUG_REPLAN")) {
+            if (c->debug_replan) {
                 fprintf(stderr, "pcop: replan, attempt %d, bits 0x%x, vt %d;", attempt, e, c->vt_batch ? 1 : 0);
                 for (uint32_t f = 0; f < c->nframes; ++f) {
                     const DevState* hs = c->slots[f].h_state;
@@ -810,6 +811,16 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         const DevState* hs = c->slots[f].h_state;
         if (c->kind != kFrameClusterOnly && !hs->passthrough && hs->n_valid) kb_voxel = std::max(kb_voxel, hs->plan_voxel.key_bits);
         if (c->kind != kFrameVoxelOnly && !c->slots[f].result_trivial) kb_csr = std::max(kb_csr, hs->plan_csr.key_bits);
+    }
+    // (a frame keyed on the context's box plans its passes on the BOX's key bits - k_vt_setup sees nothing else - which are at least the
+    //  true grid's and often one more: the pass count never goes below what the box needs, or every single frame after a batch
+    //  would raise kErrReplanVoxel and run twice)
+    if (kb_voxel && c->sbox_enabled && c->box_valid) {
+        uint64_t cells = 1;
+        for (int a = 0; a < 3; ++a) cells *= (uint64_t)((int64_t)c->box_hi[a] - c->box_lo[a] + 1);
+        uint32_t bb = 1;
+        while (bb < 64u && (1ull << bb) < cells) ++bb;
+        if (cells <= (1ull << 30)) kb_voxel = std::max(kb_voxel, bb);
     }
     if (kb_voxel) c->npass_voxel = passes_for(c, kb_voxel);
     if (kb_csr) c->npass_csr = passes_for(c, kb_csr);
@@ -1170,6 +1181,33 @@ int stage_input(pcop_ctx* c, Slot& sl, const float* xyz, int layout, size_t n, i
     return PCOP_OK;
 }
 
+// The same for a sensor_msgs/PointCloud2 blob (the conversion of od.cpp:688-689 on the device): any point_step, row padding, field
+// offsets, endianness.  The message is checked before a byte of it is read: offsets inside a point, rows that hold their points.
+int stage_pointcloud2(pcop_ctx* c, Slot& sl, const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step,
+                      uint32_t off_x, uint32_t off_y, uint32_t off_z, int is_bigendian) {
+    const size_t n = (size_t)width * height;
+    if (n > c->cap) { c->err = "n exceeds max_points of the context"; return PCOP_ERR_CAPACITY; }
+    if (n && !data) return PCOP_ERR_ARG;
+    if (point_step < 4 || off_x > point_step - 4 || off_y > point_step - 4 || off_z > point_step - 4) { c->err = "PointCloud2: a field offset leaves the point"; return PCOP_ERR_ARG; }   // (written so that an offset near 2^32 cannot wrap past the test)
+    if (n && row_step < (size_t)width * point_step) { c->err = "PointCloud2: row_step below width * point_step"; return PCOP_ERR_ARG; }
+    sl.n = (uint32_t)n;
+    sl.src_x = sl.in_x; sl.src_y = sl.in_y; sl.src_z = sl.in_z;
+    if (n) {
+        const size_t row_bytes = (size_t)width * point_step;
+        int rc = ensure_raw(c, sl, n * point_step);
+        if (rc) return rc;
+        if (row_step == row_bytes) {
+            HIPCHK(c, hipMemcpyAsync(sl.d_raw, data, n * point_step, hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIPCHK(c, hipMemcpy2DAsync(sl.d_raw, row_bytes, data, row_step, row_bytes, height, hipMemcpyHostToDevice, c->stream));
+        }
+        k_unpack_points<<<stride_grid((uint32_t)n), kBlock, 0, c->stream>>>(sl.d_raw, (uint32_t)n, point_step, off_x, off_y, off_z,
+                                                                           is_bigendian, sl.in_x, sl.in_y, sl.in_z);
+        HIPCHK(c, hipGetLastError());
+    }
+    return PCOP_OK;
+}
+
 int set_device(pcop_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     return PCOP_OK;
@@ -1299,6 +1337,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_BIN_TILE")) { const uint32_t v = (uint32_t)atoi(e); if (v == 4096u || v == 8192u || v == 16384u || v == 32768u) c->bin_tile_forced = v; }
     if (const char* e = getenv("PCOP_DEBUG_SYNC")) { c->debug_sync = atoi(e) != 0; if (c->debug_sync) c->use_graph = false; }
     if (const char* e = getenv("PCOP_DEBUG_ORDER_MISMATCH")) c->debug_order_mismatch = atoi(e) != 0;
+    if (const char* e = getenv("PCOP_DEBUG_REPLAN")) c->debug_replan = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VT_CAP")) c->vt_plan_cap = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_VT_REDUCE")) c->vt_accum = std::string(e) == "accum";
     if (const char* e = getenv("PCOP_VT_REDUCE_BLOCKS")) c->vt_reduce_blocks = (uint32_t)std::max(16, atoi(e));
@@ -1364,7 +1403,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
         }
     }
     if (rc) { fprintf(stderr, "pcop_create: %s\n", c->err.c_str()); pcop_destroy(c); return rc; }
-    if (getenv("PCOP_DEBUG_REPLAN")) fprintf(stderr, "pcop: context: lds_ordered %d, tiled voxel path %s\n", c->lds_ordered ? 1 : 0, c->vt_enabled ? "on" : "off");
+    if (c->debug_replan) fprintf(stderr, "pcop: context: lds_ordered %d, tiled voxel path %s\n", c->lds_ordered ? 1 : 0, c->vt_enabled ? "on" : "off");
     *out = c;
     return PCOP_OK;
 }
@@ -1510,27 +1549,8 @@ int pcop_process_pointcloud2(pcop_ctx* c, const uint8_t* data, uint32_t width, u
     int rc = busy(c);
     if (rc) return rc;
     if ((rc = check_params(c, true, true))) return rc;
-    const size_t n = (size_t)width * height;
-    if (n > c->cap) { c->err = "n exceeds max_points of the context"; return PCOP_ERR_CAPACITY; }
-    if (n && !data) return PCOP_ERR_ARG;
-    if (point_step < 4 || off_x > point_step - 4 || off_y > point_step - 4 || off_z > point_step - 4) return PCOP_ERR_ARG;   // (written so that an offset near 2^32 cannot wrap past the test)
-    if (n && row_step < (size_t)width * point_step) return PCOP_ERR_ARG;
     if ((rc = set_device(c))) return rc;
-    Slot& sl = c->slots[0];
-    sl.n = (uint32_t)n;
-    sl.src_x = sl.in_x; sl.src_y = sl.in_y; sl.src_z = sl.in_z;
-    if (n) {
-        const size_t row_bytes = (size_t)width * point_step;
-        if ((rc = ensure_raw(c, sl, n * point_step))) return rc;
-        if (row_step == row_bytes) {
-            HIPCHK(c, hipMemcpyAsync(sl.d_raw, data, n * point_step, hipMemcpyHostToDevice, c->stream));
-        } else {
-            HIPCHK(c, hipMemcpy2DAsync(sl.d_raw, row_bytes, data, row_step, row_bytes, height, hipMemcpyHostToDevice, c->stream));
-        }
-        k_unpack_points<<<stride_grid((uint32_t)n), kBlock, 0, c->stream>>>(sl.d_raw, (uint32_t)n, point_step, off_x, off_y, off_z,
-                                                                           is_bigendian, sl.in_x, sl.in_y, sl.in_z);
-        HIPCHK(c, hipGetLastError());
-    }
+    if ((rc = stage_pointcloud2(c, c->slots[0], data, width, height, point_step, row_step, off_x, off_y, off_z, is_bigendian))) return rc;
     c->nframes = 1;
     if ((rc = submit_common(c, kFrameChain, c->params.publish_clouds != 0, c->cloud_layout, is_dense))) return rc;
     return finish_batch(c, out, out ? 1 : 0);
@@ -1841,15 +1861,45 @@ int pcop_process_node(pcop_ctx* c, const float* xyz, int layout, size_t n, int i
     return pcop_process_node_clouds(c, xyz, layout, n, is_dense, mem, occ, counts, row_avg, grid, mean_k, stddev_mul, plane, out, stats, nullptr);
 }
 
+// The node chain on a cloud that is staged in slot 0 (any entry point): checks, then node_chain_run.
+static int node_chain_checks(pcop_ctx* c, pcop_result* out, const pcop_occ_params* occ, int mean_k, float stddev_mul, const pcop_plane_params* plane,
+                             pcop_node_clouds* clouds);
+static int node_chain_run(pcop_ctx* c, size_t n, int is_dense, const pcop_occ_params* occ, int64_t* counts, int64_t* row_avg, int8_t* grid,
+                          int mean_k, float stddev_mul, const pcop_plane_params* plane, pcop_result* out, pcop_node_stats* stats, pcop_node_clouds* clouds);
+
 int pcop_process_node_clouds(pcop_ctx* c, const float* xyz, int layout, size_t n, int is_dense, int mem, const pcop_occ_params* occ,
                              int64_t* counts, int64_t* row_avg, int8_t* grid, int mean_k, float stddev_mul, const pcop_plane_params* plane,
                              pcop_result* out, pcop_node_stats* stats, pcop_node_clouds* clouds) {
     if (!c || !out) return PCOP_ERR_ARG;
+    if (mem != PCOP_MEM_HOST && mem != PCOP_MEM_DEVICE) return PCOP_ERR_ARG;
+    int rc = node_chain_checks(c, out, occ, mean_k, stddev_mul, plane, clouds);
+    if (rc) return rc;
+    if ((rc = set_device(c))) return rc;
+    c->slots[0].have_result = false;
+    if ((rc = stage_input(c, c->slots[0], xyz, layout, n, mem))) return rc;
+    return node_chain_run(c, n, is_dense, occ, counts, row_avg, grid, mean_k, stddev_mul, plane, out, stats, clouds);
+}
+
+int pcop_process_node_pointcloud2(pcop_ctx* c, const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step,
+                                  uint32_t off_x, uint32_t off_y, uint32_t off_z, int is_bigendian, int is_dense, const pcop_occ_params* occ,
+                                  int64_t* counts, int64_t* row_avg, int8_t* grid, int mean_k, float stddev_mul, const pcop_plane_params* plane,
+                                  pcop_result* out, pcop_node_stats* stats, pcop_node_clouds* clouds) {
+    if (!c || !out) return PCOP_ERR_ARG;
+    int rc = node_chain_checks(c, out, occ, mean_k, stddev_mul, plane, clouds);
+    if (rc) return rc;
+    if ((rc = set_device(c))) return rc;
+    c->slots[0].have_result = false;
+    if ((rc = stage_pointcloud2(c, c->slots[0], data, width, height, point_step, row_step, off_x, off_y, off_z, is_bigendian))) return rc;
+    return node_chain_run(c, (size_t)width * height, is_dense, occ, counts, row_avg, grid, mean_k, stddev_mul, plane, out, stats, clouds);
+}
+
+static int node_chain_checks(pcop_ctx* c, pcop_result* out, const pcop_occ_params* occ, int mean_k, float stddev_mul, const pcop_plane_params* plane,
+                             pcop_node_clouds* clouds) {
+    (void)out;
     if (clouds) clouds->n_voxel_grid = clouds->n_statistical_outliers = clouds->n_planar_cloud = clouds->n_indices_cloud = clouds->n_cloud_f = -1;
     int rc = busy(c);
     if (rc) return rc;
     if ((rc = check_params(c, true, true))) return rc;
-    if (mem != PCOP_MEM_HOST && mem != PCOP_MEM_DEVICE) return PCOP_ERR_ARG;
     if (occ && (rc = occ_check(c, occ))) return rc;
     const bool sor = mean_k != 0;
     if (sor) {
@@ -1864,10 +1914,14 @@ int pcop_process_node_clouds(pcop_ctx* c, const float* xyz, int layout, size_t n
         const double radius = (double)c->params.tol;
         if (!((float)(radius * radius) > 0.0f)) { c->err = "the node chain with outlier or plane removal needs a tolerance > 0"; return PCOP_ERR_PARAM; }
     }
-    if ((rc = set_device(c))) return rc;
+    return PCOP_OK;
+}
+
+static int node_chain_run(pcop_ctx* c, size_t n, int is_dense, const pcop_occ_params* occ, int64_t* counts, int64_t* row_avg, int8_t* grid,
+                          int mean_k, float stddev_mul, const pcop_plane_params* plane, pcop_result* out, pcop_node_stats* stats, pcop_node_clouds* clouds) {
+    int rc = PCOP_OK;
+    const bool sor = mean_k != 0;
     Slot& sl = c->slots[0];
-    sl.have_result = false;
-    if ((rc = stage_input(c, sl, xyz, layout, n, mem))) return rc;
     c->occ_valid = false;
     const uint32_t* n_dev = nullptr;
     if (occ) {   // the kept cloud and its point count stay on the device
@@ -1986,6 +2040,17 @@ int pcop_process_node_clouds(pcop_ctx* c, const float* xyz, int layout, size_t n
             if (clouds && clouds->planar_cloud) {   // (before the final stage overwrites the pinned buffer the host copy lives in)
                 for (uint32_t i = 0; i < left; ++i) { float* q = clouds->planar_cloud + 4 * (size_t)i; q[0] = left_host[i]; q[1] = left_host[left_n0 + i]; q[2] = left_host[2 * (size_t)left_n0 + i]; q[3] = 1.0f; }
                 clouds->n_planar_cloud = (int32_t)left;
+            }
+            if (clouds && plane_coeffs.empty()) {
+                // no plane went: the reference's indices_cloud_y / filtered_cloud_y are still the copies of the outlier removal's cloud
+                // cloud_cb made of it (od.cpp:774-775), and both are published as they are (od.cpp:410-426).  Nothing was removed, so
+                // that cloud is what is left.
+                for (float* dst : {clouds->indices_cloud, clouds->cloud_f}) {
+                    if (!dst) continue;
+                    for (uint32_t i = 0; i < left; ++i) { float* q = dst + 4 * (size_t)i; q[0] = left_host[i]; q[1] = left_host[left_n0 + i]; q[2] = left_host[2 * (size_t)left_n0 + i]; q[3] = 1.0f; }
+                }
+                if (clouds->indices_cloud) clouds->n_indices_cloud = (int32_t)left;
+                if (clouds->cloud_f) clouds->n_cloud_f = (int32_t)left;
             }
             if (ox == ra && left) {   // the cell stage sorts its records into rec_a: what is left moves to rec_b's planes (free by now)
                 HIPCHK(c, hipMemcpyAsync(rb, ox, (size_t)left * 4, hipMemcpyDeviceToDevice, s));

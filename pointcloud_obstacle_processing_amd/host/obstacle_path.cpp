@@ -209,8 +209,10 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
     pcop_result r{};
     node_voxel_grid_sent_ = false;
     if (node_order) {
-        PointCloudXYZ in;                                   // pcl::fromPCLPointCloud2 (od.cpp:688-689), on the host as there
-        if (!from_pointcloud2(cloud_msg, &in, &error_)) return PCOP_ERR_ARG;
+        // pcl::fromPCLPointCloud2 (od.cpp:688-689) happens on the GPU: the blob goes over as it is (pcop_process_node_pointcloud2); the
+        // library checks the message's geometry, the blob's size is checked here, where the vector is
+        const size_t n_in = (size_t)cloud_msg.width * cloud_msg.height;
+        if (n_in && cloud_msg.data.size() < (size_t)cloud_msg.row_step * cloud_msg.height) { error_ = "PointCloud2 data shorter than height * row_step"; return PCOP_ERR_ARG; }
         pcop_occ_params occ{};
         occ.x_min = params.x_min; occ.x_max = params.x_max; occ.y_min = params.y_min; occ.y_max = params.y_max;
         occ.z_min = params.z_min; occ.z_max = params.z_max; occ.block_size = params.block_size; occ.dev_percent = params.dev_percent;
@@ -222,13 +224,13 @@ int ObstacleNode::cloud_cb(const PointCloud2& cloud_msg) {
         occupancy_grid.assign(cells, 0); occupancy_counts.assign(cells, 0); occupancy_row_averages.assign((size_t)std::max(occ.grid_height, 0), 0);
         static_assert(sizeof(long long) == sizeof(int64_t), "counts are 64-bit");
         // one fused call feeds every topic of the node's order: the clouds between the steps come back as pcl::PointXYZ records
-        const size_t room = std::max<size_t>(in.points.size(), 1);
+        const size_t room = std::max<size_t>(n_in, 1);
         std::vector<PointXYZ> c_vg(room), c_so(room), c_pl(room), c_ix(room), c_cf(room);
         pcop_node_clouds clouds{};
         clouds.voxel_grid = &c_vg[0].x; clouds.statistical_outliers = &c_so[0].x; clouds.planar_cloud = &c_pl[0].x;
         clouds.indices_cloud = &c_ix[0].x; clouds.cloud_f = &c_cf[0].x;
-        rc = pcop_process_node_clouds(ctx_, in.points.empty() ? nullptr : &in.points[0].x, PCOP_LAYOUT_AOS16, in.points.size(), 1, PCOP_MEM_HOST,
-                                      &occ, reinterpret_cast<int64_t*>(occupancy_counts.data()), reinterpret_cast<int64_t*>(occupancy_row_averages.data()),
+        rc = pcop_process_node_pointcloud2(ctx_, cloud_msg.data.data(), cloud_msg.width, cloud_msg.height, cloud_msg.point_step, cloud_msg.row_step,
+                                      ox, oy, oz, cloud_msg.is_bigendian ? 1 : 0, 1, &occ, reinterpret_cast<int64_t*>(occupancy_counts.data()), reinterpret_cast<int64_t*>(occupancy_row_averages.data()),
                                       reinterpret_cast<int8_t*>(occupancy_grid.data()), params.statistical_outlier_meanK,
                                       params.statistical_outlier_stdDevThres, remove_planes ? &plane : nullptr, &r, &stats, &clouds);
         if (rc == PCOP_OK && params.publish_point_clouds) {

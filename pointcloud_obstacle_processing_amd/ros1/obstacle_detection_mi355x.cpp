@@ -71,12 +71,12 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr& cloud_msg) {
     pcop_result r{};
     int rc;
     if (node_order) {   // od.cpp:727-797 in the node's order, one call; the clouds of the topics between the steps come out of it
+        // The message goes to the GPU as it is (pcop_process_node_pointcloud2 unpacks x / y / z by field offset there: od.cpp:688-689);
+        // the library checks its geometry, the size of the blob is checked here, where the vector is.
         const size_t n = (size_t)cloud_msg->width * cloud_msg->height;
-        std::vector<float> in(4 * n + 4);   // pcl::fromPCLPointCloud2 (od.cpp:688-689): x, y, z by field offset into 16-byte records
-        for (size_t i = 0; i < n; ++i) {
-            const uint8_t* q = &cloud_msg->data[(i / cloud_msg->width) * cloud_msg->row_step + (i % cloud_msg->width) * cloud_msg->point_step];
-            std::memcpy(&in[4 * i], q + off[0], 4); std::memcpy(&in[4 * i + 1], q + off[1], 4); std::memcpy(&in[4 * i + 2], q + off[2], 4);
-            in[4 * i + 3] = 1.0f;
+        if (n && cloud_msg->data.size() < (size_t)cloud_msg->height * cloud_msg->row_step) {
+            ROS_ERROR("cloud message truncated: %zu bytes for %u rows of %u", cloud_msg->data.size(), cloud_msg->height, cloud_msg->row_step);
+            return;
         }
         pcop_occ_params occ{};
         occ.x_min = pt_lower_lim_x; occ.x_max = pt_upper_lim_x; occ.y_min = pt_lower_lim_y; occ.y_max = pt_upper_lim_y;
@@ -84,14 +84,19 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr& cloud_msg) {
         pcop_occupancy_grid_dims(occ.x_min, occ.x_max, occ.y_min, occ.y_max, occ.block_size, &occ.grid_width, &occ.grid_height);   // od.cpp:958-959
         pcop_plane_params pp{};
         pp.dist_thresh = plane_segment_dist_thres; pp.axis[2] = 1.0f; pp.eps_angle = (double)plane_segment_angle;                  // od.cpp:768, 778-781
-        const size_t cells = (size_t)occ.grid_width * occ.grid_height;
-        std::vector<int64_t> counts(cells + 1), rows((size_t)occ.grid_height + 1);
-        std::vector<int8_t> grid(cells + 1);
-        std::vector<float> vg(4 * n + 4), so(4 * n + 4), pl(4 * n + 4), ix(4 * n + 4), cf(4 * n + 4);
+        const size_t cells = (size_t)(occ.grid_width > 0 ? occ.grid_width : 0) * (size_t)(occ.grid_height > 0 ? occ.grid_height : 0);
+        // scratch kept across callbacks (the queue depth is 1 and the callback is single-threaded: od.cpp:1001, 1014)
+        static std::vector<int64_t> counts, rows;
+        static std::vector<int8_t> grid;
+        static std::vector<float> vg, so, pl, ix, cf;
+        if (counts.size() < cells + 1) { counts.resize(cells + 1); grid.resize(cells + 1); }
+        if (rows.size() < (size_t)(occ.grid_height > 0 ? occ.grid_height : 0) + 1) rows.resize((size_t)(occ.grid_height > 0 ? occ.grid_height : 0) + 1);
+        for (std::vector<float>* v : {&vg, &so, &pl, &ix, &cf}) if (v->size() < 4 * n + 4) v->resize(4 * n + 4);
         pcop_node_clouds cl{};
         cl.voxel_grid = vg.data(); cl.statistical_outliers = so.data(); cl.planar_cloud = pl.data(); cl.indices_cloud = ix.data(); cl.cloud_f = cf.data();
-        rc = pcop_process_node_clouds(g_ctx, in.data(), PCOP_LAYOUT_AOS16, n, cloud_msg->is_dense, PCOP_MEM_HOST, &occ, counts.data(), rows.data(),
-                                      grid.data(), statistical_outlier_meanK, statistical_outlier_stdDevThres, &pp, &r, nullptr, &cl);
+        rc = pcop_process_node_pointcloud2(g_ctx, cloud_msg->data.data(), cloud_msg->width, cloud_msg->height, cloud_msg->point_step, cloud_msg->row_step,
+                                           off[0], off[1], off[2], cloud_msg->is_bigendian, cloud_msg->is_dense, &occ, counts.data(), rows.data(),
+                                           grid.data(), statistical_outlier_meanK, statistical_outlier_stdDevThres, &pp, &r, nullptr, &cl);
         if (rc != PCOP_OK) { ROS_ERROR("pcop: %s (%s)", pcop_status_string(rc), pcop_last_error(g_ctx)); return; }
         if (publish_point_clouds) {   // od.cpp:288-295, 331-338, 401-426 (a count of -1: the call did not produce that cloud)
             if (cl.n_voxel_grid >= 0) downsample_publisher.publish(xyz_cloud_msg(cl.voxel_grid, (size_t)cl.n_voxel_grid, "world"));
@@ -101,6 +106,10 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr& cloud_msg) {
             if (cl.n_cloud_f >= 0) filtered_cloud_publisher.publish(xyz_cloud_msg(cl.cloud_f, (size_t)cl.n_cloud_f, "world"));
         }
     } else {
+        if ((size_t)cloud_msg->width * cloud_msg->height && cloud_msg->data.size() < (size_t)cloud_msg->height * cloud_msg->row_step) {
+            ROS_ERROR("cloud message truncated: %zu bytes for %u rows of %u", cloud_msg->data.size(), cloud_msg->height, cloud_msg->row_step);
+            return;
+        }
         rc = pcop_process_pointcloud2(g_ctx, cloud_msg->data.data(), cloud_msg->width, cloud_msg->height,
                                       cloud_msg->point_step, cloud_msg->row_step, off[0], off[1], off[2],
                                       cloud_msg->is_bigendian, cloud_msg->is_dense, &r);

@@ -234,3 +234,55 @@ def test_box_path_single_frames_on_the_sort_path(capi, oracle):
     same(c.process_xyz(empty), oracle.process_xyz(empty, **p))
     same(c.process_xyz(a[:3]), oracle.process_xyz(a[:3], **p))
     c.close()
+
+
+def test_the_configuration_the_bench_times(capi, oracle):
+    """The bench line's configuration at its full size (bench.py: a context of 16 slots, 16 distinct 1 M-point C3 clouds resident in
+    HBM, three submit_batch_device rounds: the bounds pass first, then twice with the keys on the context's box, 2^15 points a tile):
+    frames 0, 7 and 15 of every round bit-exact against the oracle.  Reference call sites: od.cpp:740-741, 791-797."""
+    p = synth.params_of("C3")
+    n = synth.CONFIGS["C3"]["n"]
+    seeds = [3000 + i for i in range(16)]
+    c = capi.Context(n, max_frames=16)
+    c.set_params(publish_clouds=1, **p)
+    ptrs, ns, refs = [], [], {}
+    for i, s in enumerate(seeds):
+        cloud = synth.make_cloud("C3", seed=s)
+        q, k = c.upload_soa(cloud)
+        ptrs.append(q); ns.append(k)
+        if i in (0, 7, 15):
+            refs[i] = oracle.process_xyz(cloud, **p)
+        del cloud
+    for rnd in range(3):
+        c.submit_batch_device(ptrs, ns)
+        got = c.wait_batch()
+        st = c.debug_state()
+        assert st.vpath == 1, "a batch takes the streaming voxel path"
+        if rnd >= 1:
+            assert st.sbox == 1 and st.tile == 32768, (rnd, st.sbox, st.tile)
+        else:
+            assert st.sbox == 0
+        for i, r in refs.items():
+            same(got[i], r)
+    c.close()
+
+
+def test_single_frames_on_a_box_one_key_bit_longer_do_not_replan_every_call(capi, oracle):
+    """A grid of 40^3 voxels has 16-bit keys (two 8-bit passes); the context's box around it (a margin of one voxel at least) has
+    42^3 cells = 17 bits (three passes).  Single frames keyed on the box plan on the box's bits: the pass count must stay at what
+    the box needs, or every call raises kErrReplanVoxel and runs twice."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(0.0005, 0.3995, (60_000, 3)).astype(f32)
+    pts[0] = (0.0005, 0.0005, 0.0005); pts[1] = (0.3995, 0.3995, 0.3995)
+    p = dict(leaf=0.01, tol=0.03, min_cluster=1, max_cluster=100000)
+    ref = oracle.process_xyz(pts, **p)
+    c = capi.Context(len(pts))
+    c.set_params(publish_clouds=1, **p)
+    seen = []
+    for rep in range(6):
+        same(c.process_xyz(pts), ref)
+        seen.append(c.debug_counter("replans"))
+    st = c.debug_state()
+    assert tuple(st.div_b) == (40, 40, 40) and st.sbox == 1
+    assert seen[-1] == seen[2], seen   # (the first boxed frame may move the pass count once; after that nothing moves)
+    c.close()

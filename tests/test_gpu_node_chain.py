@@ -210,3 +210,78 @@ def test_node_chain_error_in_the_middle_leaves_a_usable_context(capi, oracle, mo
         got = c.wait_batch()
         assert got[0]["voxel_xyz"].tobytes() == ref["voxel_xyz"].tobytes() and np.array_equal(got[0]["indices"], ref["indices"])
     c.close()
+
+
+def kinect_message(pts, width, height, step=32, pad=64, bigendian=False):
+    """A sensor_msgs/PointCloud2 blob the way a Kinect driver lays it out: xyz + padding + rgb in 32-byte points (here with the fields
+    out of order: y @4, x @8, z @16) and padded rows."""
+    row_step = width * step + pad
+    buf = np.zeros(height * row_step, dtype=np.uint8)
+    rows = buf.reshape(height, row_step)[:, :width * step].reshape(height, width, step)
+    for off, a in ((4, 1), (8, 0), (16, 2)):
+        v = pts[:, a].reshape(height, width).copy()
+        b = v.view(np.uint8).reshape(height, width, 4)
+        rows[:, :, off:off + 4] = b[:, :, ::-1] if bigendian else b
+    return buf, row_step
+
+
+@pytest.mark.parametrize("bigendian", [False, True])
+def test_node_chain_fed_with_the_pointcloud2_blob(capi, oracle, bigendian):
+    """pcop_process_node_pointcloud2 (od.cpp:688-689 in front of od.cpp:727-797): the message goes to the GPU as it is; same results
+    as pcop_process_node on the cloud a host loop would have unpacked, and as the stage-by-stage oracle chain."""
+    leaf, tol, mn, mx, mul, pthr = 0.04, 0.12, 5, 20000, 1.0, 0.04
+    width, height = 640, 400
+    pts = field_cloud(width * height, 29)
+    buf, row_step = kinect_message(pts, width, height, bigendian=bigendian)
+    po, pc = occ_of(capi, oracle)
+    ref = oracle_chain(oracle, pts, po, leaf, 15, mul, tol, mn, mx, plane_thr=pthr)
+    c = capi.Context(len(pts))
+    c.set_params(leaf=leaf, tol=tol, min_cluster=mn, max_cluster=mx, publish_clouds=1)
+    want = c.process_node(pts, occ=pc, mean_k=15, stddev_mul=mul, plane=capi.plane_params(pthr))
+    got = c.process_node_pointcloud2(buf, width, height, 32, row_step, 8, 4, 16, is_bigendian=bigendian, is_dense=False, occ=pc, mean_k=15,
+                                     stddev_mul=mul, plane=capi.plane_params(pthr), want_clouds=True)
+    for g in (want, got):
+        assert g["voxel_xyz"].tobytes() == ref["cloud"].tobytes()
+        assert np.array_equal(g["offsets"], ref["offsets"]) and np.array_equal(g["indices"], ref["indices"])
+        assert g["n_voxels"] == ref["n_voxels"] and g["n_inliers"] == ref["n_inliers"] and g["n_planes"] == ref["n_planes"]
+        assert g["n_filtered"] == ref["n_filtered"]
+    assert got["clouds"]["planar_cloud"][:, :3].tobytes() == ref["cloud"].tobytes()
+    # a malformed message is refused before a byte of it is read
+    for bad in (dict(point_step=32, off_x=29), dict(point_step=32, off_x=0xFFFFFFFE), dict(point_step=3, off_x=0), dict(row_step=width * 32 - 1)):
+        kw = dict(point_step=32, row_step=row_step, off_x=8)
+        kw.update(bad)
+        with pytest.raises(capi.PcopError) as e:
+            c.process_node_pointcloud2(buf, width, height, kw["point_step"], kw["row_step"], kw["off_x"], 4, 16, occ=pc, mean_k=15, plane=capi.plane_params(pthr))
+        assert e.value.status == -1
+    with pytest.raises(capi.PcopError) as e:   # more points than the context holds
+        c.process_node_pointcloud2(buf, width, height + 1, 32, row_step, 8, 4, 16)
+    assert e.value.status == -5
+    again = c.process_node_pointcloud2(buf, width, height, 32, row_step, 8, 4, 16, is_bigendian=bigendian, is_dense=False, occ=pc, mean_k=15,
+                                       stddev_mul=mul, plane=capi.plane_params(pthr))
+    assert np.array_equal(again["indices"], ref["indices"])   # the context is as usable as before
+    c.close()
+
+
+def test_node_chain_without_a_plane_publishes_the_outlier_cloud_twice(capi, oracle):
+    """No plane removed (a cloud the RANSAC finds no inliers in - here: fewer than three points left - or an empty one): the reference still
+    publishes indices_cloud and cloud_f, both the copies of the outlier removal's output cloud_cb made (od.cpp:774-775, 410-426)."""
+    leaf, tol = 0.05, 0.2
+    c = capi.Context(4096)
+    c.set_params(leaf=leaf, tol=tol, min_cluster=1, max_cluster=100, publish_clouds=1)
+    pts = np.array([[0.01, 0.01, 0.0], [1.0, 1.0, 0.3]], dtype=f32)   # two voxels: the plane model needs three points
+    buf = np.zeros(2 * 16, dtype=np.uint8)
+    buf.view(f32).reshape(2, 4)[:, :3] = pts
+    got = c.process_node_pointcloud2(buf, 2, 1, 16, 32, 0, 4, 8, plane=capi.plane_params(0.04), want_clouds=True)
+    assert got["n_planes"] == 0 and got["n_voxels"] == 2
+    cl = got["clouds"]
+    vox, _ = oracle.voxel_downsample(pts, leaf)
+    assert cl["voxel_grid"][:, :3].tobytes() == vox.tobytes()
+    assert cl["statistical_outliers"] is None            # that step was not asked for
+    for nm in ("planar_cloud", "indices_cloud", "cloud_f"):
+        assert cl[nm] is not None and cl[nm][:, :3].tobytes() == vox.tobytes(), nm
+        assert np.all(cl[nm][:, 3] == 1.0)
+    # an empty message: five empty clouds where the steps ran
+    got = c.process_node_pointcloud2(np.zeros(16, dtype=np.uint8), 0, 1, 16, 0, 0, 4, 8, plane=capi.plane_params(0.04), want_clouds=True)
+    for nm in ("planar_cloud", "indices_cloud", "cloud_f"):
+        assert got["clouds"][nm] is not None and len(got["clouds"][nm]) == 0, nm
+    c.close()

@@ -6,6 +6,7 @@ O=gpurun_out/refresh_$tag
 cp $O/bench.json profiles/${tag}_bench_n1.json
 cp $O/rocprofv3_kernel_stats.csv profiles/${tag}_rocprofv3_kernel_stats.csv
 cp $O/kernel_summary_batch$B.txt profiles/${tag}_kernel_summary_batch$B.txt
+cp $O/kernel_summary_batch${B}_solo.txt profiles/${tag}_kernel_summary_batch${B}_solo.txt
 cp $O/kernel_summary_single_frame.txt profiles/${tag}_kernel_summary_single_frame.txt
 cp $O/pmc_summary.txt profiles/${tag}_pmc_summary.txt
 cp $O/pmc_traffic.json profiles/${tag}_pmc_traffic.json

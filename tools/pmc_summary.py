@@ -36,7 +36,7 @@ for k in sorted(F, key=lambda k: -sum(v for v, _, _ in F[k])):
     w = sum(wv) / max(len(wv), 1)
     hbm = (2.0 * f + w) * 1024.0
     name = k.split("(")[0].replace("void ", "")
-    res[name] = {"fetch_kib": f, "write_kib": w, "hbm_bytes_per_launch": hbm, "batch": batch}
+    res[name] = {"fetch_kib": f, "write_kib": w, "hbm_bytes_per_launch": hbm, "batch": batch, "launches": len(fv)}
     print("%-58s %12.0f %12.0f %12.2f" % (name[:58], f, w, hbm / 1e6))
 if out:
     json.dump(res, open(out, "w"), indent=1)

@@ -10,13 +10,16 @@ rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-secondary > $O/trace.log 2>&1
 echo "trace done"
+# the same trace with ONE context (the kernels alone on the GPU): what bench.py's HIP-event durations can be reproduced from
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_solo -o trace -- python3 $R/bench.py --steps 3 --warmup 1 --contexts 1 --no-cpu-baseline --no-end-to-end --no-secondary > $O/trace_solo.log 2>&1
+echo "solo trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --rounds 3 --no-cpu-baseline --no-end-to-end --contexts 1 > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --rounds 3 --no-cpu-baseline --no-end-to-end --no-secondary --contexts 1 > $O/pmc_$c.log 2>&1
 done
 # the "why" of the LDS-heavy kernels: bank conflicts against LDS-active cycles, LDS issue stalls, wave cycles (one pass: 8 SQ counters fit)
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --rounds 3 --no-cpu-baseline --no-end-to-end --contexts 1 > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq -o pmc -- python3 $R/bench.py --steps 1 --warmup 1 --rounds 3 --no-cpu-baseline --no-end-to-end --no-secondary --contexts 1 > $O/pmc_sq.log 2>&1
 echo "pmc done"
 # single-frame latency: the kernel trace of one-frame calls
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -o trace -- python3 $R/tools/single_frame.py > $O/trace1.log 2>&1
@@ -24,6 +27,8 @@ echo "single-frame trace done"
 cd $R
 T=$(dirname $(find $O/trace -name trace_kernel_trace.csv | head -1))
 python3 tools/prof_summary.py $T $B > $O/kernel_summary_batch$B.txt
+TS=$(dirname $(find $O/trace_solo -name trace_kernel_trace.csv | head -1))
+python3 tools/prof_summary.py $TS $B > $O/kernel_summary_batch${B}_solo.txt
 cp $(find $O/trace -name trace_kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats.csv
 T1=$(dirname $(find $O/trace1 -name trace_kernel_trace.csv | head -1))
 python3 tools/prof_summary.py $T1 1 > $O/kernel_summary_single_frame.txt
