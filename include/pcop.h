@@ -320,7 +320,8 @@ int pcop_device_count(void);
  * Used by the stage-wise parity tests only; not part of the drop-in surface. */
 int pcop_debug_buffer(pcop_ctx* ctx, const char* name, void** dev_ptr, size_t* bytes);
 /* Test hook: a named host-side counter of the context ("internal_retries": batches queued a second time after a bounded
- * device-side wait ran out; "replans": batches re-run with larger launch parameters or on another path; "lds_ordered": 1 while
+ * device-side wait ran out; "replans": batches re-run with larger launch parameters or on another path; "stale_reruns": batches re-run on scrubbed
+ * occupancy flags after a kernel found a flag no point of the batch had set; "lds_ordered": 1 while
  * ranks come from lane-ordered LDS atomics, 0 once a self-check sent the context back to peer masks; "stream_checked": the
  * streaming voxel path's partition has been verified against the peer-mask ranks). */
 int pcop_debug_counter(pcop_ctx* ctx, const char* name, uint64_t* value);

@@ -94,7 +94,7 @@ class DevState(C.Structure):
                 ("vpath", C.c_uint32), ("gbits", C.c_uint32), ("cshift", C.c_uint32), ("nbuckets", C.c_uint32), ("nb_cap", C.c_uint32),
                 ("cgrid_req", C.c_uint32), ("cpath", C.c_uint32), ("cmap_words", C.c_uint32), ("c_rowbits", C.c_uint32),
                 ("c_plane", C.c_uint32), ("c0", C.c_int32 * 3), ("c_dim", C.c_uint32 * 3), ("maxbin", C.c_uint32),
-                ("vt", C.c_uint32), ("plan_cap", C.c_uint32), ("vt_nonfinite", C.c_uint32), ("spin_limit", C.c_uint32), ("box_tile", C.c_uint32), ("sbox", C.c_uint32)]
+                ("box_nonfinite", C.c_uint32), ("pad1", C.c_uint32), ("spin_limit", C.c_uint32), ("box_tile", C.c_uint32), ("sbox", C.c_uint32)]
 
 
 _lib = None

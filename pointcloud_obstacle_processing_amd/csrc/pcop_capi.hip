@@ -37,10 +37,10 @@ struct GraphKey {
     uint32_t tile;                   // streaming voxel path: points per tile
     uint32_t stream, nb_cap, gbits;  // streaming voxel path: on?, buckets provided for (LDS, grids), log2 of the coarse bins (LDS)
     // (lds_ordered is fixed for the life of a context: not part of the key)
-    uint32_t cgrid, ctiles;          // dense cell grid: on?, occupancy tiles (grid)
-    uint32_t vt;                     // tiled voxel path: 0 off, 1 on, 2 on with the order check; 3: keys against the host's box; + 16: streaming path with its order check
+    uint32_t cgrid, ctiles;          // dense cell grid: on? (2: with the second hook round), occupancy tiles (grid)
+    uint32_t box;                    // 3: keys against the host's box (no bounds pass); + 16: streaming path with its order check
     bool operator<(const GraphKey& o) const {
-        if (vt != o.vt) return vt < o.vt;
+        if (box != o.box) return box < o.box;
         if (cgrid != o.cgrid) return cgrid < o.cgrid;
         if (ctiles != o.ctiles) return ctiles < o.ctiles;
         if (stream != o.stream) return stream < o.stream;
@@ -123,26 +123,19 @@ struct pcop_ctx {
     // LDS atomic adds of one wave instruction return their old values in lane order on this device (checked by
     // k_lds_order_probe when the context is made; PCOP_LDS_ORDER=0 skips the check and keeps the peer-mask ranks)
     bool lds_ordered = false;
-    // tiled voxel path (pcop_voxel_tiled.hpp): batches of frames, once the context knows a voxel box that holds its clouds (the
-    // union of the boxes of the frames it has seen since the leaf size was set, with a margin).  A batch the path refuses -
-    // a point outside the box, a bucket above its LDS, a grid it does not fit - is re-run on the streaming path.
-    bool vt_enabled = false, vt_ok = true;   // PCOP_VOXEL_TILED=1 switches it on (measured slower than the streaming path on C3: DESIGN.md 4.1b); vt_ok: this leaf size has not been refused for good
-    // The same box serves the streaming path: with the keys formed against it there is no bounds pass (k_minmax) - k_bin_hist takes the
-    // true bounds on its way and checks every point against the box.  PCOP_VOXEL_BOX=0 keeps the bounds pass.
+    // The context's voxel box: the union of the voxel grids of the frames it has seen since the leaf size was set, with a margin.
+    // With the keys formed against it there is no bounds pass (k_minmax) - k_bin_hist (k_radix_hist of pass 0 on the sort path) takes
+    // the true bounds on its way and checks every point against the box; a point outside: the batch is re-run with the bounds pass.
+    // PCOP_VOXEL_BOX=0 keeps the bounds pass.
     bool sbox_enabled = true;
     bool sbox_batch = false;                 // the batch in flight runs the streaming path on the box
-    bool vt_skip = false;                    // the batch in flight was refused: its re-run takes the streaming path
+    bool box_skip = false;                   // the batch in flight left the box: its re-run takes the bounds pass
     bool stream_checked = false, stream_chk = false;   // the streaming path's partition was verified once against the peer-mask ranks / this batch does it
     uint32_t bin_tile_forced = 0;            // PCOP_BIN_TILE=4096|8192|16384|32768 (a multiple of the partition's chunk; the tile tables count in 16 bits)
     bool debug_sync = false;                 // PCOP_DEBUG_SYNC=1: see mark()
+    bool debug_voxel_only = false;           // PCOP_DEBUG_VOXEL_ONLY=1: pcop_submit_batch runs the voxel stage only (measurements)
     bool debug_replan = false;               // PCOP_DEBUG_REPLAN=1: every re-plan says on stderr what it was about (read once, when the context is made)
     bool debug_order_mismatch = false;       // PCOP_DEBUG_ORDER_MISMATCH=1: that check fails once
-    bool vt_checked = false;                 // the first tiled batch ran the build that verifies the order of every tile
-    bool vt_batch = false;                   // the batch in flight runs the tiled path
-    uint32_t vt_strikes = 0;                 // batches refused for a bucket above its LDS (three: off for this leaf size)
-    uint32_t vt_plan_cap = kVtPlanCap;       // points per bucket the plan aims at (PCOP_VT_CAP)
-    bool vt_accum = false;                   // PCOP_VT_REDUCE=accum: k_vt_accum instead of the gathering k_bucket_reduce
-    uint32_t vt_reduce_blocks = 1792;        // blocks of k_vt_accum over the whole batch (PCOP_VT_REDUCE_BLOCKS): seven to a CU
     // A bounded device-side wait that runs out (kErrInternal: a block polled a lower block's publish word too long - only
     // possible when the GPU is shared so heavily that blocks of one launch are kept apart) costs a re-run, not the frame: the batch is
     // queued once more, by eager launches.  PCOP_DEBUG_SPIN0=1 makes the first batch of a context give up at its first poll (tests).
@@ -151,6 +144,8 @@ struct pcop_ctx {
     bool debug_plane_mismatch = false;       // PCOP_DEBUG_PLANE_MISMATCH=1: the next plane split "disagrees" with the host's selection (tests of the error path)
     uint32_t internal_retries = 0;           // re-runs so far (diagnostics)
     uint64_t replans = 0;                    // batches re-run with other launch parameters / on another path (diagnostics)
+    uint64_t stale_reruns = 0;               // batches re-run after a kernel found occupancy flags no point of the batch had set (kErrStale)
+    uint32_t stale_reruns_batch = 0;         // ... of the batch at hand (a third time: an error, not a loop)
     bool box_valid = false;
     int32_t box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};   // voxel coordinates, inclusive
     std::vector<float> sor_sq;               // outlier removal: the squares of the mean distances
@@ -163,6 +158,10 @@ struct pcop_ctx {
     // per cell; when cells are crowded (large tolerance / tiny leaf) the hash-table kernels, which put a whole wave
     // on a cell, are faster.  Chosen from the previous batch's points per cell; either choice gives the same result.
     bool crowded_cells = false;
+    // A second hook round at tree level (k_cgrid_hook2) before the union: pays when a frame has so many cells that the first round
+    // leaves the union kernel hundreds of thousands of trees to merge (C5); costs two launches.  Chosen from the previous batch's
+    // cells (PCOP_HOOK2=0|1 pins it); either choice gives the same result.
+    bool hook2 = false, hook2_fixed = false;
     uint32_t ctiles = kCmapCells / 32u / kVmapTile;
     std::map<GraphKey, hipGraphExec_t> graphs;
 
@@ -274,22 +273,9 @@ bool stream_on(const pcop_ctx* c) {
     return c->voxel_stream && c->stream_ok && c->kind != kFrameClusterOnly && (c->nframes > 1 || c->stream_single);
 }
 
-// The tiled voxel path: a batch of the plain chain (not the node chain's parts), lane-ordered LDS atomics, a box, clouds of a
-// size it is built for.
-bool vt_on(const pcop_ctx* c) {
-    if (!(stream_on(c) && c->vt_enabled && c->vt_ok && c->lds_ordered && c->box_valid && !c->vt_skip)) return false;
-    if (c->retry_to_caller || c->cur_n_dev || c->nframes < 2) return false;
-    uint64_t cells = 1;
-    for (int a = 0; a < 3; ++a) cells *= (uint64_t)((int64_t)c->box_hi[a] - c->box_lo[a] + 1);
-    if (cells > (1ull << 30)) return false;
-    for (uint32_t f = 0; f < c->nframes; ++f)
-        if (c->slots[f].n < 4u * kVtTile || c->slots[f].n > (kVtMaxTiles - 1u) * kVtTile) return false;
-    return true;
-}
-
 // The streaming path without its bounds pass: any batch the streaming path serves, once there is a box.
 bool sbox_on(const pcop_ctx* c) {
-    if (!(stream_on(c) && c->sbox_enabled && c->box_valid && !c->vt_skip)) return false;
+    if (!(stream_on(c) && c->sbox_enabled && c->box_valid && !c->box_skip)) return false;
     if (c->retry_to_caller || c->cur_n_dev) return false;
     uint64_t cells = 1;
     for (int a = 0; a < 3; ++a) cells *= (uint64_t)((int64_t)c->box_hi[a] - c->box_lo[a] + 1);
@@ -298,7 +284,7 @@ bool sbox_on(const pcop_ctx* c) {
 
 // The sort path without its bounds pass (single frames, and whatever the streaming path does not take), once there is a box.
 bool sbox_sort_on(const pcop_ctx* c) {
-    if (!(c->sbox_enabled && c->box_valid && !c->vt_skip && !stream_on(c) && c->kind != kFrameClusterOnly)) return false;
+    if (!(c->sbox_enabled && c->box_valid && !c->box_skip && !stream_on(c) && c->kind != kFrameClusterOnly)) return false;
     if (c->retry_to_caller || c->cur_n_dev) return false;
     uint64_t cells = 1;
     for (int a = 0; a < 3; ++a) cells *= (uint64_t)((int64_t)c->box_hi[a] - c->box_lo[a] + 1);
@@ -331,49 +317,11 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
         k_frame_init<<<dim3(1, nf), 64, 0, s>>>(fr);
         mark(c, "k_frame_init");
     }
-    if (kind != kFrameClusterOnly && (parts & kPartVoxel) && c->vt_batch) {
-        const size_t bins = (size_t)1 << c->gbits;
-        const dim3 bt(std::max(1u, div_up(nb, kBinTile)), nf);      // tiles of the sampled histogram
-        const dim3 vtg(std::max(1u, div_up(nb, kVtTile)), nf);      // tiles of the sort
-        k_vt_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, c->npass_voxel, (uint32_t)MAXB, fold_grid, 1u);
-        mark(c, "k_vt_setup");
-        k_vt_sample<<<bt, kBinThreads, bins * 4u, s>>>(fr);
-        mark(c, "k_vt_sample");
-        k_bin_colsum<<<dim3((uint32_t)div_up((uint32_t)bins, kWave), nf), kBlock, 0, s>>>(fr);
-        mark(c, "k_bin_colsum");
-        k_bin_plan<<<dim3(1, nf), kBinThreads, plan_lds_bytes((uint32_t)bins), s>>>(fr);
-        mark(c, "k_bin_plan");
-        const bool chk = !c->vt_checked;
-        if (c->nb_cap <= 2u * kVtThreads) {
-            if (chk) k_vt_sort<2, true><<<vtg, kVtThreads, vt_sort_lds_bytes(2u * kVtThreads, 4096u), s>>>(fr);
-            else k_vt_sort<2, false><<<vtg, kVtThreads, vt_sort_lds_bytes(2u * kVtThreads, 4096u), s>>>(fr);
-        } else if (c->nb_cap <= 3u * kVtThreads) {
-            if (chk) k_vt_sort<3, true><<<vtg, kVtThreads, vt_sort_lds_bytes(3u * kVtThreads, 4096u), s>>>(fr);
-            else k_vt_sort<3, false><<<vtg, kVtThreads, vt_sort_lds_bytes(3u * kVtThreads, 4096u), s>>>(fr);
-        } else if (c->nb_cap <= 4u * kVtThreads) {
-            if (chk) k_vt_sort<4, true><<<vtg, kVtThreads, vt_sort_lds_bytes(4u * kVtThreads, 2048u), s>>>(fr);
-            else k_vt_sort<4, false><<<vtg, kVtThreads, vt_sort_lds_bytes(4u * kVtThreads, 2048u), s>>>(fr);
-        } else {
-            if (chk) k_vt_sort<8, true><<<vtg, kVtThreads, vt_sort_lds_bytes(8u * kVtThreads, 2048u), s>>>(fr);
-            else k_vt_sort<8, false><<<vtg, kVtThreads, vt_sort_lds_bytes(8u * kVtThreads, 2048u), s>>>(fr);
-        }
-        mark(c, "k_vt_sort");
-        if (c->vt_accum) {   // PCOP_VT_REDUCE=accum: a wave per bucket, lane-ordered float adds to LDS (persistent waves: each takes every grid-th bucket)
-            k_vt_accum<<<dim3((std::max(8u, std::min(div_up(c->nb_cap, kWavesPerBlock), std::max(8u, c->vt_reduce_blocks / nf))) + 7u) / 8u * 8u, nf), kBlock, 0, s>>>(fr);
-            mark(c, "k_vt_accum");
-        } else {             // the streaming path's bucket kernel, its records gathered piece by piece
-            k_bucket_reduce<true, true><<<dim3((div_up(c->nb_cap, kReduceBucketsPerBlock) + 7u) / 8u * 8u, nf), kBlock, 0, s>>>(fr);   // (a multiple of eight blocks: the XCD mapping)
-            mark(c, "k_bucket_reduce");
-        }
-        k_vt_scan<<<dim3(1, nf), kBlock, 0, s>>>(fr);
-        mark(c, "k_vt_scan");
-        k_voxel_gather<<<dim3(div_up(c->nb_cap, kGatherPer), nf), kBlock, 0, s>>>(fr);
-        mark(c, "k_voxel_gather");
-    } else if (kind != kFrameClusterOnly && (parts & kPartVoxel)) {
+    if (kind != kFrameClusterOnly && (parts & kPartVoxel)) {
         const bool stream = stream_on(c);
         if (c->sbox_batch) {   // keys against the host's box: no bounds pass, k_bin_hist / k_radix_hist of pass 0 takes the bounds on its way
-            k_vt_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, c->npass_voxel, (uint32_t)MAXB, fold_grid, stream ? 2u : 3u);
-            mark(c, "k_vt_setup");
+            k_box_setup<<<dim3(1, nf), kBlock, 0, s>>>(fr, c->npass_voxel, (uint32_t)MAXB, fold_grid, stream ? 2u : 3u);
+            mark(c, "k_box_setup");
         } else {
             k_minmax<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, 0u);
             mark(c, "k_minmax");
@@ -392,8 +340,6 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             mark(c, "k_bin_plan");
             k_bin_tilecnt<<<bt, kBlock, (bins + 8u) * 2u, s>>>(fr);
             mark(c, "k_bin_tilecnt");
-            k_bin_colscan<<<dim3(div_up(c->nb_cap, kWavesPerBlock), nf), kBlock, 0, s>>>(fr);
-            mark(c, "k_bin_colscan");
             if (c->lds_ordered) {
                 if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, true><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr, 0u);
                 else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, true><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr, 0u);
@@ -415,11 +361,10 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
                 k_heavy_split<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
                 mark(c, "k_heavy_split");
             }
-            if (c->lds_ordered) k_bucket_reduce<true><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
-            else k_bucket_reduce<false><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
+            // one wave per bucket; the centroids go straight to their ranks and mark the grid cells of a chain frame (marks_cells below)
+            if (c->lds_ordered) k_bucket_reduce<true><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kWave, 0, s>>>(fr);
+            else k_bucket_reduce<false><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kWave, 0, s>>>(fr);
             mark(c, "k_bucket_reduce");
-            k_voxel_gather<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);   // (also marks the grid cells of a chain frame: see marks_cells below)
-            mark(c, "k_voxel_gather");
         } else {
             for (uint32_t p = 0; p < c->npass_voxel; ++p) {
                 k_radix_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
@@ -448,7 +393,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             }
             // a chain frame has its cells marked by the voxel stage's last kernel (same launch sequence, grid set up before
             // the voxel stage)
-            const bool marks_cells = kind == kFrameChain && (parts & kPartVoxel) && !(parts & kPartOwnGridSetup);   // by k_voxel_gather / k_voxel_reduce
+            const bool marks_cells = kind == kFrameChain && (parts & kPartVoxel) && !(parts & kPartOwnGridSetup);   // by k_bucket_reduce / k_voxel_reduce
             if (!marks_cells) {
                 k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
                 mark(c, "k_cell_mark");
@@ -457,7 +402,8 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             mark(c, "k_cmap_scan");
             k_cell_count<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "k_cell_count");
-            k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
+            const uint32_t hook2 = c->hook2 ? 1u : 0u;   // a second, tree-level hook round: frames with very many cells (see k_cgrid_hook2)
+            k_cell_starts<<<sg, kBlock, 0, s>>>(fr, hook2);
             mark(c, "k_cell_starts");
             k_cell_place<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "k_cell_place");
@@ -465,6 +411,12 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             mark(c, "k_cgrid_hook");
             k_cell_compress<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "k_cell_compress");
+            if (hook2) {
+                k_cgrid_hook2<<<cg, kBlock, 0, s>>>(fr);
+                mark(c, "k_cgrid_hook2");
+                k_cell_compress2<<<tg, kBlock, 0, s>>>(fr);
+                mark(c, "k_cell_compress2");
+            }
             k_cgrid_union<<<cg, kBlock, 0, s>>>(fr, nf == 1 ? 1u : 0u);
             mark(c, "k_cgrid_union");
             if (nf == 1) {   // one frame: where it pays, the cells at tree borders get a wave each (fix_by_wave)
@@ -540,20 +492,19 @@ uint32_t fill_frame_args(pcop_ctx* c) {
         a.src_x = sl.src_x; a.src_y = sl.src_y; a.src_z = sl.src_z;
         a.n_dev = f == 0 ? c->cur_n_dev : nullptr; a.sor_thr = 0.0;
         a.spin_limit = (c->debug_spin0 && !c->internal_retry) ? 1u : kSpinLimit; a.pad1 = 0u;   // (PCOP_DEBUG_SPIN0: give up at the second poll)
-        a.vt_on = c->vt_batch ? 1u : (c->sbox_batch ? 2u : 0u); a.plan_cap = c->vt_batch ? std::max(1u, c->vt_plan_cap / kVtSampleRows) : 0u;
+        a.box_on = c->sbox_batch ? 2u : 0u; a.pad0 = 0u;
         for (int k = 0; k < 3; ++k) { a.box_lo[k] = c->box_lo[k]; a.box_dim[k] = (uint32_t)(c->box_hi[k] - c->box_lo[k] + 1); }
         nmax = std::max(nmax, sl.n);
     }
     c->frame_npass_csr = c->npass_csr;
     const uint32_t nb = bucket_of(c, nmax);
-    for (uint32_t f = 0; f < c->nframes; ++f) c->slots[f].h_args->tile = c->vt_batch ? kBinTile : tile_for(c, nb, c->nframes);
+    for (uint32_t f = 0; f < c->nframes; ++f) c->slots[f].h_args->tile = tile_for(c, nb, c->nframes);
     return nb;
 }
 
 int enqueue_batch(pcop_ctx* c) {
-    c->vt_batch = vt_on(c);
-    c->sbox_batch = !c->vt_batch && (sbox_on(c) || sbox_sort_on(c));
-    c->stream_chk = !c->vt_batch && c->kind != kFrameClusterOnly && stream_on(c) && c->lds_ordered && !c->stream_checked;
+    c->sbox_batch = sbox_on(c) || sbox_sort_on(c);
+    c->stream_chk = c->kind != kFrameClusterOnly && stream_on(c) && c->lds_ordered && !c->stream_checked;
     const uint32_t nb = fill_frame_args(c);
     c->ev_used = 0;
     if (c->profiling || !c->use_graph || c->internal_retry) {
@@ -563,7 +514,7 @@ int enqueue_batch(pcop_ctx* c) {
     } else {
         const bool st_on = stream_on(c);
         const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr | ((c->csr_onepass && c->csr_small) ? 0x100u : 0u), c->nframes, st_on ? tile_for(c, nb, c->nframes) : 0u, st_on ? (c->heavy_ok ? 2u : 1u) : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
-                           grid_on(c) ? 1u : 0u, grid_on(c) ? c->ctiles : 0u, (c->vt_batch ? (c->vt_checked ? 1u : 2u) : (c->sbox_batch ? 3u : 0u)) | (c->stream_chk ? 16u : 0u)};
+                           grid_on(c) ? (c->hook2 ? 2u : 1u) : 0u, grid_on(c) ? c->ctiles : 0u, (c->sbox_batch ? 3u : 0u) | (c->stream_chk ? 16u : 0u)};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -684,7 +635,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         }
         if (e & kErrSorFew) { c->in_flight = false; scrub_flags(c); c->err = "fewer points than mean_k + 1"; return PCOP_ERR_STATE; }
         if (e & (kErrReplanVoxel | kErrReplanCsr | kErrReplanPath | kErrReplanVcap | kErrReplanBins | kErrReplanCpath | kErrReplanCtiles |
-                 kErrReplanBox | kErrReplanVt | kErrOrder)) {
+                 kErrReplanBox | kErrOrder | kErrStale)) {
             // (every adaptive piece may have to move once for a cloud unlike the last: bins, buckets, heavy bins, voxel path,
             //  pass counts, occupancy tiles, cell path, CSR form - each moves towards "larger" only, so the loop ends)
             ++c->replans;
@@ -692,27 +643,25 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             // and the re-run need not mark the same cells again: a batch that leaves the host's box for the bounds pass sets its cell
             // grid up from other bounds.  Flags nobody consumes would sit there until some later frame's grid covers them - cells
             // without points.  So no re-run starts on anything but clean flags.
-            scrub_flags(c, c->nframes);
+            if (e & kErrStale) {   // a flag byte that was set before the batch began (a slot's "all zero between frames" scratch was not): every slot is scrubbed
+                ++c->stale_reruns;
+                scrub_flags(c);
+                if (c->stale_reruns_batch++ >= 2u) { c->in_flight = false; c->stale_reruns_batch = 0; c->err = "internal: occupancy flags keep turning up set"; return PCOP_ERR_STATE; }
+            } else scrub_flags(c, c->nframes);
             if (c->debug_replan) {
-                fprintf(stderr, "pcop: replan, attempt %d, bits 0x%x, vt %d;", attempt, e, c->vt_batch ? 1 : 0);
+                fprintf(stderr, "pcop: replan, attempt %d, bits 0x%x, box %d;", attempt, e, c->sbox_batch ? 1 : 0);
                 for (uint32_t f = 0; f < c->nframes; ++f) {
                     const DevState* hs = c->slots[f].h_state;
                     fprintf(stderr, " [f%u err 0x%x nb %u maxbin %u n_valid %u]", f, hs->err, hs->nbuckets, hs->maxbin, hs->n_valid);
                 }
                 fprintf(stderr, "\n");
             }
-            if ((c->sbox_batch || c->vt_batch) && (e & kErrReplanBox)) {   // a point outside the box: this batch is re-run with the bounds pass
-                c->vt_skip = true;   // (whatever else a frame keyed against the wrong box reported says nothing about the cloud)
-                e &= ~(uint32_t)(kErrReplanPath | kErrReplanBins | kErrReplanVt | kErrReplanVcap);
+            if (c->sbox_batch && (e & kErrReplanBox)) {   // a point outside the box: this batch is re-run with the bounds pass
+                c->box_skip = true;   // (whatever else a frame keyed against the wrong box reported says nothing about the cloud)
+                e &= ~(uint32_t)(kErrReplanPath | kErrReplanBins | kErrReplanVcap);
             } else if (c->stream_chk && (e & kErrOrder)) {
                 c->lds_ordered = false;          // the streamed partition differs between the two ways of ranking: peer masks from here on
                 c->debug_order_mismatch = false;
-            } else if (c->vt_batch) {   // what the tiled voxel path refuses goes to the streaming path: this batch, or from here on
-                if (e & kErrOrder) c->lds_ordered = false;       // a tile came out in the wrong order: ranks from peer masks from here on
-                if ((e & kErrReplanVt) && ++c->vt_strikes >= 3u) c->vt_ok = false;
-                if (e & kErrReplanPath) { c->vt_ok = false; e &= ~(uint32_t)kErrReplanPath; }   // (the streaming path has its own limits)
-                if ((e & kErrReplanBins) && (c->gbits >= kBinBitsMax || c->gbits_fixed)) { c->vt_ok = false; e &= ~(uint32_t)kErrReplanBins; }
-                if ((e & (kErrReplanVt | kErrOrder)) || !c->vt_ok) c->vt_skip = true;
             }
             if (attempt >= 16) { c->in_flight = false; scrub_flags(c); c->err = "replanning did not converge"; return PCOP_ERR_STATE; }
             if (kb_voxel) c->npass_voxel = std::max(c->npass_voxel, passes_for(c, kb_voxel));
@@ -745,10 +694,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             } else if (e & kErrReplanVcap) {
                 for (uint32_t f = 0; f < c->nframes; ++f) {
                     const DevState* hs = c->slots[f].h_state;
-                    if (hs->err & kErrReplanVcap) {   // 1024, 1536 (the tiled path's sort still fits two blocks to a CU), 2048, 4096; the tiled path keeps one row more than it has buckets
-                        const uint32_t need = hs->nbuckets + (c->vt_batch ? 1u : 0u);
-                        c->nb_cap = std::max(c->nb_cap, need > kNbMin && need <= 3u * kVtThreads ? 3u * kVtThreads : std::min(kNbMax, pow2_at_least(need)));
-                    }
+                    if (hs->err & kErrReplanVcap) c->nb_cap = std::max(c->nb_cap, std::min(kNbMax, pow2_at_least(hs->nbuckets)));   // 1024, 2048, 4096
                 }
             }
             if (c->retry_to_caller) { c->in_flight = false; return 1; }   // (not a pcop_status: the caller runs its own sequence again)
@@ -760,10 +706,9 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
     }
     collect_times(c);
     c->in_flight = false;
-    c->internal_retry = false; c->debug_spin0 = false;
-    if (c->vt_batch) c->vt_checked = true;   // (its tiles were verified, or an earlier batch's were)
+    c->internal_retry = false; c->debug_spin0 = false; c->stale_reruns_batch = 0;
     if (c->stream_chk) c->stream_checked = true;
-    c->vt_skip = false;
+    c->box_skip = false;
     // the voxel box of the next batches: the union of the frames' own grids (every path leaves PCL's min_b / div_b in DevState),
     // widened to multiples of eight voxels with a margin, so that it settles after a few batches of a steady source
     if (c->kind != kFrameClusterOnly) {
@@ -812,7 +757,7 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (c->kind != kFrameClusterOnly && !hs->passthrough && hs->n_valid) kb_voxel = std::max(kb_voxel, hs->plan_voxel.key_bits);
         if (c->kind != kFrameVoxelOnly && !c->slots[f].result_trivial) kb_csr = std::max(kb_csr, hs->plan_csr.key_bits);
     }
-    // (a frame keyed on the context's box plans its passes on the BOX's key bits - k_vt_setup sees nothing else - which are at least the
+    // (a frame keyed on the context's box plans its passes on the BOX's key bits - k_box_setup sees nothing else - which are at least the
     //  true grid's and often one more: the pass count never goes below what the box needs, or every single frame after a batch
     //  would raise kErrReplanVoxel and run twice)
     if (kb_voxel && c->sbox_enabled && c->box_valid) {
@@ -838,6 +783,12 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (cells) {
             if (pts > 24 * cells) c->crowded_cells = true;
             else if (pts < 16 * cells) c->crowded_cells = false;
+        }
+        if (!c->hook2_fixed) {   // (with hysteresis, like the choice above)
+            uint32_t most = 0;
+            for (uint32_t f = 0; f < c->nframes; ++f) if (!c->slots[f].result_trivial) most = std::max(most, c->slots[f].h_state->n_cells);
+            if (most >= (1u << 19)) c->hook2 = true;
+            else if (most < (1u << 18)) c->hook2 = false;
         }
     }
     if (grid_on(c)) {
@@ -1228,7 +1179,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
     TRY(dev_alloc(c, &f.table, ntiles * kMaxBins)); TRY(dev_alloc(c, &f.table_x, ntiles * kMaxBins));
     TRY(dev_alloc(c, &f.bin_total, (size_t)kMaxBins));
     TRY(dev_alloc(c, &f.tile_a, nscan)); TRY(dev_alloc(c, &f.tile_b, nscan));
-    TRY(dev_alloc(c, &f.partials, std::max<size_t>(kReduceBlocks, n / kTile + 2)));   // (keys on the host's box: one per tile of k_bin_hist / k_radix_hist / k_vt_sort)
+    TRY(dev_alloc(c, &f.partials, std::max<size_t>(kReduceBlocks, n / kTile + 2)));   // (keys on the host's box: one per tile of k_bin_hist / k_radix_hist)
     TRY(dev_alloc(c, &f.hkey, hcap)); TRY(dev_alloc(c, &f.hcount, hcap)); TRY(dev_alloc(c, &f.hmin, hcap));
     TRY(dev_alloc(c, &f.cell_start, hcap)); TRY(dev_alloc(c, &f.parent, hcap));
     TRY(dev_alloc(c, &f.comp_size, hcap)); TRY(dev_alloc(c, &f.comp_rank, hcap)); TRY(dev_alloc(c, &f.cell_list, n + 1));
@@ -1252,7 +1203,6 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
         TRY(dev_alloc(c, &f.binsum, ((size_t)1 << kBinBitsMax) + 8));
         f.tstride = (uint32_t)((tiles + 7) / 8 * 8);
         TRY(dev_alloc(c, &f.tcnt, (size_t)f.tstride * kNbMax + 8));
-        TRY(dev_alloc(c, &f.tbase, (size_t)f.tstride * kNbMax + 8));
         TRY(dev_alloc(c, &f.bucket_pub, (size_t)kNbMax));
         TRY(dev_alloc(c, &f.hsub, ((size_t)kNbMax + 1) * kHeavyGroups));
         TRY(dev_alloc(c, &f.hparts, (size_t)kNbMax + 1));
@@ -1280,7 +1230,7 @@ int alloc_slot(pcop_ctx* c, Slot& sl, size_t n, size_t ntiles, size_t hcap, size
 }
 
 int submit_common(pcop_ctx* c, uint32_t kind, bool emit_cloud, int out_layout, int is_dense) {
-    c->cur_n_dev = nullptr; c->retry_to_caller = false; c->vt_skip = false;
+    c->cur_n_dev = nullptr; c->retry_to_caller = false; c->box_skip = false;
     c->is_dense = is_dense; c->kind = kind; c->emit_cloud = emit_cloud; c->out_layout = out_layout;
     return enqueue_batch(c);
 }
@@ -1330,7 +1280,6 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_NO_GRAPH")) c->use_graph = atoi(e) == 0;
     if (const char* e = getenv("PCOP_VOXEL_PATH")) { c->voxel_stream = std::string(e) != "sort"; c->stream_single = std::string(e) == "stream"; }
     if (const char* e = getenv("PCOP_CSR_ONEPASS")) c->csr_onepass = atoi(e) != 0;
-    if (const char* e = getenv("PCOP_VOXEL_TILED")) c->vt_enabled = atoi(e) != 0;
     if (const char* e = getenv("PCOP_VOXEL_BOX")) c->sbox_enabled = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_SPIN0")) c->debug_spin0 = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_PLANE_MISMATCH")) c->debug_plane_mismatch = atoi(e) != 0;
@@ -1338,15 +1287,14 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_DEBUG_SYNC")) { c->debug_sync = atoi(e) != 0; if (c->debug_sync) c->use_graph = false; }
     if (const char* e = getenv("PCOP_DEBUG_ORDER_MISMATCH")) c->debug_order_mismatch = atoi(e) != 0;
     if (const char* e = getenv("PCOP_DEBUG_REPLAN")) c->debug_replan = atoi(e) != 0;
-    if (const char* e = getenv("PCOP_VT_CAP")) c->vt_plan_cap = (uint32_t)std::max(64, atoi(e));
-    if (const char* e = getenv("PCOP_VT_REDUCE")) c->vt_accum = std::string(e) == "accum";
-    if (const char* e = getenv("PCOP_VT_REDUCE_BLOCKS")) c->vt_reduce_blocks = (uint32_t)std::max(16, atoi(e));
+    if (const char* e = getenv("PCOP_DEBUG_VOXEL_ONLY")) c->debug_voxel_only = atoi(e) != 0;
     if (const char* e = getenv("PCOP_CELL_PATH")) c->cell_grid = std::string(e) != "hash";
     if (const char* e = getenv("PCOP_BIN_BITS")) { c->gbits = (uint32_t)std::min<int>(kBinBitsMax, std::max<int>(kBinBitsMin, atoi(e))); c->gbits_fixed = true; }
     if (const char* e = getenv("PCOP_CELL_BLOCKS")) c->cell_blocks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_STRIDE_BLOCKS")) c->stride_blocks = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("PCOP_FLATTEN_BLOCKS")) c->flatten_blocks = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("PCOP_DEBUG_SKIP_UNION")) c->debug_skip_union = (uint32_t)atoi(e);
+    if (const char* e = getenv("PCOP_HOOK2")) { c->hook2 = atoi(e) != 0; c->hook2_fixed = true; }
     const size_t nbk = bucket_of(c, (uint32_t)max_points);           // launch sizes round up to this
     const size_t n = std::max<size_t>(max_points, nbk);
     const size_t ntiles = (n + kTile - 1) / kTile + 1;
@@ -1378,32 +1326,10 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
                 hipFree(d_bad);
             }
             c->lds_ordered = bad == 0;
-            if (c->lds_ordered) {   // the eight-wave pattern of the tiled path
-                bad = 1;
-                if (hipMalloc(reinterpret_cast<void**>(&d_bad), 4) == hipSuccess) {
-                    if (hipMemsetAsync(d_bad, 0, 4, c->stream) == hipSuccess) {
-                        k_lds_order_probe8<<<64, kVtThreads, 0, c->stream>>>(d_bad);
-                        if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) bad = 1;
-                    }
-                    hipFree(d_bad);
-                }
-                if (bad) c->vt_enabled = false;
-                if (c->vt_enabled) {   // and the float adds k_vt_accum sums the voxels with
-                    bad = 1;
-                    if (hipMalloc(reinterpret_cast<void**>(&d_bad), 4) == hipSuccess) {
-                        if (hipMemsetAsync(d_bad, 0, 4, c->stream) == hipSuccess) {
-                            k_lds_float_order_probe<<<64, kBlock, 0, c->stream>>>(d_bad);
-                            if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) bad = 1;
-                        }
-                        hipFree(d_bad);
-                    }
-                    if (bad) c->vt_enabled = false;
-                }
-            }
         }
     }
     if (rc) { fprintf(stderr, "pcop_create: %s\n", c->err.c_str()); pcop_destroy(c); return rc; }
-    if (c->debug_replan) fprintf(stderr, "pcop: context: lds_ordered %d, tiled voxel path %s\n", c->lds_ordered ? 1 : 0, c->vt_enabled ? "on" : "off");
+    if (c->debug_replan) fprintf(stderr, "pcop: context: lds_ordered %d\n", c->lds_ordered ? 1 : 0);
     *out = c;
     return PCOP_OK;
 }
@@ -1430,7 +1356,7 @@ int pcop_max_frames(const pcop_ctx* c) { return c ? (int)c->max_frames : 0; }
 int pcop_set_params(pcop_ctx* c, const pcop_params* p) {
     if (!c || !p) return PCOP_ERR_ARG;
     if (c->in_flight) { c->err = "parameters cannot change while a batch is in flight (its re-planning and ordering read them)"; return PCOP_ERR_STATE; }
-    if (!c->params_set || p->leaf != c->params.leaf) { c->stream_ok = true; c->heavy_ok = false; c->vt_ok = true; c->vt_strikes = 0; c->box_valid = false; }   // a new leaf size is a new voxel grid
+    if (!c->params_set || p->leaf != c->params.leaf) { c->stream_ok = true; c->heavy_ok = false; c->box_valid = false; }   // a new leaf size is a new voxel grid
     if (!c->params_set || p->tol != c->params.tol) c->cgrid_ok = true;      // a new tolerance is a new cell grid
     c->params = *p;
     c->params_set = true;
@@ -1518,7 +1444,8 @@ int pcop_submit_batch(pcop_ctx* c, const float* const* xyz, int layout, const si
     for (int f = 0; f < nframes; ++f)
         if ((rc = stage_input(c, c->slots[f], xyz[f], layout, n[f], mem))) return rc;
     c->nframes = (uint32_t)nframes;
-    return submit_common(c, kFrameChain, c->params.publish_clouds != 0, c->cloud_layout, is_dense);
+    // (PCOP_DEBUG_VOXEL_ONLY=1, a measuring knob: batches stop after the voxel stage - what the cluster stage costs a pipelined run)
+    return submit_common(c, c->debug_voxel_only ? kFrameVoxelOnly : kFrameChain, c->params.publish_clouds != 0, c->cloud_layout, is_dense);
 }
 
 int pcop_wait_batch(pcop_ctx* c, pcop_result* out, int nframes) {
@@ -1720,7 +1647,7 @@ int pcop_statistical_outlier_removal(pcop_ctx* c, const float* xyz, int layout, 
     k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
     k_cmap_coarse<<<dim3(256, 1), kBlock, 0, s>>>(fr);
     k_cell_count<<<tg, kBlock, 0, s>>>(fr);
-    k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
+    k_cell_starts<<<sg, kBlock, 0, s>>>(fr, 0u);
     k_cell_place<<<tg, kBlock, 0, s>>>(fr);
     mark(c, "cell_grid");
     if (mean_k + 1 <= 16) { k_knn_mean<16><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); mark(c, "k_knn_mean"); k_knn_far<16><<<dim3(kFarBlocks, 1), kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); }
@@ -1964,7 +1891,7 @@ static int node_chain_run(pcop_ctx* c, size_t n, int is_dense, const pcop_occ_pa
             break;
         }
         c->retry_to_caller = true;
-        c->vt_batch = false; c->sbox_batch = false; c->stream_chk = false;   // (the node chain launches by parts: the plain voxel stage with its bounds pass)
+        c->sbox_batch = false; c->stream_chk = false;   // (the node chain launches by parts: the plain voxel stage with its bounds pass)
         const uint32_t nb = fill_frame_args(c);
         Frame* fr = c->d_frames;
         hipStream_t s = c->stream;
@@ -1981,7 +1908,7 @@ static int node_chain_run(pcop_ctx* c, size_t n, int is_dense, const pcop_occ_pa
             k_occ_scan<<<dim3(kCmapCells / 32u / kVmapTile, 1), kBlock, 0, s>>>(fr);
             k_cmap_coarse<<<dim3(256, 1), kBlock, 0, s>>>(fr);
             k_cell_count<<<tg, kBlock, 0, s>>>(fr);
-            k_cell_starts<<<sg, kBlock, 0, s>>>(fr);
+            k_cell_starts<<<sg, kBlock, 0, s>>>(fr, 0u);
             k_cell_place<<<tg, kBlock, 0, s>>>(fr);
             mark(c, "sor_grid");
             if (mean_k + 1 <= 16) { k_knn_mean<16><<<tg, kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); mark(c, "k_knn_mean"); k_knn_far<16><<<dim3(kFarBlocks, 1), kBlock, 0, s>>>(fr, (uint32_t)mean_k, 0.0, 1u); }
@@ -2205,6 +2132,7 @@ int pcop_debug_counter(pcop_ctx* c, const char* name, uint64_t* value) {
     if (!c || !name || !value) return PCOP_ERR_ARG;
     if (std::strcmp(name, "internal_retries") == 0) { *value = c->internal_retries; return PCOP_OK; }
     if (std::strcmp(name, "replans") == 0) { *value = c->replans; return PCOP_OK; }
+    if (std::strcmp(name, "stale_reruns") == 0) { *value = c->stale_reruns; return PCOP_OK; }
     if (std::strcmp(name, "lds_ordered") == 0) { *value = c->lds_ordered ? 1u : 0u; return PCOP_OK; }
     if (std::strcmp(name, "stream_checked") == 0) { *value = c->stream_checked ? 1u : 0u; return PCOP_OK; }
     return PCOP_ERR_ARG;

@@ -16,12 +16,13 @@ namespace pcop {
 //   * ids follow the grid, so cells that are neighbours in space are neighbours in every
 //     per-cell array and the lanes of a wave (64 consecutive cells) touch the same cache lines.
 //   k_cgrid_setup   grid origin / size from the bounding box (margins added), or "replan"
-//   k_cell_mark     grid position of every point; one byte per occupied cell
+//   k_cell_mark     grid position of every point; one byte per occupied cell (a chain frame's centroids mark theirs as
+//                   k_bucket_reduce / k_voxel_reduce write them: no launch of this kernel)
 //   k_occ_scan      bytes -> occupancy bits + running popcount => cell ids, n_cells
 //   k_cell_count    points per cell, rank inside the cell, smallest point index (= priority)
 //   k_cell_starts   exclusive scan of the counts; per-cell metadata; union-find init
 //   k_cell_place    (shared with the hash path) records sorted by cell
-//   k_cgrid_hook / k_cell_compress / k_cgrid_union   components, lane = cell
+//   k_cgrid_hook / k_cell_compress / [k_cgrid_hook2 / k_cell_compress2] / k_cgrid_union   components, lane = cell
 // ------------------------------------------------------------------------------------------
 
 // The whole block: grid origin and size from the bounding box in st->vmin / vmax (a superset of what the cell stage will
@@ -76,63 +77,6 @@ __global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
 }
 
-// End of the streaming voxel path and start of the cell stage in one pass over the voxels: the centroids k_bucket_reduce left
-// at their buckets' places go to their ranks (output order = voxel key order), and each marks its grid cell on the way,
-// so the chain has no k_cell_mark launch.  One block per bucket.  A frame the voxel grid passed through (or gave no voxels)
-// has no buckets: its cell stage sees the input cloud, marked here by all blocks together.
-constexpr uint32_t kGatherPer = 8;   // tiled voxel path: buckets per block of k_voxel_gather
-
-__global__ __launch_bounds__(kBlock) void k_voxel_gather(Frame* frames) {
-    __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    Frame& F = frames[blockIdx.y];
-    DevState* st = &F.st;
-    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
-    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
-    if (st->err || st->kind == kFrameClusterOnly) return;
-    const bool cells = !cgrid_off(st);
-    CellMarker mark;
-    if (cells) mark.init(st);
-    if (st->vt && st->n_valid && !st->passthrough) {   // tiled path: k_vt_scan left every bucket's output rank; a block takes kGatherPer buckets
-        const uint32_t nb = st->nbuckets;
-        const uint32_t* __restrict__ bucket_pub = F.bucket_pub; const uint32_t* __restrict__ bbase = F.tbase;
-        const float4* __restrict__ scratch = F.rec_b;
-        for (uint32_t b = blockIdx.x * kGatherPer; b < min(nb, (blockIdx.x + 1u) * kGatherPer); ++b) {
-            const uint32_t first = F.binfo[b].x, nvox = bucket_pub[b], base = bbase[b];
-            for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
-                const float4 p = scratch[first + v];
-                const uint32_t i = base + v;
-                cx[i] = p.x; cy[i] = p.y; cz[i] = p.z;
-                if (cells) pt_pos[i] = mark(st, cflag, p.x, p.y, p.z);
-            }
-        }
-    } else if (st->vpath && st->n_valid && !st->passthrough) {
-        const uint32_t b = blockIdx.x, nb = st->nbuckets;
-        if (b >= nb) return;
-        const uint32_t* __restrict__ bucket_pub = F.bucket_pub;
-        // output rank of the bucket's first voxel = voxels of the buckets before it (a few hundred words: every block adds
-        // them up for itself rather than wait for a scan kernel); the last bucket's block knows M
-        uint32_t before = 0;
-        for (uint32_t i = threadIdx.x; i < b; i += kBlock) before += bucket_pub[i];
-        const uint32_t base = block_sum(before, s_w);
-        const float4* __restrict__ scratch = F.rec_b;
-        const uint32_t first = F.binfo[b].x, nvox = bucket_pub[b];
-        if (b == nb - 1u && threadIdx.x == 0) finish_voxel(st, base + nvox);
-        for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
-            const float4 p = scratch[first + v];
-            const uint32_t i = base + v;
-            cx[i] = p.x; cy[i] = p.y; cz[i] = p.z;
-            if (cells) pt_pos[i] = mark(st, cflag, p.x, p.y, p.z);
-        }
-    } else if (cells) {
-        const bool from_in = st->c_from_input != 0;
-        const float* __restrict__ x = from_in ? st->src_x.get() : cx;
-        const float* __restrict__ y = from_in ? st->src_y.get() : cy;
-        const float* __restrict__ z = from_in ? st->src_z.get() : cz;
-        const uint32_t n = st->c_n;
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
-    }
-}
-
 // id of the occupied cell at grid position pos
 __device__ __forceinline__ uint32_t cell_id_at(const uint2* __restrict__ cmap, uint32_t pos) {
     const uint2 e = cmap[pos >> 5];
@@ -178,10 +122,11 @@ __global__ __launch_bounds__(kBlock) void k_cell_count(Frame* frames) {
 
 // cell_start = exclusive scan of the counts (tiles publish / add up the lower tiles); per-cell
 // metadata {first record, points, smallest point index, grid position}; union-find init
-__global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames) {
+__global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames, uint32_t hook2) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
+    unsigned long long* __restrict__ cand = reinterpret_cast<unsigned long long*>(F.cell_info.get());
     const uint32_t* __restrict__ ccount = F.hcount; const uint32_t* __restrict__ cmin = F.hmin;
     const uint32_t* __restrict__ cell_pos = F.cell_list;
     uint32_t* __restrict__ tile_pub = F.tile_b;
@@ -196,8 +141,13 @@ __global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames) {
     uint32_t v[kScanItems];
     uint32_t c = 0;
     const uint32_t s0 = base + threadIdx.x * kScanItems;
+    bool stale = false;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) { v[k] = s0 + k < nc ? ccount[s0 + k] : 0u; c += v[k]; }
+    for (int k = 0; k < kScanItems; ++k) { v[k] = s0 + k < nc ? ccount[s0 + k] : 0u; c += v[k]; stale |= s0 + k < nc && v[k] == 0u; }
+    // Every flagged cell was flagged by a point of this frame, so every cell has points.  One without: a flag byte that was set before
+    // the frame began (the "all zero between frames" scratch was not).  The frame is given up here - the kernels after this one never
+    // follow such a cell (and clamp what they read), the host scrubs every flag and runs the batch again.
+    if (stale) atomicOr(&st->err, (uint32_t)kErrStale);
     uint32_t tot;
     uint32_t run = block_excl_scan(c, s_w, &tot);
     if (threadIdx.x == 0) st_agent(tile_pub + blockIdx.x, tot + 1u);
@@ -220,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames) {
             cell_start[id] = run;
             parent[id] = id; comp_size[id] = 0u; comp_rank[id] = 0xFFFFFFFFu;
             slot_meta[id] = make_uint4(run, v[k], cmin[id], cell_pos[id]);
+            if (hook2) cand[id] = ~0ull;   // k_cgrid_hook2's candidate parent of a root: none yet
         }
         run += v[k];
     }
@@ -260,12 +211,12 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
     const uint4* __restrict__ slot_meta = F.slot_meta;
     uint32_t* __restrict__ parent = F.parent;
     if (cgrid_off(st)) return;
-    const uint32_t nc = st->n_cells;
+    const uint32_t nc = st->n_cells, c_n = st->c_n, grid_cells = st->cmap_words * 32u;
     const float r2 = st->r2;
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
         const uint4 ma = slot_meta[c];   // {first record, points, priority, grid position}
-        if (ma.y == 0u) continue;        // (a flagged cell no point of this frame lies in has no position either: never followed)
+        if (ma.y == 0u || ma.x + ma.y > c_n || ma.w >= grid_cells) continue;   // (a flagged cell no point of this frame lies in has no position either: never followed; a record range or a position that leaves the frame: never read)
         // rows: (dy,dz) = (-1,-1) (0,-1) (1,-1) (-1,0) with dx = -1..1, and the cell's own row with dx = -1
         uint2 e0[5];
         uint32_t e1[5], sh[5], wd[5];
@@ -306,6 +257,99 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
     }
 }
 
+// A second hook round, one level up (for frames with so many cells that the first round leaves hundreds of thousands of trees:
+// C5's three million cells hook into 251 k trees of a dozen cells each, and the union kernel then merges them pair by pair,
+// by CAS, mostly into ONE component).  After the compress every cell knows its tree's root.  Here every cell looks at the same
+// 13 backward cells once more: a neighbour in ANOTHER tree that a pair test connects is an edge between two trees, and the root
+// of larger priority value takes the other root as its candidate parent if it is the smallest it has seen - atomicMin on one
+// 64-bit word {priority, root} per root, fire and forget, no finds, no CAS loops.  Links go to strictly smaller priorities:
+// still a forest, and a root is still the cell of smallest priority of its tree.  k_cell_compress2 then follows a cell's root
+// through the candidate links to the end.  Roots that are not local minima among their neighbours disappear: the trees left
+// for k_cgrid_union shrink by the factor the first round achieved once more.
+__global__ __launch_bounds__(kBlock) void k_cgrid_hook2(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    const float4* __restrict__ rec = F.rec_a;
+    const uint2* __restrict__ cmap = F.cmap;
+    const uint4* __restrict__ slot_meta = F.slot_meta;
+    const uint32_t* __restrict__ parent = F.parent;
+    const uint32_t* __restrict__ prio = F.hmin;
+    unsigned long long* __restrict__ cand = reinterpret_cast<unsigned long long*>(F.cell_info.get());   // (the hash path's per-cell records: idle on the grid)
+    if (cgrid_off(st) || st->debug_skip_union == 1u) return;
+    const uint32_t nc = st->n_cells, c_n = st->c_n, grid_cells = st->cmap_words * 32u;
+    const float r2 = st->r2;
+    const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+        const uint4 ma = slot_meta[c];   // {first record, points, priority, grid position}
+        if (ma.y == 0u || ma.x + ma.y > c_n || ma.w >= grid_cells) continue;
+        const uint32_t ra = parent[c];   // its tree's root (k_cell_compress ran)
+        uint2 e0[5];
+        uint32_t e1[5], sh[5], wd[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {   // the rows of k_cgrid_hook
+            uint32_t pos;
+            if (r < 3) { pos = ma.w - plane + (uint32_t)(r - 1) * rowbits - 1u; wd[r] = 3u; }
+            else if (r == 3) { pos = ma.w - rowbits - 1u; wd[r] = 3u; }
+            else { pos = ma.w - 1u; wd[r] = 1u; }
+            sh[r] = pos & 31u;
+            e0[r] = cmap[pos >> 5];
+            e1[r] = cmap[(pos >> 5) + 1u].x;
+        }
+        uint32_t nid[13], rb[13];
+        int slot = 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            uint32_t bits = e0[r].x >> sh[r];
+            if (sh[r] + wd[r] > 32u) bits |= (e1[r] << 1) << (31u - sh[r]);
+            const uint32_t cnt = __popc(bits & ((1u << wd[r]) - 1u));
+            const uint32_t id0 = e0[r].y + __popc(e0[r].x & ((1u << sh[r]) - 1u));
+            const int w = r == 4 ? 1 : 3;
+#pragma unroll
+            for (int k = 0; k < w; ++k) {
+                nid[slot] = (uint32_t)k < cnt ? min(id0 + (uint32_t)k, nc - 1u) : c;
+                rb[slot] = parent[nid[slot]];
+                ++slot;
+            }
+        }
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 13; ++q) any |= rb[q] != ra;
+        if (!any) continue;
+        const uint32_t pa = prio[ra];
+#pragma unroll 1
+        for (int q = 0; q < 13; ++q) {
+            if (rb[q] == ra) continue;
+            const uint32_t pb = prio[rb[q]];
+            const uint32_t hi = pa > pb ? ra : rb[q], lo = pa > pb ? rb[q] : ra;
+            const unsigned long long key = ((unsigned long long)min(pa, pb) << 32) | lo;
+            if (key >= cand[hi]) continue;   // (a stale read only costs a pair test: the atomicMin decides)
+            const uint4 mb = slot_meta[nid[q]];
+            if (mb.y == 0u || mb.x + mb.y > c_n) continue;
+            if (lane_cells_hit(rec, ma.x, ma.y, mb.x, mb.y, r2)) atomicMin(cand + hi, key);
+        }
+    }
+}
+
+// parent[c] = the end of the candidate links that start at c's root (read-only links: no races; strictly falling priorities: no cycles)
+__global__ __launch_bounds__(kBlock) void k_cell_compress2(const Frame* frames) {
+    const Frame& F = frames[blockIdx.y];
+    const DevState* st = &F.st;
+    uint32_t* __restrict__ parent = F.parent;
+    const unsigned long long* __restrict__ cand = reinterpret_cast<const unsigned long long*>(F.cell_info.get());
+    if (cgrid_off(st) || st->debug_skip_union == 1u) return;
+    const uint32_t nc = st->n_cells;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+        uint32_t r = min(parent[c], nc - 1u);
+        bool moved = false;
+        for (uint32_t hops = 0; hops < nc; ++hops) {
+            const unsigned long long k = cand[r];
+            if (k == ~0ull) break;
+            r = min((uint32_t)k, nc - 1u); moved = true;
+        }
+        if (moved) parent[c] = r;
+    }
+}
+
 // Forward half of the 5x5x5 stencil (13 rows, 62 cells).  Neighbours whose parent word equals the
 // cell's are in its set already, and after hook + compress that is nearly all of them, so the common
 // case is made of two rounds of independent loads: the 13 row windows, then the parent words of
@@ -340,11 +384,11 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames, uin
     if (cgrid_off(st) || st->debug_skip_union == 1u) return;
     const bool scan_only = st->debug_skip_union == 2u;
     const bool list = fix_by_wave(st, single_frame);
-    const uint32_t nc = st->n_cells;
+    const uint32_t nc = st->n_cells, c_n = st->c_n, grid_cells = st->cmap_words * 32u;
     const uint32_t rowbits = st->c_rowbits, plane = st->c_plane;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
         const uint4 ma = slot_meta[c];
-        if (ma.y == 0u) continue;        // (as in k_cgrid_hook)
+        if (ma.y == 0u || ma.x + ma.y > c_n || ma.w >= grid_cells) continue;   // (as in k_cgrid_hook)
         const uint32_t pa = ld_agent(parent + c);
         // round 1: the windows of all rows.  Every load is issued before any is used and none sits under a
         // branch (the second word of a window is fetched whether it is needed or not).

@@ -351,7 +351,7 @@ struct HostOut {
     float* cloud;          // voxel cloud in st->out_layout
 };
 
-__device__ __forceinline__ void vt_true_grid(Frame& F, MinMaxPartial* s_p);
+__device__ __forceinline__ void box_true_grid(Frame& F, MinMaxPartial* s_p);
 
 __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t npass_csr) {
     __shared__ MinMaxPartial s_p[kBlock];   // (keys on the host's box: the first block reduces the tiles' bounds)
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t n
     }
     if (blockIdx.x == 0) {
         // a frame keyed against the host's box: every kernel that forms voxel keys is through, PCL's own min_b / div_b go into DevState
-        if (st->sbox && !st->err && !st->passthrough) { vt_true_grid(const_cast<Frame&>(F), s_p); __syncthreads(); }
+        if (st->sbox && !st->err && !st->passthrough) { box_true_grid(const_cast<Frame&>(F), s_p); __syncthreads(); }
         if (threadIdx.x == 0) *out.state = *st;
     }
     if (st->err) return;

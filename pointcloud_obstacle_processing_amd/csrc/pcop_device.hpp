@@ -8,13 +8,12 @@
 //    streaming path (batches of frames; no scattered global access anywhere):
 //     k_bin_hist              per 16384-point tile: counts of the coarse key bins (key >> cshift)
 //     k_bin_colsum, k_bin_plan  bins -> buckets of consecutive bins, at most kBucketCap points each
-//     k_bin_tilecnt, k_bin_colscan  per (tile, bucket): where the tile's points start inside the bucket
+//     k_bin_tilecnt           per (tile, bucket): the tile's points in the bucket (k_bin_scatter adds up the lower tiles itself)
 //     k_bin_scatter           ONE stable partition of packed 12-byte xyz records by bucket
 //     k_heavy_split           (only once a frame needed it) a coarse bin above a bucket, cut into buckets along the keys
-//     k_bucket_reduce         per bucket: occupancy bits in LDS -> local voxel ids, stable LDS counting
-//                             sort, one lane per voxel sums its run in order -> the bucket's centroids
-//     k_voxel_gather          buckets' voxel counts -> output ranks, M; centroids to their ranks (and, in a
-//                             chain frame on the dense cell grid, each marks its grid cell on the way)
+//     k_bucket_reduce         one wave per bucket: local voxel ids, stable LDS counting sort, one lane per voxel sums
+//                             its run in order; the buckets' voxel counts -> output ranks, M; centroids straight to
+//                             their ranks (and, in a chain frame on the dense cell grid, each marks its grid cell)
 //    sort path (single frames - the shorter chain of launches - and clouds the streaming path does not cover):
 //     k_radix_hist / k_table_scan / k_radix_scatter   (x passes) stable LSD radix partition of
 //                             packed xyz records by PCL's linear voxel index
@@ -72,7 +71,7 @@ constexpr uint32_t kBinTileSmall = 4096;
 constexpr uint32_t kBinTileLarge = 32768;       // (the tile tables count in 16 bits: no tile above 2^15 points)
 constexpr uint32_t kBinThreads = 1024;          // threads of k_bin_hist / k_bin_plan
 constexpr uint32_t kBinBitsMin = 11, kBinBitsMax = 14;   // coarse key bins per frame: 2^11 .. 2^14 (a host hint; any value gives the same result)
-constexpr uint32_t kBucketCap = 2048;           // points per bucket (k_bucket_reduce: 256 threads x 8 records, all in LDS)
+constexpr uint32_t kBucketCap = 2048;           // points per bucket (k_bucket_reduce: one wave x 32 records a lane, all in LDS)
 constexpr uint32_t kBucketCells = 1u << 17;     // grid cells a bucket may span (bits of its LDS occupancy map)
 constexpr uint32_t kHeavyMax = 4u * 2048u;       // points of a coarse bin that holds more than a bucket and is split by k_heavy_split (beyond: sort path)
 constexpr uint32_t kHeavyGroups = 16;           // ... into at most this many buckets
@@ -81,14 +80,6 @@ constexpr uint32_t kNbMin = 1024, kNbMax = 4096;   // buckets per frame a launch
 constexpr uint32_t kScatThreads = 512, kScatItems = 8, kScatChunk = kScatThreads * kScatItems;   // k_bin_scatter: a tile in chunks of 4096
 constexpr uint32_t kCmapCells = 1u << 24;       // dense cell grid: largest grid (cells, margins included) with an occupancy map
 constexpr uint32_t kCoarseBits = 1u << 20;      // room for the blocks of 4x4x4 cells of the largest grid (partial blocks at the ends of y and z included)
-// tiled voxel path (pcop_voxel_tiled.hpp)
-constexpr uint32_t kVtTile = 8192;              // points per block of k_vt_sort: a tile is sorted by bucket inside its own region of the records
-constexpr uint32_t kVtThreads = 512, kVtItems = kVtTile / kVtThreads;   // 16 records per thread, held in registers
-constexpr uint32_t kVtSampleRows = 4;           // k_vt_sample reads one row of 64 points in four: the bucket plan comes from a quarter of the cloud
-constexpr uint32_t kVtPlanCap = 1536;           // points up to which the plan merges small coarse bins into one bucket (the sample's estimate; a bin above it is a bucket of its own)
-constexpr uint32_t kVtMaxTiles = 128;           // tiles of a frame k_vt_accum provides for (a wave's piece table: two rows to a lane): 1 M points
-constexpr uint32_t kVtSpan = 256;               // voxel ids of a wave of k_vt_accum: four words each in LDS
-constexpr uint32_t kVtSpanMax = 4096;           // voxel keys a tiled bucket may span (wider than kVtSpan: ids by rank in an occupancy map)
 constexpr int kCellMargin = 3;                  // empty cells around the grid: 2 for the 5x5x5 stencil + 1 of slack (a centroid
                                                 // may round a hair outside the bounding box of its points)        // voxel key / id of a dropped (non-finite) point
 
@@ -126,9 +117,9 @@ enum ErrBits : uint32_t {
     kErrSorFew = 2048u,      // statistical outlier removal on fewer than mean_k + 1 points (the reference reads past its search result)
     kErrReplanCpath = 256u,  // the dense cell grid does not apply to this frame (grid too large)
     kErrReplanCtiles = 512u, // the occupancy scan of the dense cell grid was launched with too few tiles
-    kErrReplanBox = 4096u,   // tiled voxel path: a point lies outside the bounding box the keys were formed with (the box of earlier frames)
-    kErrReplanVt = 8192u,    // tiled voxel path: a bucket holds more points than the sample promised (or the frame does not fit the path)
-    kErrOrder = 16384u,      // tiled voxel path, checking build: a tile came out in the wrong order (LDS atomics not lane-ordered after all)
+    kErrReplanBox = 4096u,   // keys on the context's box: a point lies outside the box the keys were formed with (the box of earlier frames)
+    kErrStale = 8192u,       // dense cell grid: an occupancy flag no point of this frame set (scratch a given-up frame left behind): the host scrubs the flags and runs the batch again
+    kErrOrder = 16384u,      // the streamed partition's self-check: the two ways of ranking disagree (LDS atomics not lane-ordered after all)
 };
 
 enum FrameKind : uint32_t { kFrameChain = 0, kFrameVoxelOnly = 1, kFrameClusterOnly = 2 };
@@ -153,8 +144,8 @@ struct FrameArgs {
     DevPtr<const float> src_x, src_y, src_z;
     DevPtr<const uint32_t> n_dev;             // when set: the point count lives on the device (at most n): the cloud a previous kernel kept
     double sor_thr;                           // statistical outlier removal: mean + stddev_mul * sigma, formed by the host between the two halves of the node chain
-    // tiled voxel path: the voxel box the keys are formed with (a superset of every earlier frame's), the plan's bucket size in sampled points
-    uint32_t vt_on, plan_cap;                 // vt_on: 1 tiled path, 2 streaming path on the host's box (no k_minmax)
+    // keys on the context's box: the voxel box the keys are formed with (a superset of every earlier frame's)
+    uint32_t box_on, pad0;                    // box_on: 2 the keys of this batch are formed against the host's box (no k_minmax)
     int32_t box_lo[3];
     uint32_t box_dim[3];
     uint32_t spin_limit, pad1;                // bounded waits of the publish / look-back kernels: polls before a block gives up
@@ -204,14 +195,13 @@ struct DevState {
     int32_t  c0[3];         // cell coordinate of grid position 0 (margin included)
     uint32_t c_dim[3];      // grid size per axis, margins included
     uint32_t maxbin;        // streaming voxel path: points in the fullest coarse bin (the host tunes gbits with it)
-    // tiled voxel path
-    uint32_t vt;            // 1: this frame's voxel stage runs the tiled path (keys relative to the host's box until k_voxel_gather puts PCL's own grid here)
-    uint32_t plan_cap;      // k_bin_plan: points per bucket (in the units of the histogram it is given); 0: kBucketCap
-    uint32_t vt_nonfinite;  // non-finite points k_vt_sort / k_bin_hist dropped
+    // keys on the context's box
+    uint32_t box_nonfinite; // non-finite points the pass that took the bounds dropped
+    uint32_t pad1;
     uint32_t spin_limit;    // polls a block may make on a lower block's publish word before it gives the frame up (kErrInternal)
     uint32_t box_tile;      // keys on the host's box: points per tile of the pass that took the bounds (one MinMaxPartial each)
-    uint32_t sbox;          // 1: the voxel keys of this frame are formed against the host's box (tiled path, or the streaming path without its
-                            // bounds pass); k_voxel_gather / k_vt_scan put PCL's own grid here when the keys are done with
+    uint32_t sbox;          // 1: the voxel keys of this frame are formed against the host's box (no bounds pass); k_emit puts PCL's own
+                            // grid here when the keys are done with
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState layout");
 
@@ -244,7 +234,6 @@ struct Frame {
     DevPtr<uint4> binfo;              // [bucket]: {first record, records, first voxel key, voxel keys spanned}
     DevPtr<uint32_t> binsum;          // [coarse bin]: points of the frame in the bin
     DevPtr<uint16_t> tcnt;            // [bucket][tstride]: points of the tile in the bucket
-    DevPtr<uint32_t> tbase;           // [bucket][tstride]: points of the lower tiles in the bucket
     uint32_t tstride, cap;            // tiles a context provides for, rounded up to a multiple of 8; points a slot provides for
     DevPtr<float> h_aux;              // pinned host: per-point values a call hands to the host (mean neighbour distances)
     DevPtr<uint32_t> bucket_pub;      // [bucket]: its voxel count
@@ -433,7 +422,7 @@ struct CellMarker {
 
 // the kernels, by stage (each part opens namespace pcop itself)
 #include "pcop_voxel.hpp"
-#include "pcop_voxel_tiled.hpp"
+#include "pcop_voxel_box.hpp"
 #include "pcop_cells_hash.hpp"
 #include "pcop_cells_grid.hpp"
 #include "pcop_clusters.hpp"

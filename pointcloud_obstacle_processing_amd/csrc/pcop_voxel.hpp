@@ -582,9 +582,13 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 // after its sums are done; a lower tile never waits for a higher one and blocks are dispatched in
 // index order, so the lower tiles are always running or finished (the wait is bounded anyway).
 #ifndef PCOP_REDUCE_BPB
-#define PCOP_REDUCE_BPB 2
+#define PCOP_REDUCE_BPB 1
 #endif
-constexpr uint32_t kReduceBucketsPerBlock = PCOP_REDUCE_BPB;   // k_bucket_reduce: consecutive buckets per block (2: measured against 1, 3 and 4, tools/ab_build.sh)
+// k_bucket_reduce: consecutive buckets per block.  ONE: a bucket publishes its voxel count as soon as it has it and every bucket
+// waits for the counts of all lower ones, so a block's second bucket - which cannot publish before the block is through with its
+// first - would make every higher block wait for it, and that one for the block before: a chain through the whole frame
+// (measured with two: 6.9 ms a batch instead of 0.06).
+constexpr uint32_t kReduceBucketsPerBlock = PCOP_REDUCE_BPB;
 
 // mark_cells: a chain frame on the dense cell grid (set up by k_voxel_setup): every centroid marks its grid cell as it is
 // written, so the cell stage has no k_cell_mark launch (k_voxel_gather does the same on the streaming path).
@@ -713,14 +717,14 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 //   k_bin_colsum    : bin totals over the tiles
 //   k_bin_plan      : one block per frame: buckets = runs of consecutive bins with at most kBucketCap points and
 //                     kBucketCells cells each, packed greedily -> bin2bucket, binfo
-//   k_bin_tilecnt, k_bin_colscan : per (tile, bucket) the points of the lower tiles -> tbase
-//   k_bin_scatter   : ONE stable partition of packed 12-byte xyz records by bucket (peer masks through LDS,
-//                     per-wave counts, chunks of kScatChunk points staged in LDS so that stores are contiguous)
-//   k_bucket_reduce : a bucket lives in LDS: occupancy bits of its key range -> local voxel ids (rank of the key),
-//                     stable counting sort by id, one lane per voxel sums its run in order from 0.0f and divides
-//                     by float(count); the centroids stay at the bucket's place, the bucket publishes its voxel count
-//   k_voxel_gather  : (pcop_cells_grid.hpp) the voxels of the lower buckets added up -> output rank of the bucket's first
-//                     voxel, M; centroids to their ranks = voxel key order, grid cells marked on the way
+//   k_bin_tilecnt   : per (tile, bucket) the tile's points in the bucket -> tcnt (bucket-major)
+//   k_bin_scatter   : ONE stable partition of packed 12-byte xyz records by bucket (ranks from lane-ordered LDS atomics or peer
+//                     masks, per-wave counts, chunks of kScatChunk points staged in LDS so that stores are contiguous); a tile adds up
+//                     the counts of the lower tiles for itself
+//   k_bucket_reduce : ONE WAVE per bucket, the bucket in its registers and LDS: local voxel ids (the key itself, or its rank in an
+//                     occupancy map), stable counting sort by id, one lane per voxel sums its run in order from 0.0f and divides
+//                     by float(count); the voxels of the lower buckets added up (publish + look-back) -> output rank of the
+//                     bucket's first voxel, M; centroids straight to their ranks = voxel key order, grid cells marked on the way
 // Same float operations in the same order as the sort path.  No global atomics, no scattered global access: the
 // cloud is read three times (bounds, histogram, partition), written once and read once as 12-byte records.
 // Any bucket plan that respects the two limits gives the same result, so the host may tune gbits freely.
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
     uint4* __restrict__ binfo = F.binfo;
     uint32_t* __restrict__ bucket_pub = F.bucket_pub;
     if (stream_off(st)) return;
-    if (st->sbox && !st->vt && st->n_valid == 0u) {   // (k_bin_hist found nothing valid in the cloud: an empty output, as voxel_setup makes it)
+    if (st->sbox && st->n_valid == 0u) {   // (k_bin_hist found nothing valid in the cloud: an empty output, as voxel_setup makes it)
         if (threadIdx.x == 0) { st->nbuckets = 0u; finish_voxel(st, 0); }
         return;
     }
@@ -879,18 +883,14 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
     uint32_t maxbin = 0u;
 #pragma unroll
     for (int i = 0; i < NW; ++i) maxbin = max(maxbin, s_max[i]);
-    // The tiled path plans on a sample of the cloud (one point in kVtSampleRows): the capacity comes in the sample's units, and
-    // every segment becomes a bucket whether the sample saw points in it or not (the cloud may still have some there).
-    const bool vt = st->vt != 0u;
-    const uint32_t kCap = st->plan_cap ? st->plan_cap : kBucketCap;
-    if (threadIdx.x == 0) st->maxbin = vt ? maxbin * kVtSampleRows : maxbin;
-    const uint32_t bmax = min(G, (vt ? kVtSpanMax : kBucketCells) >> cs);   // bins a bucket may span
+    constexpr uint32_t kCap = kBucketCap;
+    if (threadIdx.x == 0) st->maxbin = maxbin;
+    const uint32_t bmax = min(G, kBucketCells >> cs);   // bins a bucket may span
     // A bin with more points than a bucket: finer bins are asked for; when there are none finer (a dense sheet of points
     // lying in a few rows of the key space) the bin becomes a bucket of its own - the window rule below does that by
     // itself - which k_heavy_split cuts into buckets along the keys before k_bucket_reduce sees it.
     const bool finest = st->gbits >= kBinBitsMax || cs == 0u;
-    // (the tiled path's reduce takes a bucket of any size: there the capacity only says how far small bins are merged)
-    if (bmax == 0u || (!vt && maxbin > kCap && !(finest && (*F.args).heavy_ok && maxbin <= kHeavyMax))) {
+    if (bmax == 0u || (maxbin > kCap && !(finest && (*F.args).heavy_ok && maxbin <= kHeavyMax))) {
         if (threadIdx.x == 0) atomicOr(&st->err, (uint32_t)kErrReplanBins);
         return;
     }
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
         for (int k = 0; k < kPerMax; ++k) {
             if ((uint32_t)k < per) {
                 if ((sbits >> k) & 1u) {
-                    if (vt || P(s_first[si + 1u]) != r) { fbits |= 1u << k; ++nfull; }
+                    if (P(s_first[si + 1u]) != r) { fbits |= 1u << k; ++nfull; }
                     ++si;
                 }
                 r += c[k];
@@ -971,11 +971,10 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_plan(Frame* frames) {
     const uint32_t bk0 = block_excl_scan_n<NW>(nfull, s_w, &nb);
     if (threadIdx.x == 0) {
         st->nbuckets = nb;
-        // (the tiled path keeps one row more than it has buckets: the tiles' totals)
-        if (nb + (vt ? 1u : 0u) > kNbMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
-        else if (nb + (vt ? 1u : 0u) > st->nb_cap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
+        if (nb > kNbMax) atomicOr(&st->err, (uint32_t)kErrReplanPath);
+        else if (nb > st->nb_cap) atomicOr(&st->err, (uint32_t)kErrReplanVcap);
     }
-    if (nb + (vt ? 1u : 0u) > kNbMax) return;
+    if (nb > kNbMax) return;
     PCOP_STAMP(F, 0, 4, 0);
     if (mine) {
         uint32_t si = seg0, bk = bk0, r = run0;
@@ -1071,42 +1070,6 @@ __global__ __launch_bounds__(kBlock) void k_bin_tilecnt(const Frame* frames) {
     }
 }
 
-// tbase[bucket][tile] = points of the lower tiles in the bucket: one wave per bucket, a lane takes eight tiles (one 16-byte
-// load), a wave scan joins the lanes; 512 tiles per round.
-__global__ __launch_bounds__(kBlock) void k_bin_colscan(const Frame* frames) {
-    const Frame& F = frames[blockIdx.y];
-    const DevState* st = &F.st;
-    const uint16_t* __restrict__ tcnt = F.tcnt;
-    uint32_t* __restrict__ tbase = F.tbase;
-    if (stream_off(st)) return;
-    const uint32_t b = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-    if (b >= st->nbuckets) return;
-    const uint32_t ntiles = (st->n_in + st->tile - 1u) / st->tile, ts = F.tstride;   // ts: a multiple of 8
-    const uint32_t ngroups = (ntiles + 7u) / 8u;
-    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(tcnt + (size_t)b * ts);
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(tbase + (size_t)b * ts);
-    uint32_t carry = 0u;
-    for (uint32_t g0 = 0; g0 < ngroups; g0 += kWave) {
-        const uint32_t g = g0 + lane_id();
-        const uint4 v = src[min(g, ngroups - 1u)];   // (entries past ntiles are never read by anyone: whatever they hold)
-        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-        uint32_t sum = 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sum += (wv[j] & 0xFFFFu) + (wv[j] >> 16);
-        if (g >= ngroups) sum = 0u;
-        const uint32_t incl = wave_incl_scan(sum);
-        uint32_t run = carry + incl - sum;
-        if (g < ngroups) {
-            uint32_t o[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { o[2 * j] = run; run += wv[j] & 0xFFFFu; o[2 * j + 1] = run; run += wv[j] >> 16; }
-            dst[2u * g] = make_uint4(o[0], o[1], o[2], o[3]);
-            dst[2u * g + 1u] = make_uint4(o[4], o[5], o[6], o[7]);
-        }
-        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-    }
-}
-
 // Peers of this lane's value among the active lanes of the wave, through two peer-mask words in LDS: word `a` of
 // m_lo and word `b` of m_hi, where (a, b) determines the value (a = its low 6 bits, b = its high bits shifted by a, so
 // that values with equal high bits still spread over the words of m_hi).  Lanes that share both words hold the same
@@ -1175,7 +1138,7 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames, uin
     DevState* st = &F.st;
     const uint16_t* __restrict__ bin2bucket = F.bin2bucket;
     const uint4* __restrict__ binfo = F.binfo;
-    const uint32_t* __restrict__ tbase = F.tbase;
+    const uint16_t* __restrict__ tcnt = F.tcnt;
     Rec3* __restrict__ out = reinterpret_cast<Rec3*>(alt ? F.rec_b.get() : F.rec_a.get());
     if (stream_off(st)) return;
     const uint32_t n = st->n_in, nchunks = st->tile / kScatChunk;
@@ -1195,8 +1158,29 @@ __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames, uin
     VoxelKey key; key.init(st);
     const uint32_t w = threadIdx.x / kWave, lane = lane_id();
     const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
-    // where this tile's points start in every bucket
-    for (uint32_t b = threadIdx.x; b < nbc; b += kScatThreads) cur[b] = b < nb ? binfo[b].x + tbase[(size_t)b * F.tstride + blockIdx.x] : 0u;
+    // where this tile's points start in every bucket: the bucket's first record + its points in the lower tiles (a row of tcnt is
+    // bucket-major: the lower tiles' 16-bit counts are one short contiguous run, eight to a 16-byte load - every block adds them up
+    // for itself rather than pay a kernel for the scan)
+    {
+        const uint32_t ts = F.tstride, ngroups = (blockIdx.x + 7u) / 8u;   // ts: a multiple of 8
+        for (uint32_t b = threadIdx.x; b < nbc; b += kScatThreads) {
+            uint32_t sum = 0u;
+            if (b < nb) {
+                const uint4* __restrict__ row = reinterpret_cast<const uint4*>(tcnt + (size_t)b * ts);
+                for (uint32_t g = 0; g < ngroups; ++g) {
+                    const uint4 v = row[g];
+                    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {   // tiles 8 g + 2 j and 8 g + 2 j + 1
+                        sum += (8u * g + 2u * j < blockIdx.x) ? (wv[j] & 0xFFFFu) : 0u;
+                        sum += (8u * g + 2u * j + 1u < blockIdx.x) ? (wv[j] >> 16) : 0u;
+                    }
+                }
+                sum += binfo[b].x;
+            }
+            cur[b] = sum;
+        }
+    }
     constexpr uint32_t pb = PB;
     unsigned long long* m_lo = s_match + w * kMatchWords;
     unsigned long long* m_hi = m_lo + 64u;
@@ -1331,7 +1315,7 @@ __global__ __launch_bounds__(kBlock) void k_rec_compare(Frame* frames, uint32_t 
 
 // A bucket with more than kBucketCap points (a single coarse bin, k_bin_plan) is cut into buckets that fit: counts of up
 // to kHeavySub equal key sub-ranges, sub-ranges packed greedily into groups of at most kBucketCap points, the records
-// partitioned by group - stably, so that index order survives - through the centroid planes (idle until k_voxel_gather)
+// partitioned by group - stably, so that index order survives - through the centroid planes (idle until k_bucket_reduce writes the centroids)
 // and written back over the bucket's records.  hsub[b][g] then describes group g the way binfo describes a bucket, and
 // k_bucket_reduce runs them one after the other.  One block per bucket; blocks of ordinary buckets return at once.
 __global__ __launch_bounds__(kBlock) void k_heavy_split(Frame* frames) {
@@ -1464,305 +1448,253 @@ __global__ __launch_bounds__(kBlock) void k_heavy_split(Frame* frames) {
     if (threadIdx.x == 0) F.hparts[b] = ng;
 }
 
-// TILED (the tiled voxel path, pcop_voxel_tiled.hpp): the bucket's records are not one run of rec_a but one PIECE per tile of
-// k_vt_sort, in tile order (= index order): pre[b][t] .. pre[b + 1][t] of tile t's output.  The block builds the piece table
-// (first record and first position of every piece: one scan), every thread finds the piece of each of its eight
-// positions - eight binary searches side by side, one LDS read each per round - and from there on the bucket is in
-// registers as on the streaming path.  The kernel publishes {first, records} in binfo[b] itself (first = the records of the
-// lower buckets over all tiles); a bucket above kBucketCap points (the sample's plan is an estimate) raises kErrReplanVt.
-template <bool ORDERED, bool TILED = false>   // ORDERED: as in k_bin_scatter
-__global__ __launch_bounds__(kBlock, TILED ? 3 : 1) void k_bucket_reduce(Frame* frames) {   // (TILED: three blocks to a CU, as its LDS allows)
-    constexpr uint32_t NW = kBlock / kWave;                    // 4 waves; a wave ranks 512 consecutive points of the bucket
-    constexpr uint32_t kItemsB = kBucketCap / kBlock;          // 8
-    constexpr uint32_t kBucketsPerBlock = kReduceBucketsPerBlock;
-    constexpr uint32_t kMapWords = kBucketCells / 32u;         // 4096
-    constexpr uint32_t kPerW = kMapWords / kBlock;             // at most 16 occupancy words per thread
-    constexpr uint32_t kPlane = kBucketCap + kBucketCap / 32u + 8u;   // a staged coordinate plane: slot s lives at s + (s >> 5)
+// ONE WAVE PER BUCKET.  Round 3's kernel gave a bucket to a block of four waves, which cost a barrier per phase (seven of them),
+// per-wave counters to join (16 KB of LDS) and 46 KB a block: three blocks to a CU, each a chain of phases none of which could
+// start before the slowest wave of the one before.  A bucket is at most 2048 records, 32 to a lane: here one wave holds all of
+// them in registers, ranks them with ONE counter per voxel id (a wave's LDS instructions execute in program order and, with
+// lane-ordered atomics, in lane order inside an instruction: the returned value of ds_add_rtn IS the record's place in its
+// voxel's run), turns the counters into run starts with a scan that never leaves the wave, stages the records in run order and
+// sums every run with a lane of its own.  No barrier anywhere, 28 KB of LDS a wave (five waves to a CU, all independent), and
+// what used to be the next kernel happens here as well: a bucket publishes its voxel count as soon as it has it, adds up the
+// counts of the buckets before it (lower blocks never wait on higher ones and are dispatched first; the wait is bounded) and
+// writes its centroids straight to their output ranks - voxel key order - marking each one's grid cell on the way.  The last
+// bucket knows M.  (k_voxel_gather is gone, and with it the trip of the centroids through the scratch records.)
+// A frame the voxel grid passed through (or gave no voxels) has no buckets: its cell stage sees the input cloud, marked here by
+// all blocks together.
+template <bool ORDERED>   // ORDERED: as in k_bin_scatter
+__global__ __launch_bounds__(kWave) void k_bucket_reduce(Frame* frames) {
+    constexpr uint32_t kSlots = kBucketCap / kWave;            // 32 records to a lane
+    constexpr uint32_t kMapWords = kBucketCells / 32u;         // 4096 occupancy words (a bucket that spans more voxel keys than it may have ids)
+    constexpr uint32_t kCntWords = kBucketCap / 2u;            // per voxel id a 16-bit count, then the start of its run (two ids to a word)
+    static_assert(kBucketCap * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
+    static_assert(kCntWords == 16u * kWave, "the scan gives a lane sixteen words");
     static_assert(kHeavyGroups <= 128u, "k_heavy_split matches groups on 7 bits");
-    static_assert(kPlane * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
-    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPlane * 12u];   // occupancy bits + running counts, then the staged records (three planes)
-    __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kBucketCap];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3; then the waves' places
-    __shared__ __attribute__((aligned(16))) uint16_t s_vs[kBucketCap + 8u];   // per occupied voxel id, in order: where its run starts in the staged bucket; then the end of the last run
-    __shared__ unsigned long long s_match[ORDERED ? 1u : NW * 96u];   // per wave: 64 + 32 peer-mask words (voxel ids below 2048)
-    __shared__ uint32_t s_w[kWavesPerBlock + 1];
-    __shared__ uint32_t s_src[TILED ? kVtMaxTiles : 1u];          // TILED, per piece: its first record in rec_a
-    __shared__ uint16_t s_dst[TILED ? kVtMaxTiles + 2u : 2u];     //                   its first position in the bucket (0xFFFF beyond the tiles)
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kBucketCap * 12u];   // occupancy bits + running counts, then the staged records (three planes)
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kCntWords + 4u];
+    __shared__ unsigned long long s_match[ORDERED ? 1u : 96u];   // 64 + 32 peer-mask words (voxel ids below 2048)
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
-    uint4* __restrict__ binfo = F.binfo;
+    if (st->err || st->kind == kFrameClusterOnly) return;
+    const bool cells = !cgrid_off(st);
+    const uint32_t lane = lane_id();
+    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
+    CellMarker mark;
+    if (cells) mark.init(st);
+    if (!(st->vpath && st->n_valid && !st->passthrough)) {
+        if (cells) {   // no buckets: the cell stage's cloud is the input (or nothing)
+            const bool from_in = st->c_from_input != 0;
+            const float* __restrict__ x = from_in ? st->src_x.get() : F.cen_x.get();
+            const float* __restrict__ y = from_in ? st->src_y.get() : F.cen_y.get();
+            const float* __restrict__ z = from_in ? st->src_z.get() : F.cen_z.get();
+            const uint32_t n = st->c_n;
+            for (uint32_t i = blockIdx.x * kWave + lane; i < n; i += gridDim.x * kWave) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
+        }
+        return;
+    }
+    const uint32_t nb = st->nbuckets;
+    const uint32_t b0 = blockIdx.x * kReduceBucketsPerBlock;
+    if (b0 >= nb) return;
+    const uint4* __restrict__ binfo = F.binfo;
     const Rec3* __restrict__ recs = reinterpret_cast<const Rec3*>(F.rec_a.get());
     uint32_t* __restrict__ bucket_pub = F.bucket_pub;
-    float4* __restrict__ scratch = F.rec_b;
-    if (TILED ? (voxel_stage_off(st) || !st->vt) : stream_off(st)) return;
-    const uint32_t nb = st->nbuckets;
-    // (TILED, measured: handing every XCD one contiguous eighth of the buckets - so that the cache lines neighbouring pieces share are
-    //  fetched by one L2 only - is slower, not faster: the buckets' costs fall along the key order and the XCDs end up unevenly loaded)
-    const uint32_t blk = blockIdx.x;
-    if (blk * kBucketsPerBlock >= nb) return;
+    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(s_mem);
     uint16_t* wpre = reinterpret_cast<uint16_t*>(s_mem + kMapWords * 4u);
-    float* stage_x = reinterpret_cast<float*>(s_mem); float* stage_y = stage_x + kPlane; float* stage_z = stage_y + kPlane;
-    const uint32_t w = threadIdx.x / kWave, lane = lane_id();
+    float* stage_x = reinterpret_cast<float*>(s_mem); float* stage_y = stage_x + kBucketCap; float* stage_z = stage_y + kBucketCap;
+    const uint16_t* start16 = reinterpret_cast<const uint16_t*>(s_cnt);
     VoxelKey key; key.init(st);
-    const uint32_t pbase = w * (kItemsB * kWave) + lane;   // position in the bucket = index order
-    // A block takes kBucketsPerBlock consecutive buckets, one after the other; the records of the next one are requested
-    // before the current one is worked on, so only the first bucket's load latency is exposed.
-    Rec3 rec[kItemsB], recn[kItemsB];
-    uint4 info_n = binfo[blk * kBucketsPerBlock];
-    // TILED: the rows of `pre` of a bucket (clamped, unconditional), then its piece table and {first, records} into info_n
-    constexpr uint32_t kPieces = TILED ? kVtMaxTiles / kBlock + 1u : 1u;
-    uint32_t ra[kPieces], re[kPieces];
-    uint32_t ntiles = 1u, tpad = 2u;
-    if constexpr (TILED) {
-        ntiles = (st->n_in + kVtTile - 1u) / kVtTile;
-        while (tpad < ntiles + 1u) tpad <<= 1;   // (<= kVtMaxTiles: the host keeps ntiles below it)
-    }
-    auto rows = [&](uint32_t bb) {
-        if constexpr (TILED) {
-            const uint16_t* __restrict__ pre = F.tcnt;
-            const uint32_t ts = F.tstride;
-#pragma unroll
-            for (uint32_t q = 0; q < kPieces; ++q) {
-                const uint32_t tc = min(threadIdx.x + q * kBlock, ntiles - 1u);
-                ra[q] = pre[(size_t)bb * ts + tc]; re[q] = pre[(size_t)(bb + 1u) * ts + tc];
+    const uint32_t spin_limit = st->spin_limit, out_cap = F.cap;
+    // voxels of the buckets before this block's first one: asked for once, after the block has published a count of its own
+    uint32_t before = 0u, run_nv = 0u;
+    bool have_before = false;
+    uint4 info_next = binfo[b0];
+    for (uint32_t it = 0; it < kReduceBucketsPerBlock; ++it) {
+        const uint32_t b = b0 + it;
+        if (b >= nb) break;
+        const uint4 info_b = info_next;   // {first record, records, first key, keys spanned}
+        if (it + 1u < kReduceBucketsPerBlock && b + 1u < nb) info_next = binfo[b + 1u];
+        // a heavy bucket comes as the buckets k_heavy_split cut it into, taken one after the other; their voxels follow each other
+        const bool heavy = info_b.y > kBucketCap;
+        const uint32_t nparts = heavy ? min(F.hparts[b], kHeavyGroups) : 1u;
+        uint32_t nv_acc = 0u;
+        bool failed = heavy && nparts == 0u;
+        for (uint32_t part = 0; part < nparts && !failed; ++part) {
+            uint4 info = info_b;
+            if (heavy) {
+                info = F.hsub[(size_t)b * kHeavyGroups + part];
+                if (info.y == 0u) { if (part + 1u == nparts && lane == 0) st_agent(bucket_pub + b, nv_acc + 1u); continue; }   // (a group of empty key sub-ranges at the end)
             }
-        }
-    };
-    auto table = [&]() {   // (every thread calls: two block scans)
-        if constexpr (TILED) {
-            uint32_t lsum = 0u, asum = 0u, len[kPieces];
+            const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
+            if (cnt == 0u || cnt > kBucketCap || span > kBucketCells || span == 0u) { failed = true; break; }   // never: k_bin_plan keeps both limits
+            // all records requested at once (clamped, unconditional: a load under a branch would be waited for at its join)
+            Rec3 rec[kSlots];
+            const uint32_t lastr = cnt - 1u;
 #pragma unroll
-            for (uint32_t q = 0; q < kPieces; ++q) {
-                const bool there = threadIdx.x + q * kBlock < ntiles;
-                len[q] = there ? re[q] - ra[q] : 0u;
-                lsum += len[q]; asum += there ? ra[q] : 0u;
+            for (uint32_t j = 0; j < kSlots; ++j) rec[j] = recs[info.x + min(j * kWave + lane, lastr)];
+            // A bucket whose ids would mostly be empty first ranks its occupied voxels through an occupancy map, so that every id has
+            // a run (the sums give a lane to an id); one that is well filled sorts by the voxel key itself.
+            const bool direct = span <= kBucketCap && (span <= 256u || span <= cnt);
+            const uint32_t words = (span + 31u) / 32u;
+            // (the LDS is cleared while the records are on their way)
+            {
+                uint4* c4 = reinterpret_cast<uint4*>(s_cnt) + lane * 4u;
+                const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+                c4[0] = z4; c4[1] = z4; c4[2] = z4; c4[3] = z4;
+                if (lane == 0) s_cnt[kCntWords] = 0u;
+                if (!direct) for (uint32_t i = lane; i < words; i += kWave) bitmap[i] = 0u;
+                if (!ORDERED) { s_match[lane] = 0ull; if (lane < 32u) s_match[64u + lane] = 0ull; }
             }
-            // (pieces are numbered t = thread + q * 256: a thread's pieces are not neighbours, so the scan runs per q)
-            uint32_t cnt_b = 0u, first_b = 0u;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t id[kSlots];   // low half: the voxel id (0xFFFF: no record here); high half: the record's place in its voxel's run
+            bool bad = false;
 #pragma unroll
-            for (uint32_t q = 0; q < kPieces; ++q) {
-                uint32_t tot;
-                const uint32_t ex = block_excl_scan(len[q], s_w, &tot);
-                const uint32_t t = threadIdx.x + q * kBlock;
-                if (t < tpad) { s_src[t] = t * kVtTile + ra[q]; s_dst[t] = t < ntiles ? (uint16_t)min(cnt_b + ex, 0xFFFEu) : (uint16_t)0xFFFFu; }
-                cnt_b += tot;
-                __syncthreads();
-                first_b += block_sum(t < ntiles ? ra[q] : 0u, s_w);
+            for (uint32_t j = 0; j < kSlots; ++j) {
+                const uint32_t lk = key(rec[j]) - key_lo;
+                const bool act = j * kWave + lane < cnt;
+                if (act && lk >= span) bad = true;
+                id[j] = (act && lk < span) ? lk : 0xFFFFFFFFu;
             }
-            (void)lsum; (void)asum;
-            info_n.x = first_b; info_n.y = cnt_b;
-            __syncthreads();
-        }
-    };
-    auto request = [&](Rec3* r, const uint4& inf) {
-        const uint32_t lastr = inf.y ? min(inf.y, kBucketCap) - 1u : 0u;
-        if constexpr (TILED) {
-            uint32_t lo[kItemsB], p[kItemsB];
+            if (__ballot(bad)) { failed = true; break; }
+            uint32_t nid = span;
+            if (!direct) {
 #pragma unroll
-            for (uint32_t j = 0; j < kItemsB; ++j) { p[j] = min(pbase + j * kWave, lastr); lo[j] = 0u; }
-            for (uint32_t h = tpad >> 1; h; h >>= 1) {
+                for (uint32_t j = 0; j < kSlots; ++j)
+                    if (id[j] != 0xFFFFFFFFu) atomicOr(&bitmap[id[j] >> 5], 1u << (id[j] & 31u));
+                __builtin_amdgcn_wave_barrier();
+                // running count of the occupied voxels: lane l owns the perw consecutive words from l * perw
+                const uint32_t perw = (words + kWave - 1u) / kWave;   // 1 .. 64
+                uint32_t c = 0u;
+                for (uint32_t k = 0; k < perw; ++k) { const uint32_t wi = lane * perw + k; c += wi < words ? __popc(bitmap[wi]) : 0u; }
+                const uint32_t incl = wave_incl_scan(c);
+                uint32_t run = incl - c;
+                for (uint32_t k = 0; k < perw; ++k) {
+                    const uint32_t wi = lane * perw + k;
+                    if (wi < words) { wpre[wi] = (uint16_t)run; run += __popc(bitmap[wi]); }
+                }
+                nid = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (uint32_t j = 0; j < kItemsB; ++j) lo[j] += ((uint32_t)s_dst[lo[j] + h] <= p[j]) ? h : 0u;
+                for (uint32_t j = 0; j < kSlots; ++j) {   // id = occupied voxels of the bucket before this one
+                    if (id[j] != 0xFFFFFFFFu) {
+                        const uint32_t wi = id[j] >> 5;
+                        id[j] = (uint32_t)wpre[wi] + __popc(bitmap[wi] & ((1u << (id[j] & 31u)) - 1u));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();   // the occupancy words are done with: the staging area may be written from here on
             }
+            // places inside the runs: steps in order, lanes in order
+            if constexpr (ORDERED) {
 #pragma unroll
-            for (uint32_t j = 0; j < kItemsB; ++j) r[j] = recs[s_src[lo[j]] + (p[j] - (uint32_t)s_dst[lo[j]])];
-        } else {
+                for (uint32_t j = 0; j < kSlots; ++j) {
+                    if (id[j] != 0xFFFFFFFFu) {
+                        const uint32_t sh = 16u * (id[j] & 1u);
+                        const uint32_t old = atomicAdd(&s_cnt[id[j] >> 1], 1u << sh);
+                        id[j] |= ((old >> sh) & 0xFFFFu) << 16;
+                    }
+                }
+            } else {
+                unsigned long long* m_lo = s_match;
+                unsigned long long* m_hi = s_match + 64u;
 #pragma unroll
-            for (uint32_t j = 0; j < kItemsB; ++j) r[j] = recs[inf.x + min(pbase + j * kWave, lastr)];   // clamped, unconditional
+                for (uint32_t j = 0; j < kSlots; ++j) {
+                    const bool act = id[j] != 0xFFFFFFFFu;
+                    const uint32_t d = act ? id[j] : 0u;
+                    const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 31u, act);   // d < 2048
+                    const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
+                    const uint32_t sh = 16u * (d & 1u);
+                    uint32_t old = 0u;
+                    if (act && lr == 0u) old = atomicAdd(&s_cnt[d >> 1], (uint32_t)__popcll(peers) << sh);   // (the leader adds for its peers; the wave is alone on these words)
+                    const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
+                    old = __shfl(old, leader, kWave);
+                    if (act) id[j] |= (((old >> sh) & 0xFFFFu) + lr) << 16;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // counts -> run starts: lane l owns the ids 32 l .. 32 l + 31 (sixteen words), one wave scan joins the lanes; the voxels
+            // (ids with a run) are counted on the way
+            uint32_t nvox;
+            {
+                uint4* c4 = reinterpret_cast<uint4*>(s_cnt) + lane * 4u;
+                const uint4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
+                uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                uint32_t tot = 0u, occ = 0u;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16; tot += lo + hi; occ += (lo ? 1u : 0u) + (hi ? 1u : 0u); }
+                const uint32_t incl = wave_incl_scan(tot | (occ << 16));   // (at most 2048 of either: no carry between the halves)
+                uint32_t run = (incl & 0xFFFFu) - tot;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16; w[k] = run | ((run + lo) << 16); run += lo + hi; }
+                c4[0] = make_uint4(w[0], w[1], w[2], w[3]); c4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                c4[2] = make_uint4(w[8], w[9], w[10], w[11]); c4[3] = make_uint4(w[12], w[13], w[14], w[15]);
+                const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+                nvox = all >> 16;
+                if (lane == 0) s_cnt[kCntWords] = all & 0xFFFFu;   // the end of the last run, for an id of kBucketCap - 1
+            }
+            // the bucket's voxel count goes out as early as it is known (a heavy bucket's: with its last part)
+            if (lane == 0 && (!heavy || part + 1u == nparts)) st_agent(bucket_pub + b, nv_acc + nvox + 1u);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (uint32_t j = 0; j < kSlots; ++j) {
+                if (id[j] != 0xFFFFFFFFu) {
+                    const uint32_t slot = (uint32_t)start16[id[j] & 0xFFFFu] + (id[j] >> 16);
+                    stage_x[slot] = rec[j].x; stage_y[slot] = rec[j].y; stage_z[slot] = rec[j].z;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (!have_before) {   // voxels of the lower buckets (a few hundred words; published early, needed only now)
+                uint32_t sum = 0u;
+                for (uint32_t i = lane; i < b0; i += kWave) {
+                    uint32_t v = ld_agent(bucket_pub + i), spins = 0u;
+                    while (v == 0u) {
+                        if (++spins > spin_limit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        v = ld_agent(bucket_pub + i);
+                    }
+                    sum += v - 1u;
+                }
+                before = wave_sum(sum);
+                have_before = true;
+            }
+            // one lane per id: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count); the v-th voxel of
+            // the frame goes to place v of the centroid planes and marks its grid cell
+            const uint32_t out0 = before + run_nv + nv_acc;
+            uint32_t occ_before = 0u;
+            for (uint32_t i0 = 0; i0 < nid; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                uint32_t s0 = 0u, e0 = 0u;
+                if (i < nid) { s0 = start16[i]; e0 = start16[i + 1u]; }
+                const bool has = e0 > s0;
+                const uint64_t hm = __ballot(has);
+                if (has) {
+                    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+                    for (uint32_t q = s0; q < e0; q += 4u) {   // four records requested at a time (clamped), added in order
+                        float vx[4], vy[4], vz[4];
+#pragma unroll
+                        for (uint32_t u = 0; u < 4u; ++u) { const uint32_t qq = min(q + u, e0 - 1u); vx[u] = stage_x[qq]; vy[u] = stage_y[qq]; vz[u] = stage_z[qq]; }
+#pragma unroll
+                        for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
+                    }
+                    const float fc = (float)(e0 - s0);
+                    const float ox = sx / fc, oy = sy / fc, oz = sz / fc;
+                    const uint32_t o = out0 + occ_before + (uint32_t)__popcll(hm & lanemask_lt());
+                    if (o < out_cap) {   // (always: M <= the points of the frame; a rank that went wrong must not become a wild store)
+                        cx[o] = ox; cy[o] = oy; cz[o] = oz;
+                        if (cells) pt_pos[o] = mark(st, cflag, ox, oy, oz);
+                    } else atomicOr(&st->err, (uint32_t)kErrInternal);
+                }
+                occ_before += (uint32_t)__popcll(hm);
+            }
+            nv_acc += nvox;
+            __builtin_amdgcn_wave_barrier();   // the next bucket clears and fills the same LDS
         }
-    };
-    if constexpr (TILED) { rows(blk * kBucketsPerBlock); table(); }
-    request(recn, info_n);
-    if constexpr (TILED) { if (blk * kBucketsPerBlock + 1u < nb) rows(blk * kBucketsPerBlock + 1u); }
-    for (uint32_t it = 0; it < kBucketsPerBlock; ++it) {
-    const uint32_t b = blk * kBucketsPerBlock + it;
-    if (b >= nb) break;
-    const uint4 info_b = info_n;   // {first record, records, first key, keys spanned}
-#pragma unroll
-    for (uint32_t j = 0; j < kItemsB; ++j) rec[j] = recn[j];
-    if (it + 1u < kBucketsPerBlock && b + 1u < nb) {
-        info_n = binfo[b + 1u];
-        if constexpr (TILED) table();   // (its rows came in while the bucket before was being set up)
-        request(recn, info_n);
-    }
-    // a heavy bucket comes as the buckets k_heavy_split cut it into, taken one after the other; their voxels follow each
-    // other in the bucket's part of the scratch records
-    const bool heavy = !TILED && info_b.y > kBucketCap;
-    const uint32_t nparts = heavy ? min(F.hparts[b], kHeavyGroups) : 1u;
-    uint32_t nv_acc = 0u;
-    bool failed = heavy && nparts == 0u;
-    if (TILED && info_b.y == 0u) {   // (a bucket the sample planned and the cloud left empty)
-        if (threadIdx.x == 0) { binfo[b] = make_uint4(info_b.x, 0u, info_b.z, info_b.w); bucket_pub[b] = 0u; }
-        continue;
-    }
-    for (uint32_t part = 0; part < nparts && !failed; ++part) {
-    uint4 info = info_b;
-    if (heavy) {
-        info = F.hsub[(size_t)b * kHeavyGroups + part];
-        if (info.y == 0u) continue;   // (a group of empty key sub-ranges at the end)
-        request(rec, info);
-    }
-    const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
-    // A bucket that spans at most kBucketCap cells sorts by the cell itself (ids of empty cells get empty runs);
-    // a wider one first ranks its occupied cells through an occupancy map, so that ids stay below the point count.
-    const bool direct = span <= kBucketCap;
-    const uint32_t words = (span + 31u) / 32u;
-    bool bad = cnt == 0u || cnt > kBucketCap || span > kBucketCells;   // never: k_bin_plan keeps both limits
-    uint32_t lk[kItemsB], id[kItemsB], rank[kItemsB];
-    bool act[kItemsB];
-    PCOP_STAMP(F, 2, 0, 150);
-    // (the LDS is cleared while the records are on their way)
-    if (!direct) for (uint32_t i = threadIdx.x; i < min(words, kMapWords); i += kBlock) bitmap[i] = 0u;
-    // ids stay below nidr (the cells spanned, or the points, rounded up to a multiple of the block): the per-id steps stop there
-    const uint32_t nidr = min(kBucketCap, ((direct ? span : cnt) + kBlock - 1u) / kBlock * kBlock);
-    for (uint32_t v = threadIdx.x; v < nidr; v += kBlock) { s_wc[v] = 0u; s_wc[kBucketCap + v] = 0u; }
-    if (!ORDERED) for (uint32_t i = threadIdx.x; i < NW * 96u; i += kBlock) s_match[i] = 0ull;
-#pragma unroll
-    for (uint32_t j = 0; j < kItemsB; ++j) {
-        lk[j] = key(rec[j]) - key_lo;
-        act[j] = !bad && pbase + j * kWave < cnt;
-        if (act[j] && lk[j] >= span) { bad = true; act[j] = false; }
-        id[j] = act[j] ? lk[j] : 0u;
-    }
-    bad = __syncthreads_or(bad ? 1 : 0) != 0;
-    PCOP_STAMP(F, 2, 1, 150);
-    if (bad) { failed = true; break; }
-    if (!direct) {
-#pragma unroll
-        for (uint32_t j = 0; j < kItemsB; ++j)
-            if (act[j]) atomicOr(&bitmap[lk[j] >> 5], 1u << (lk[j] & 31u));
-        __syncthreads();
-    PCOP_STAMP(F, 2, 2, 150);
-        // running count of the occupied cells: thread t owns the perw consecutive words from t * perw
-        const uint32_t perw = (words + kBlock - 1u) / kBlock;   // 1 .. 16
-        uint32_t wv[kPerW];
-        uint32_t c = 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < kPerW; ++k) {
-            const uint32_t wi = threadIdx.x * perw + k;
-            wv[k] = (k < perw && wi < words) ? bitmap[wi] : 0u;
-            c += __popc(wv[k]);
+        if (failed) {
+            if (lane == 0) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)kErrInternal); st_agent(bucket_pub + b, 1u); }
+            return;   // (the frame is given up: nothing after this kernel runs on it)
         }
-        uint32_t nocc;
-        uint32_t run = block_excl_scan(c, s_w, &nocc);
-#pragma unroll
-        for (uint32_t k = 0; k < kPerW; ++k) {
-            const uint32_t wi = threadIdx.x * perw + k;
-            if (k < perw && wi < words) wpre[wi] = (uint16_t)run;
-            run += __popc(wv[k]);
+        run_nv += nv_acc;
+        if (b == nb - 1u) {   // the last bucket knows M (its own look-back is done: it had a record to sum)
+            if (lane == 0) finish_voxel(st, before + run_nv);
         }
-        __syncthreads();
-    PCOP_STAMP(F, 2, 3, 150);
-#pragma unroll
-        for (uint32_t j = 0; j < kItemsB; ++j) {   // id = occupied cells of the bucket before this one
-            const uint32_t wi = act[j] ? lk[j] >> 5 : 0u;
-            id[j] = (uint32_t)wpre[wi] + __popc(bitmap[wi] & ((1u << (lk[j] & 31u)) - 1u));
-        }
-        __syncthreads();   // the occupancy words are done with: the staging area may be written from here on
-    PCOP_STAMP(F, 2, 4, 150);
-    }
-    // ranks inside (wave, id)
-    const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
-    if constexpr (ORDERED) {
-#pragma unroll
-        for (uint32_t j = 0; j < kItemsB; ++j) {
-            uint32_t old = 0u;
-            if (act[j]) old = atomicAdd(&s_wc[wword * kBucketCap + id[j]], 1u << wshift);
-            rank[j] = (old >> wshift) & 0xFFFFu;
-        }
-    } else {
-    unsigned long long* m_lo = s_match + w * 96u;
-    unsigned long long* m_hi = m_lo + 64u;
-#pragma unroll
-    for (uint32_t j = 0; j < kItemsB; ++j) {
-        const uint32_t d = id[j];
-        const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 31u, act[j]);   // d < 2048
-        const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
-        uint32_t old = 0u;
-        if (act[j] && lr == 0u) old = atomicAdd(&s_wc[wword * kBucketCap + d], (uint32_t)__popcll(peers) << wshift);
-        const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
-        old = __shfl(old, leader, kWave);
-        rank[j] = ((old >> wshift) & 0xFFFFu) + lr;
-    }
-    }
-    __syncthreads();
-    PCOP_STAMP(F, 2, 5, 150);
-    // Thread t owns ids 8 t .. 8 t + 7 (two 16-byte reads per count plane): points per id, then - after one scan over the
-    // block that carries the points in its low half and the occupied ids in its high half - every wave's place for every
-    // id (written back over the counts: the staging step then needs one word per record), and the run starts of the
-    // OCCUPIED ids in order (s_vs), so that the sums below give every lane a voxel.
-    uint32_t nvox = 0u;
-    {
-        const bool mine = threadIdx.x * kItemsB < nidr;
-        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-        const uint4* wc4 = reinterpret_cast<const uint4*>(s_wc);
-        const uint4 a0 = mine ? wc4[threadIdx.x * 2u] : z4, a1 = mine ? wc4[threadIdx.x * 2u + 1u] : z4;
-        const uint4 q0 = mine ? wc4[kBucketCap / 4u + threadIdx.x * 2u] : z4, q1 = mine ? wc4[kBucketCap / 4u + threadIdx.x * 2u + 1u] : z4;
-        // cw[2 q] = the word of waves 0, 1 for id 8 t + q, cw[2 q + 1] = that of waves 2, 3
-        uint32_t cw[16] = {a0.x, q0.x, a0.y, q0.y, a0.z, q0.z, a0.w, q0.w, a1.x, q1.x, a1.y, q1.y, a1.z, q1.z, a1.w, q1.w};
-        uint32_t tsum = 0u;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t c = (cw[2 * q] & 0xFFFFu) + (cw[2 * q] >> 16) + (cw[2 * q + 1] & 0xFFFFu) + (cw[2 * q + 1] >> 16);
-            tsum += c + (c ? 0x10000u : 0u);
-        }
-        uint32_t ttot;
-        uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
-        nvox = ttot >> 16;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t c0 = cw[2 * q] & 0xFFFFu, c1 = cw[2 * q] >> 16, c2 = cw[2 * q + 1] & 0xFFFFu, c3 = cw[2 * q + 1] >> 16;
-            const uint32_t c = c0 + c1 + c2 + c3;
-            const uint32_t r = srun & 0xFFFFu;
-            if (c) s_vs[srun >> 16] = (uint16_t)r;
-            cw[2 * q] = r | ((r + c0) << 16);
-            cw[2 * q + 1] = (r + c0 + c1) | ((r + c0 + c1 + c2) << 16);
-            srun += c + (c ? 0x10000u : 0u);
-        }
-        if (mine) {
-            uint4* wo4 = reinterpret_cast<uint4*>(s_wc);
-            wo4[threadIdx.x * 2u] = make_uint4(cw[0], cw[2], cw[4], cw[6]); wo4[threadIdx.x * 2u + 1u] = make_uint4(cw[8], cw[10], cw[12], cw[14]);
-            wo4[kBucketCap / 4u + threadIdx.x * 2u] = make_uint4(cw[1], cw[3], cw[5], cw[7]); wo4[kBucketCap / 4u + threadIdx.x * 2u + 1u] = make_uint4(cw[9], cw[11], cw[13], cw[15]);
-        }
-        if (threadIdx.x == 0) s_vs[nvox] = (uint16_t)(ttot & 0xFFFFu);
-    }
-    __syncthreads();
-    PCOP_STAMP(F, 2, 7, 150);
-#pragma unroll
-    for (uint32_t j = 0; j < kItemsB; ++j) {
-        if (act[j]) {
-            const uint32_t slot = ((s_wc[wword * kBucketCap + id[j]] >> wshift) & 0xFFFFu) + rank[j];
-            const uint32_t ps = slot + (slot >> 5);
-            stage_x[ps] = rec[j].x; stage_y[ps] = rec[j].y; stage_z[ps] = rec[j].z;
-        }
-    }
-    __syncthreads();
-    PCOP_STAMP(F, 2, 8, 150);
-    // one lane per VOXEL: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count).  The centroid
-    // of the bucket's v-th voxel goes to place (first record of the bucket + v) of the scratch records: a bucket has at
-    // least as many records as voxels, so the places of different buckets do not meet; k_voxel_gather moves them to their ranks.
-    for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
-        const uint32_t s0 = s_vs[v], e0 = s_vs[v + 1u];
-        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        for (uint32_t q = s0; q < e0; q += 4u) {   // four records requested at a time (clamped), added in order
-            float vx[4], vy[4], vz[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) { const uint32_t qq = min(q + u, e0 - 1u), ps = qq + (qq >> 5); vx[u] = stage_x[ps]; vy[u] = stage_y[ps]; vz[u] = stage_z[ps]; }
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
-        }
-        const float fc = (float)(e0 - s0);
-        scratch[info_b.x + nv_acc + v] = make_float4(sx / fc, sy / fc, sz / fc, 0.0f);
-    }
-    nv_acc += nvox;
-    PCOP_STAMP(F, 2, 20, 150);
-    __syncthreads();   // the next bucket clears and fills the same LDS
-    }
-    if (threadIdx.x == 0) {   // k_voxel_gather adds the counts up to output ranks
-        if (failed) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)(TILED ? kErrReplanVt : kErrInternal)); bucket_pub[b] = 0u; }   // (TILED: more points than the sample promised)
-        else bucket_pub[b] = nv_acc;
-        if (TILED) binfo[b] = make_uint4(info_b.x, failed ? 0u : info_b.y, info_b.z, info_b.w);   // where k_voxel_gather finds the bucket's centroids
-    }
     }
 }
 
@@ -1789,7 +1721,7 @@ __global__ __launch_bounds__(kBlock) void k_occ_scan(Frame* frames) {
     uint32_t* __restrict__ otile = F.ctile.get();
     // Runs whenever the marking kernel ran (the replan bits this kernel raises itself must not stop its
     // other tiles: every tile has flag bytes to turn back to zero).
-    const uint32_t own = (uint32_t)(kErrReplanCpath | kErrReplanCtiles | kErrInternal | kErrNonFinite);
+    const uint32_t own = (uint32_t)(kErrReplanCpath | kErrReplanCtiles | kErrInternal | kErrNonFinite | kErrStale);
     if ((st->err & ~own) || st->trivial || st->kind == kFrameVoxelOnly || !st->cpath) return;
     const uint32_t words = st->cmap_words;
     if (blockIdx.x == 0 && threadIdx.x == 0 && words > gridDim.x * kVmapTile)   // the host sized this grid from the previous frame
@@ -1845,7 +1777,12 @@ __global__ __launch_bounds__(kBlock) void k_occ_scan(Frame* frames) {
         if (j < cnt) omap[base + j] = make_uint2(w[k], run);
         run += __popc(w[k]);
     }
-    if (threadIdx.x == 0 && base + kVmapTile >= words) st->n_cells = before + tot;   // the last tile
+    if (threadIdx.x == 0 && base + kVmapTile >= words) {   // the last tile
+        st->n_cells = before + tot;
+        // every point flags one cell: more cells than points means flag bytes that were set before the frame began (cell ids would
+        // leave the per-cell arrays): the frame is given up before anything is indexed by them (kErrStale: scrub and run again)
+        if (before + tot > st->c_n) atomicOr(&st->err, (uint32_t)kErrStale);
+    }
 }
 
 }  // namespace pcop

@@ -4,11 +4,15 @@
 //
 //   pcop_node --params params.yaml --cloud in.pc2 --out outdir [--device 0] [--stage-api] [--occupancy] [--sor] [--node-order]
 //   pcop_node --params params.yaml --cloud in.pc2 --out outdir --gpus G [--same-gpu] [--frames F] [--batch B]
+//   pcop_node --params params.yaml --cloud in.pc2 --gpus G --bench [--frames F] [--batch B]
 //
 // --gpus G runs F frames (frame i = the cloud without its last i * (N / 4F) points, so that no two are alike) through the
 // C++ pool of host/pcop_pool.hpp: one feeder thread and one context per GPU, frame f on GPU f mod G, the parameters broadcast
 // from rank 0 (RCCL), results in frame order; writes pool_frame_<i>.txt (cluster indices) and pool_frame_<i>.vox (float32
 // xyz of the voxel cloud).  --same-gpu maps every worker to device 0 (rehearsal of G > 1 on a one-GPU box).
+// --bench (with --gpus) measures the pool instead of writing files: F frames of the whole cloud, each written straight into a
+// pinned staging slot the pool hands out (no copy on the caller's side), results taken as they come; prints one JSON line with
+// frames/s from host memory (the PCIe-inclusive rate: 12 bytes a point cross the bus inside the timed region).
 //
 // --node-order (frame mode) runs the node's own order in one call that keeps every intermediate cloud on the GPU:
 // bounds filter + occupancy binning -> voxel grid -> statistical outlier removal -> RANSAC plane removal -> clusters
@@ -48,7 +52,7 @@ static void write_indices(const std::string& path, const std::vector<PointIndice
 int main(int argc, char** argv) {
     std::string params_path, cloud_path, out_dir = ".";
     int device = 0, gpus = 0, frames = 8, batch = 4;
-    bool same_gpu = false;
+    bool same_gpu = false, bench = false;
     bool stage_api = false, occupancy = false, sor = false, node_order = false, planes = true;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -60,6 +64,7 @@ int main(int argc, char** argv) {
         else if (a == "--frames" && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (a == "--batch" && i + 1 < argc) batch = std::atoi(argv[++i]);
         else if (a == "--same-gpu") same_gpu = true;
+        else if (a == "--bench") bench = true;
         else if (a == "--stage-api") stage_api = true;
         else if (a == "--occupancy") occupancy = true;
         else if (a == "--sor") sor = true;
@@ -84,6 +89,7 @@ int main(int argc, char** argv) {
             pcop_params pp{};
             pp.leaf = prm.downsample_size; pp.tol = prm.euc_cluster_tolerance; pp.min_cluster = prm.euc_min_cluster_size;
             pp.max_cluster = prm.euc_max_cluster_size; pp.publish_clouds = 1;
+            if (bench) pp.publish_clouds = 0;
             GpuPool pool(gpus, std::max<size_t>(n, 1024), batch, pp, same_gpu);
             if (!pool.ok()) { std::fprintf(stderr, "pool: %s\n", pool.error().c_str()); return 1; }
             for (int g = 0; g < pool.gpus(); ++g) {   // every worker must hold rank 0's struct, bit for bit
@@ -91,15 +97,55 @@ int main(int argc, char** argv) {
                 if (std::memcmp(&q, &pp, sizeof(pcop_params)) != 0) { std::fprintf(stderr, "pool: worker %d did not receive the parameters\n", g); return 1; }
             }
             frames = std::max(1, frames);
+            if (bench) {   // throughput of the pool from host memory: frames filled in place, nothing written to disk
+                std::vector<float> soa(3 * n);
+                for (size_t k = 0; k < n; ++k) { soa[k] = cloud.points[k].x; soa[n + k] = cloud.points[k].y; soa[2 * n + k] = cloud.points[k].z; }
+                size_t got = 0, voxels = 0, clusters = 0;
+                int bad = 0;
+                auto take = [&]() -> bool {
+                    PoolResult r;
+                    if (!pool.next(&r)) return false;
+                    if (r.status) { if (!bad) std::fprintf(stderr, "frame %llu on worker %d: %s (%s)\n", (unsigned long long)r.frame, r.gpu, pcop_status_string(r.status), r.error.c_str()); bad = 1; }
+                    voxels = (size_t)r.num_voxels; clusters = r.offsets.empty() ? 0 : r.offsets.size() - 1;
+                    ++got;
+                    return true;
+                };
+                const int inflight = 3 * batch * pool.gpus();
+                // warm-up: one round of every slot
+                size_t sent = 0;
+                auto push = [&](int count) {
+                    for (int i = 0; i < count && !bad; ++i) {
+                        float* dst = pool.acquire();
+                        if (!dst) { bad = 1; break; }
+                        std::memcpy(dst, soa.data(), 3 * n * sizeof(float));
+                        if (!pool.commit(n)) { bad = 1; break; }
+                        ++sent;
+                        while (!bad && sent - got > (size_t)inflight) take();
+                    }
+                };
+                push(inflight);
+                while (got < sent && take()) {}
+                const auto b0 = std::chrono::steady_clock::now();
+                const size_t before = got;
+                push(frames);
+                while (got < sent && take()) {}
+                const double bdt = std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
+                if (bad) { std::fprintf(stderr, "pool bench failed (%s)\n", pool.error().c_str()); return 1; }
+                std::printf("{\"pool_bench\": {\"gpus\": %d, \"same_gpu\": %s, \"batch\": %d, \"contexts_per_gpu\": 2, \"frames\": %zu, \"points_per_frame\": %zu, \"seconds\": %.6f, "
+                            "\"frames_per_s\": %.1f, \"pcie_GBs\": %.2f, \"voxels\": %zu, \"clusters\": %zu, \"input\": \"host memory, written in place into pinned staging (acquire / commit)\", \"params_by\": \"%s\"}}\n",
+                            pool.gpus(), same_gpu ? "true" : "false", batch, got - before, n, bdt, (got - before) / bdt, (got - before) / bdt * 12.0 * n / 1e9, voxels, clusters, pool.broadcast_kind());
+                return 0;
+            }
             const size_t cut = n / (4u * (size_t)frames);
             std::vector<float> soa;
             const auto t0 = std::chrono::steady_clock::now();
             size_t done = 0;
+            int failed = 0;   // (an error is remembered and returned from main once the pool has been drained: its destructor joins the workers)
             auto drain_one = [&]() -> bool {
                 PoolResult r;
                 if (!pool.next(&r)) return false;
-                if (r.status) { std::fprintf(stderr, "frame %llu on worker %d: %s (%s)\n", (unsigned long long)r.frame, r.gpu, pcop_status_string(r.status), r.error.c_str()); std::exit(1); }
-                if (r.gpu != (int)(r.frame % (uint64_t)pool.gpus())) { std::fprintf(stderr, "frame %llu ran on worker %d\n", (unsigned long long)r.frame, r.gpu); std::exit(1); }
+                if (r.status) { std::fprintf(stderr, "frame %llu on worker %d: %s (%s)\n", (unsigned long long)r.frame, r.gpu, pcop_status_string(r.status), r.error.c_str()); failed = 1; ++done; return true; }
+                if (r.gpu != (int)(r.frame % (uint64_t)pool.gpus())) { std::fprintf(stderr, "frame %llu ran on worker %d\n", (unsigned long long)r.frame, r.gpu); failed = 1; ++done; return true; }
                 std::vector<PointIndices> clusters(r.offsets.size() - 1);
                 for (size_t c = 0; c + 1 < r.offsets.size(); ++c) clusters[c].indices.assign(r.indices.begin() + r.offsets[c], r.indices.begin() + r.offsets[c + 1]);
                 write_indices(out_dir + "/pool_frame_" + std::to_string(r.frame) + ".txt", clusters);
@@ -113,9 +159,10 @@ int main(int argc, char** argv) {
                 soa.resize(3 * ni);
                 for (size_t k = 0; k < ni; ++k) { soa[k] = cloud.points[k].x; soa[ni + k] = cloud.points[k].y; soa[2 * ni + k] = cloud.points[k].z; }
                 if (!pool.submit(soa.data(), ni)) { std::fprintf(stderr, "pool: submit failed (%s)\n", pool.error().c_str()); return 1; }
-                while ((size_t)i + 1 - done > (size_t)(2 * batch * pool.gpus())) drain_one();   // (results are taken as they come, so that the staging never fills)
+                while ((size_t)i + 1 - done > (size_t)(3 * batch * pool.gpus())) drain_one();   // (results are taken as they come, so that the staging never fills)
             }
             while (drain_one()) {}
+            if (failed) return 1;
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::printf("pool: %d worker(s)%s, batch %d, %zu frames in %.3f s (%.1f frames/s, host-memory input), parameters by %s\n", pool.gpus(),
                         same_gpu ? " on one device" : "", batch, done, dt, done / dt, pool.broadcast_kind());

@@ -3,10 +3,17 @@
 //
 // The hot path is embarrassingly frame-parallel (a frame touches no other frame's data: od.cpp:699-797, the accumulator
 // is cleared at od.cpp:926), so the pool shards by frame: frame f goes to GPU f mod G.  Per GPU there is one FEEDER
-// THREAD that owns everything of that GPU - its pcop context (created with max_frames = batch), its pinned staging
+// THREAD that owns everything of that GPU - TWO pcop contexts (created with max_frames = batch), its pinned staging
 // buffers (allocated by the thread itself, so that first touch puts them on the thread's NUMA node) and its queue.
+// The thread queues batch k + 1 on one context (host-to-device copies and kernels are asynchronous) before it collects
+// batch k from the other: the copy of one batch runs under the kernels of the other, which is what keeps a GPU fed from
+// host memory.  A caller fills a staging slot IN PLACE (acquire / commit: no copy on the caller's thread; submit() is the
+// convenience form with one).
 // The only bytes that cross GPUs are the 32-byte pcop_params: rank 0's struct is broadcast with ncclBroadcast (RCCL)
 // when the pool starts; there is no data-path collective.  Results come back in frame order.
+// Start-up is all-or-nothing: every worker finishes the steps that can fail (device, staging, stream, contexts) and the
+// workers agree on the outcome BEFORE anyone enters the collective, so a worker that fails cannot leave the others
+// waiting in a broadcast it never joins.
 //
 // `same_gpu` maps every worker to one device (a one-GPU box rehearsing G > 1): RCCL cannot put two ranks of one
 // process on one device, so that mode hands the struct over in host memory instead and says so in broadcast_kind().
@@ -52,9 +59,12 @@ public:
     const char* broadcast_kind() const { return bcast_; }
     pcop_params params_of(int worker) const;          // what the worker ended up with (tests)
 
-    // One frame: n points, XYZ SoA planes in host memory (x[n] y[n] z[n]).  The data is copied into the worker's pinned
-    // staging before this returns.  Frames are numbered 0, 1, 2, ... in submission order; frame f goes to worker f mod G.
-    // Blocks while that worker's staging is full.
+    // One frame, filled in place: acquire() hands out the pinned staging slot of the NEXT frame (room for max_points points;
+    // blocks while that frame's worker has none free), the caller writes XYZ SoA planes x[n] y[n] z[n] into it, commit(n) queues
+    // it.  Frames are numbered 0, 1, 2, ... in commit order; frame f goes to worker f mod G.  One acquire per commit.
+    float* acquire();
+    bool commit(size_t n);
+    // The same with a copy: n points, planes in the caller's own memory.
     bool submit(const float* xyz_soa, size_t n);
     // The next result in frame order (blocks until it is there); false once every submitted frame has been handed out.
     bool next(PoolResult* out);
@@ -73,6 +83,11 @@ private:
         bool stop = false, ready = false, failed = false;
         std::string error;
     };
+    // start-up agreement: workers through their fallible set-up, and how many of them failed
+    std::mutex smu_;
+    std::condition_variable scv_;
+    int setup_done_ = 0, setup_failed_ = 0;
+    int acquired_slot_ = -1;                  // the slot acquire() handed out for frame submitted_
     void run(Worker* w);
     void deliver(PoolResult&& r);
 

@@ -1,5 +1,5 @@
-"""The streaming voxel path with its keys formed against the context's box (no bounds pass: csrc/pcop_voxel_tiled.hpp,
-k_vt_setup mode 2 + bin_hist_on_box) against the CPU oracle, through the C ABI.
+"""The streaming voxel path with its keys formed against the context's box (no bounds pass: csrc/pcop_voxel_box.hpp,
+k_box_setup mode 2 + bin_hist_on_box) against the CPU oracle, through the C ABI.
 
 The first batch of a context (or after a new leaf size) runs k_minmax and leaves a box; from then on k_bin_hist takes the true
 bounds on its way and checks every point against the box.  A point outside sends the batch back through the bounds pass.
@@ -58,7 +58,7 @@ def test_box_path_matches_oracle(capi, oracle):
         seen.append(int(st.sbox))
         lo, div = grid_of(clouds[0], p["leaf"])
         assert list(st.min_b) == lo and list(st.div_b) == div
-        assert st.n_valid == len(clouds[0]) and st.passthrough == 0 and st.vt == 0
+        assert st.n_valid == len(clouds[0]) and st.passthrough == 0
     assert seen == [0, 1, 1], seen
     c.close()
 

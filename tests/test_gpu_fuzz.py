@@ -31,7 +31,7 @@ def test_campaign_segment_that_left_occupancy_flags_behind():
     assert "mismatches 0" in out.stdout and "DIRTY" not in out.stdout
 
 
-@pytest.mark.parametrize("env", [{}, {"PCOP_VOXEL_TILED": "1"}], ids=["default", "tiled"])
+@pytest.mark.parametrize("env", [{}, {"PCOP_VOXEL_BOX": "0"}], ids=["default", "bounds-pass"])
 def test_batches_campaign(env):
     """tests/tools/fuzz_batches.py: batches of two to five unlike frames on one long-lived context, parameters changing now and
     then, frames outside the context's box, NaN holes, empty frames; flags and cell tables of every slot checked after every batch."""

@@ -672,6 +672,60 @@ def test_error_frame_leaves_no_marks_behind(capi, oracle):
     c.close()
 
 
+def _poke_flags(capi, c, name, positions):
+    """Fault injection: occupancy flag bytes set behind the library's back (what a given-up frame could leave behind)."""
+    import ctypes as C
+    p, b = C.c_void_p(), C.c_size_t()
+    c._chk(c.lib.pcop_debug_buffer(c.h, name.encode(), C.byref(p), C.byref(b)))
+    one = np.ones(1, dtype=np.uint8)
+    for pos in positions:
+        assert pos < b.value
+        c._chk(c.lib.pcop_dev_upload(c.h, C.c_void_p(p.value + int(pos)), one.ctypes.data, 1))
+
+
+def test_stale_occupancy_flags_cost_a_rerun_not_a_fault(capi, oracle):
+    """The dense cell grid relies on 16 MiB of flag bytes being all zero between frames.  A byte that is not (poked here) used to
+    give a cell without points - cell ids shifted, per-cell arrays indexed past what the frame owns.  Now the frame that meets it
+    raises kErrStale before anything is indexed by the ids, the host scrubs the flags and runs the batch again: oracle-identical
+    results, one counted re-run, no fault."""
+    p = synth.params_of("C1")
+    pts = synth.make_cloud("C1")
+    ref = oracle.process_xyz(pts, **p)
+    # (a) one flag inside the grid (position 3: the margin of the first row - no point ever lies there), single frames
+    c = capi.Context(len(pts))
+    c.set_params(publish_clouds=1, **p)
+    got = c.process_xyz(pts)
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    assert c.debug_counter("stale_reruns") == 0
+    _poke_flags(capi, c, "cflag", [3])
+    got = c.process_xyz(pts)
+    assert_same_cloud(got["voxel_xyz"], ref["voxel_xyz"])
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    assert c.debug_counter("stale_reruns") == 1
+    got = c.process_xyz(pts)
+    assert_same_clusters(got["offsets"], got["indices"], ref["offsets"], ref["indices"])
+    assert c.debug_counter("stale_reruns") == 1
+    assert not c.debug_buffer("cflag", np.uint8, 1 << 24).any()
+    c.close()
+    # (b) more stale flags than the frame has points (cell ids would leave the per-cell arrays), in slot 1 of a batch of three
+    tiny = synth.make_cloud("C1", n=300, seed=9)
+    rt = oracle.process_xyz(tiny, **p)
+    c = capi.Context(1024, max_frames=3)
+    c.set_params(publish_clouds=1, **p)
+    c.submit_batch_host([tiny, tiny, tiny])
+    c.wait_batch()
+    _poke_flags(capi, c, "cflag@1", list(range(3, 9000, 2)))
+    for rep in range(2):
+        c.submit_batch_host([tiny, tiny, tiny])
+        for g in c.wait_batch():
+            assert_same_cloud(g["voxel_xyz"], rt["voxel_xyz"])
+            assert_same_clusters(g["offsets"], g["indices"], rt["offsets"], rt["indices"])
+    assert c.debug_counter("stale_reruns") == 1
+    for k in range(3):
+        assert not c.debug_buffer("cflag@%d" % k, np.uint8, 1 << 24).any()
+    c.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # C5 at full size (BASELINE.json configs[4]): 5,000,000 points, leaf 0.01 m, tolerance 0.05 m
 # ---------------------------------------------------------------------------------------------
