@@ -158,9 +158,10 @@ struct pcop_ctx {
     // per cell; when cells are crowded (large tolerance / tiny leaf) the hash-table kernels, which put a whole wave
     // on a cell, are faster.  Chosen from the previous batch's points per cell; either choice gives the same result.
     bool crowded_cells = false;
-    // A second hook round at tree level (k_cgrid_hook2) before the union: pays when a frame has so many cells that the first round
-    // leaves the union kernel hundreds of thousands of trees to merge (C5); costs two launches.  Chosen from the previous batch's
-    // cells (PCOP_HOOK2=0|1 pins it); either choice gives the same result.
+    // A second hook round at tree level (k_cgrid_hook2) before the union: the first round leaves a tree per dozen cells, and the union
+    // kernel merges trees pair by pair, by CAS (C3, 16 frames: union 49 -> 14 us for 23 us of hook2 + compress2, and shallower trees for
+    // k_cell_flatten; C5: 251 k trees -> 20 k).  Two more launches: not for frames of a few thousand cells.  Chosen from the previous
+    // batch's cells (PCOP_HOOK2=0|1 pins it); either choice gives the same result.
     bool hook2 = false, hook2_fixed = false;
     uint32_t ctiles = kCmapCells / 32u / kVmapTile;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -332,7 +333,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             const uint32_t tile = tile_for(c, nb, nf);
             const dim3 bt(std::max(1u, div_up(nb, tile)), nf);       // tiles of the coarse histogram and of the partition
             const size_t bins = (size_t)1 << c->gbits;
-            k_bin_hist<<<bt, kBinThreads, bins * 4u, s>>>(fr);
+            k_bin_hist<<<bt, kHistThreads, bins * 4u, s>>>(fr);
             mark(c, "k_bin_hist");
             k_bin_colsum<<<dim3((uint32_t)div_up((uint32_t)bins, kWave), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_bin_colsum");
@@ -361,9 +362,9 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
                 k_heavy_split<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
                 mark(c, "k_heavy_split");
             }
-            // one wave per bucket; the centroids go straight to their ranks and mark the grid cells of a chain frame (marks_cells below)
-            if (c->lds_ordered) k_bucket_reduce<true><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kWave, 0, s>>>(fr);
-            else k_bucket_reduce<false><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kWave, 0, s>>>(fr);
+            // the centroids go straight to their ranks and mark the grid cells of a chain frame (marks_cells below)
+            if (c->lds_ordered) k_bucket_reduce<true><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
+            else k_bucket_reduce<false><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_bucket_reduce");
         } else {
             for (uint32_t p = 0; p < c->npass_voxel; ++p) {
@@ -787,8 +788,8 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (!c->hook2_fixed) {   // (with hysteresis, like the choice above)
             uint32_t most = 0;
             for (uint32_t f = 0; f < c->nframes; ++f) if (!c->slots[f].result_trivial) most = std::max(most, c->slots[f].h_state->n_cells);
-            if (most >= (1u << 19)) c->hook2 = true;
-            else if (most < (1u << 18)) c->hook2 = false;
+            if (most >= (1u << 12)) c->hook2 = true;
+            else if (most < (1u << 11)) c->hook2 = false;
         }
     }
     if (grid_on(c)) {

@@ -69,7 +69,14 @@ constexpr uint32_t kVmapTile = 1024;            // occupancy words per block of 
 constexpr uint32_t kBinTile = 16384;            // points per block of k_bin_hist / k_bin_scatter: kBinTileSmall when that fills the chip better
 constexpr uint32_t kBinTileSmall = 4096;
 constexpr uint32_t kBinTileLarge = 32768;       // (the tile tables count in 16 bits: no tile above 2^15 points)
-constexpr uint32_t kBinThreads = 1024;          // threads of k_bin_hist / k_bin_plan
+constexpr uint32_t kBinThreads = 1024;          // threads of k_bin_plan
+#ifndef PCOP_HIST_THREADS
+#define PCOP_HIST_THREADS 512
+#endif
+// Threads of k_bin_hist.  Two blocks fit a CU either way (64 KB of LDS each); with 1024 threads they take every wave slot of the CU and
+// nothing of another context's batch can run beside the pass, with 512 half the slots stay free - and the pass itself is as fast
+// (tools/probes/stream_read.hip: 59 us either way).
+constexpr uint32_t kHistThreads = PCOP_HIST_THREADS;
 constexpr uint32_t kBinBitsMin = 11, kBinBitsMax = 14;   // coarse key bins per frame: 2^11 .. 2^14 (a host hint; any value gives the same result)
 constexpr uint32_t kBucketCap = 2048;           // points per bucket (k_bucket_reduce: one wave x 32 records a lane, all in LDS)
 constexpr uint32_t kBucketCells = 1u << 17;     // grid cells a bucket may span (bits of its LDS occupancy map)
@@ -77,7 +84,10 @@ constexpr uint32_t kHeavyMax = 4u * 2048u;       // points of a coarse bin that 
 constexpr uint32_t kHeavyGroups = 16;           // ... into at most this many buckets
 constexpr uint32_t kHeavySub = 2048;            // ... along this many key sub-ranges
 constexpr uint32_t kNbMin = 1024, kNbMax = 4096;   // buckets per frame a launch provides LDS for (grows on demand)
-constexpr uint32_t kScatThreads = 512, kScatItems = 8, kScatChunk = kScatThreads * kScatItems;   // k_bin_scatter: a tile in chunks of 4096
+#ifndef PCOP_SCAT_ITEMS
+#define PCOP_SCAT_ITEMS 8
+#endif
+constexpr uint32_t kScatThreads = 512, kScatItems = PCOP_SCAT_ITEMS, kScatChunk = kScatThreads * kScatItems;   // k_bin_scatter: a tile in chunks of 4096 (a tuning build may take 4 or 16 records a thread: tools/ab_build.sh)
 constexpr uint32_t kCmapCells = 1u << 24;       // dense cell grid: largest grid (cells, margins included) with an occupancy map
 constexpr uint32_t kCoarseBits = 1u << 20;      // room for the blocks of 4x4x4 cells of the largest grid (partial blocks at the ends of y and z included)
 constexpr int kCellMargin = 3;                  // empty cells around the grid: 2 for the 5x5x5 stencil + 1 of slack (a centroid

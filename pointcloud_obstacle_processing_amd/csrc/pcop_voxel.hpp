@@ -581,14 +581,12 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 // publishes its own count (plus one) as soon as it knows it and reads the counts of the lower tiles
 // after its sums are done; a lower tile never waits for a higher one and blocks are dispatched in
 // index order, so the lower tiles are always running or finished (the wait is bounded anyway).
-#ifndef PCOP_REDUCE_BPB
-#define PCOP_REDUCE_BPB 1
-#endif
-// k_bucket_reduce: consecutive buckets per block.  ONE: a bucket publishes its voxel count as soon as it has it and every bucket
-// waits for the counts of all lower ones, so a block's second bucket - which cannot publish before the block is through with its
-// first - would make every higher block wait for it, and that one for the block before: a chain through the whole frame
-// (measured with two: 6.9 ms a batch instead of 0.06).
-constexpr uint32_t kReduceBucketsPerBlock = PCOP_REDUCE_BPB;
+// k_bucket_reduce: ONE bucket per block.  A bucket waits for the voxel counts of all lower buckets, and a wait is only safe on
+// LOWER BLOCK INDICES (they are dispatched first, so they are running or done whatever else shares the GPU).  Two consecutive
+// buckets per block would make every block wait for the second bucket of the block before it - a chain through the frame (measured
+// with the one-wave kernel: 6.9 ms a batch); two interleaved ones (k, k + H) would make a block's second round wait for first
+// rounds of higher blocks, which may not have been dispatched yet while the waiting blocks hold the slots they need.
+constexpr uint32_t kReduceBucketsPerBlock = 1u;
 
 // mark_cells: a chain frame on the dense cell grid (set up by k_voxel_setup): every centroid marks its grid cell as it is
 // written, so the cell stage has no k_cell_mark launch (k_voxel_gather does the same on the streaming path).
@@ -748,7 +746,7 @@ __device__ __forceinline__ bool stream_off(const DevState* st) {
 struct BoxKey;
 __device__ __forceinline__ void bin_hist_on_box(Frame& F, uint32_t* s_hist, uint32_t tile_base, uint32_t tile, uint32_t n, uint32_t G, uint32_t cs);
 
-__global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
+__global__ __launch_bounds__(kHistThreads) void k_bin_hist(Frame* frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_dyn);
     Frame& F = frames[blockIdx.y];
@@ -759,24 +757,24 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     const uint32_t tile_base = blockIdx.x * tile;
     if (tile_base >= n) return;
     const uint32_t G = 1u << st->gbits, cs = st->cshift;
-    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) s_hist[b] = 0u;
+    for (uint32_t b = threadIdx.x; b < G; b += kHistThreads) s_hist[b] = 0u;
     __syncthreads();
     const float* __restrict__ x = st->src_x; const float* __restrict__ y = st->src_y; const float* __restrict__ z = st->src_z;
     const bool drop = st->is_dense == 0;
     VoxelKey key; key.init(st);
     bool bad = false;
-    constexpr int kRound = kBinTileSmall / kBinThreads;   // records in flight per thread: 4
+    constexpr int kRound = kBinTileSmall / kHistThreads;   // records in flight per thread: 8
     if (st->sbox) { bin_hist_on_box(F, s_hist, tile_base, tile, n, G, cs); return; }
-    for (uint32_t r0 = 0; r0 < tile / kBinThreads; r0 += kRound) {
+    for (uint32_t r0 = 0; r0 < tile / kHistThreads; r0 += kRound) {
         Rec3 r[kRound];
 #pragma unroll
         for (int k = 0; k < kRound; ++k) {   // clamped, unconditional loads
-            const uint32_t i = min(tile_base + (r0 + k) * kBinThreads + threadIdx.x, n - 1u);
+            const uint32_t i = min(tile_base + (r0 + k) * kHistThreads + threadIdx.x, n - 1u);
             r[k].x = x[i]; r[k].y = y[i]; r[k].z = z[i];
         }
 #pragma unroll
         for (int k = 0; k < kRound; ++k) {
-            const uint32_t i = tile_base + (r0 + k) * kBinThreads + threadIdx.x;
+            const uint32_t i = tile_base + (r0 + k) * kHistThreads + threadIdx.x;
             if (i < n && (!drop || finite3(r[k].x, r[k].y, r[k].z))) {
                 const uint32_t bin = key(r[k]) >> cs;
                 if (bin < G) atomicAdd(&s_hist[bin], 1u); else bad = true;
@@ -786,7 +784,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(Frame* frames) {
     if (bad) atomicOr(&st->err, (uint32_t)kErrInternal);   // a key beyond the grid: never (the keys are those PCL computes)
     __syncthreads();
     uint16_t* __restrict__ row = ctab + (size_t)blockIdx.x * G;
-    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has at most 2^15 points (kBinTileLarge): fits
+    for (uint32_t b = threadIdx.x; b < G; b += kHistThreads) row[b] = (uint16_t)s_hist[b];   // a tile has at most 2^15 points (kBinTileLarge): fits
 }
 
 // Bin totals over the tiles: a block takes 64 bins (a wave reads 128 contiguous bytes of a row), its four waves
@@ -1448,255 +1446,322 @@ __global__ __launch_bounds__(kBlock) void k_heavy_split(Frame* frames) {
     if (threadIdx.x == 0) F.hparts[b] = ng;
 }
 
-// ONE WAVE PER BUCKET.  Round 3's kernel gave a bucket to a block of four waves, which cost a barrier per phase (seven of them),
-// per-wave counters to join (16 KB of LDS) and 46 KB a block: three blocks to a CU, each a chain of phases none of which could
-// start before the slowest wave of the one before.  A bucket is at most 2048 records, 32 to a lane: here one wave holds all of
-// them in registers, ranks them with ONE counter per voxel id (a wave's LDS instructions execute in program order and, with
-// lane-ordered atomics, in lane order inside an instruction: the returned value of ds_add_rtn IS the record's place in its
-// voxel's run), turns the counters into run starts with a scan that never leaves the wave, stages the records in run order and
-// sums every run with a lane of its own.  No barrier anywhere, 28 KB of LDS a wave (five waves to a CU, all independent), and
-// what used to be the next kernel happens here as well: a bucket publishes its voxel count as soon as it has it, adds up the
-// counts of the buckets before it (lower blocks never wait on higher ones and are dispatched first; the wait is bounded) and
-// writes its centroids straight to their output ranks - voxel key order - marking each one's grid cell on the way.  The last
-// bucket knows M.  (k_voxel_gather is gone, and with it the trip of the centroids through the scratch records.)
-// A frame the voxel grid passed through (or gave no voxels) has no buckets: its cell stage sees the input cloud, marked here by
-// all blocks together.
+// A bucket lives in LDS, a block of four waves works on it.  What used to be the next kernel (k_voxel_gather) happens here as
+// well: a bucket publishes its voxel count as soon as it has it, adds up the counts of the buckets before it (publish + look-back:
+// lower buckets never wait on higher ones and are dispatched first; the wait is bounded) and writes its centroids straight to
+// their output ranks - voxel key order - each marking its grid cell on the way.  The last bucket knows M.  The centroids no
+// longer travel through the scratch records, and a launch is gone.
+// (Round 4 also tried ONE WAVE per bucket - no barriers at all, 28 KB of LDS, all 2048 records in one wave's registers: bit-exact,
+//  and slower: 176 us a batch against 105 + 35.  Five independent waves to a CU are too few instruction streams to hide a chain of
+//  LDS round trips that four waves with barriers between them hide better)
 template <bool ORDERED>   // ORDERED: as in k_bin_scatter
-__global__ __launch_bounds__(kWave) void k_bucket_reduce(Frame* frames) {
-    constexpr uint32_t kSlots = kBucketCap / kWave;            // 32 records to a lane
-    constexpr uint32_t kMapWords = kBucketCells / 32u;         // 4096 occupancy words (a bucket that spans more voxel keys than it may have ids)
-    constexpr uint32_t kCntWords = kBucketCap / 2u;            // per voxel id a 16-bit count, then the start of its run (two ids to a word)
-    static_assert(kBucketCap * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
-    static_assert(kCntWords == 16u * kWave, "the scan gives a lane sixteen words");
+__global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   // (four blocks to a CU, as its 35.7 KB of LDS allow: at most 128 registers)
+    constexpr uint32_t NW = kBlock / kWave;                    // 4 waves; a wave ranks 512 consecutive points of the bucket
+    constexpr uint32_t kItemsB = kBucketCap / kBlock;          // 8
+    constexpr uint32_t kBucketsPerBlock = kReduceBucketsPerBlock;
+    constexpr uint32_t kMapWords = kBucketCells / 32u;         // 4096
+    constexpr uint32_t kPerW = kMapWords / kBlock;             // at most 16 occupancy words per thread
+    constexpr uint32_t kPlane = kBucketCap + kBucketCap / 32u + 8u;   // a staged coordinate plane: slot s lives at s + (s >> 5)
     static_assert(kHeavyGroups <= 128u, "k_heavy_split matches groups on 7 bits");
-    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kBucketCap * 12u];   // occupancy bits + running counts, then the staged records (three planes)
-    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kCntWords + 4u];
-    __shared__ unsigned long long s_match[ORDERED ? 1u : 96u];   // 64 + 32 peer-mask words (voxel ids below 2048)
+    static_assert(kPlane * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPlane * 12u];   // occupancy bits + running counts, then the staged records (three planes)
+    // The per-id tables provide for kIdsPass ids; a bucket with more (rare: nearly every record a voxel of its own) is taken in passes
+    // over its id range, the records staying in registers.  That keeps the block at 35.7 KB of LDS: four blocks to a CU instead of three.
+    constexpr uint32_t kIdsPass = kBucketCap / 2u;             // 1024
+    __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kIdsPass];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3; then the waves' places
+    __shared__ __attribute__((aligned(16))) uint16_t s_vs[kIdsPass + 8u];   // per occupied voxel id, in order: where its run starts in the staged pass; then the end of the last run
+    __shared__ unsigned long long s_match[ORDERED ? 1u : NW * 96u];   // per wave: 64 + 32 peer-mask words (voxel ids below 2048)
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
+    const uint4* __restrict__ binfo = F.binfo;
+    const Rec3* __restrict__ recs = reinterpret_cast<const Rec3*>(F.rec_a.get());
+    uint32_t* __restrict__ bucket_pub = F.bucket_pub;
+    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
+    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
     if (st->err || st->kind == kFrameClusterOnly) return;
     const bool cells = !cgrid_off(st);
-    const uint32_t lane = lane_id();
-    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
     CellMarker mark;
     if (cells) mark.init(st);
     if (!(st->vpath && st->n_valid && !st->passthrough)) {
-        if (cells) {   // no buckets: the cell stage's cloud is the input (or nothing)
+        if (cells) {   // a frame without buckets (passed through, or nothing valid): the cell stage's cloud is the input, marked by all blocks together
             const bool from_in = st->c_from_input != 0;
             const float* __restrict__ x = from_in ? st->src_x.get() : F.cen_x.get();
             const float* __restrict__ y = from_in ? st->src_y.get() : F.cen_y.get();
             const float* __restrict__ z = from_in ? st->src_z.get() : F.cen_z.get();
             const uint32_t n = st->c_n;
-            for (uint32_t i = blockIdx.x * kWave + lane; i < n; i += gridDim.x * kWave) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
+            for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
         }
         return;
     }
     const uint32_t nb = st->nbuckets;
-    const uint32_t b0 = blockIdx.x * kReduceBucketsPerBlock;
-    if (b0 >= nb) return;
-    const uint4* __restrict__ binfo = F.binfo;
-    const Rec3* __restrict__ recs = reinterpret_cast<const Rec3*>(F.rec_a.get());
-    uint32_t* __restrict__ bucket_pub = F.bucket_pub;
-    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
+    static_assert(kBucketsPerBlock == 1u, "a block may only wait on lower block indices: one bucket per block (see kReduceBucketsPerBlock)");
+    const uint32_t nblk = nb;   // blocks with work: <= gridDim.x (the launch covers nb_cap buckets)
+    const uint32_t blk = blockIdx.x;
+    if (blk >= nblk) return;
+    const uint32_t spin_limit = st->spin_limit, out_cap = F.cap;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(s_mem);
     uint16_t* wpre = reinterpret_cast<uint16_t*>(s_mem + kMapWords * 4u);
-    float* stage_x = reinterpret_cast<float*>(s_mem); float* stage_y = stage_x + kBucketCap; float* stage_z = stage_y + kBucketCap;
-    const uint16_t* start16 = reinterpret_cast<const uint16_t*>(s_cnt);
+    float* stage_x = reinterpret_cast<float*>(s_mem); float* stage_y = stage_x + kPlane; float* stage_z = stage_y + kPlane;
+    const uint32_t w = threadIdx.x / kWave, lane = lane_id();
     VoxelKey key; key.init(st);
-    const uint32_t spin_limit = st->spin_limit, out_cap = F.cap;
-    // voxels of the buckets before this block's first one: asked for once, after the block has published a count of its own
-    uint32_t before = 0u, run_nv = 0u;
+    const uint32_t pbase = w * (kItemsB * kWave) + lane;   // position in the bucket = index order
+    // A block takes kBucketsPerBlock consecutive buckets, one after the other; the records of the next one are requested
+    // before the current one is worked on, so only the first bucket's load latency is exposed.
+    Rec3 rec[kItemsB], recn[kItemsB];
+    uint4 info_n = binfo[blk];
+    auto request = [&](Rec3* r, const uint4& inf) {
+        const uint32_t lastr = inf.y ? min(inf.y, kBucketCap) - 1u : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < kItemsB; ++j) r[j] = recs[inf.x + min(pbase + j * kWave, lastr)];   // clamped, unconditional
+    };
+    request(recn, info_n);
+    for (uint32_t it = 0; it < kBucketsPerBlock; ++it) {
+    const uint32_t b = blk + it * nblk;
+    if (b >= nb) break;
+    const uint4 info_b = info_n;   // {first record, records, first key, keys spanned}
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) rec[j] = recn[j];
+    if (it + 1u < kBucketsPerBlock && b + nblk < nb) {
+        info_n = binfo[b + nblk];
+        request(recn, info_n);
+    }
+    // a heavy bucket comes as the buckets k_heavy_split cut it into, taken one after the other; their voxels follow each other
+    const bool heavy = info_b.y > kBucketCap;
+    const uint32_t nparts = heavy ? min(F.hparts[b], kHeavyGroups) : 1u;
+    uint32_t nv_acc = 0u;
+    bool failed = heavy && nparts == 0u, late = heavy;   // late: the voxel count is published at the end, not from inside the first pass
+    // voxels of the lower buckets (asked for once per bucket, after this bucket has published its own count)
+    uint32_t before = 0u;
     bool have_before = false;
-    uint4 info_next = binfo[b0];
-    for (uint32_t it = 0; it < kReduceBucketsPerBlock; ++it) {
-        const uint32_t b = b0 + it;
-        if (b >= nb) break;
-        const uint4 info_b = info_next;   // {first record, records, first key, keys spanned}
-        if (it + 1u < kReduceBucketsPerBlock && b + 1u < nb) info_next = binfo[b + 1u];
-        // a heavy bucket comes as the buckets k_heavy_split cut it into, taken one after the other; their voxels follow each other
-        const bool heavy = info_b.y > kBucketCap;
-        const uint32_t nparts = heavy ? min(F.hparts[b], kHeavyGroups) : 1u;
-        uint32_t nv_acc = 0u;
-        bool failed = heavy && nparts == 0u;
-        for (uint32_t part = 0; part < nparts && !failed; ++part) {
-            uint4 info = info_b;
-            if (heavy) {
-                info = F.hsub[(size_t)b * kHeavyGroups + part];
-                if (info.y == 0u) { if (part + 1u == nparts && lane == 0) st_agent(bucket_pub + b, nv_acc + 1u); continue; }   // (a group of empty key sub-ranges at the end)
-            }
-            const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
-            if (cnt == 0u || cnt > kBucketCap || span > kBucketCells || span == 0u) { failed = true; break; }   // never: k_bin_plan keeps both limits
-            // all records requested at once (clamped, unconditional: a load under a branch would be waited for at its join)
-            Rec3 rec[kSlots];
-            const uint32_t lastr = cnt - 1u;
+    for (uint32_t part = 0; part < nparts && !failed; ++part) {
+    uint4 info = info_b;
+    if (heavy) {
+        info = F.hsub[(size_t)b * kHeavyGroups + part];
+        if (info.y == 0u) continue;   // (a group of empty key sub-ranges at the end)
+        request(rec, info);
+    }
+    const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
+    // A bucket that spans at most kBucketCap cells sorts by the cell itself (ids of empty cells get empty runs);
+    // a wider one first ranks its occupied cells through an occupancy map, so that ids stay below the point count.
+    const bool direct = span <= kBucketCap / 2u;   // (= kIdsPass: the ids of one pass)
+    const uint32_t words = (span + 31u) / 32u;
+    bool bad = cnt == 0u || cnt > kBucketCap || span > kBucketCells;   // never: k_bin_plan keeps both limits
+    uint32_t lk[kItemsB], id[kItemsB], rank[kItemsB];
+    bool act[kItemsB];
+    PCOP_STAMP(F, 2, 0, 150);
+    // (the LDS is cleared while the records are on their way)
+    if (!direct) for (uint32_t i = threadIdx.x; i < min(words, kMapWords); i += kBlock) bitmap[i] = 0u;
+    // (pass 0's counters: cleared here as well; the id count is not known yet for a bucket that ranks its voxels: all of them)
+    for (uint32_t v = threadIdx.x; v < kIdsPass; v += kBlock) { s_wc[v] = 0u; s_wc[kIdsPass + v] = 0u; }
+    if (!ORDERED) for (uint32_t i = threadIdx.x; i < NW * 96u; i += kBlock) s_match[i] = 0ull;
 #pragma unroll
-            for (uint32_t j = 0; j < kSlots; ++j) rec[j] = recs[info.x + min(j * kWave + lane, lastr)];
-            // A bucket whose ids would mostly be empty first ranks its occupied voxels through an occupancy map, so that every id has
-            // a run (the sums give a lane to an id); one that is well filled sorts by the voxel key itself.
-            const bool direct = span <= kBucketCap && (span <= 256u || span <= cnt);
-            const uint32_t words = (span + 31u) / 32u;
-            // (the LDS is cleared while the records are on their way)
-            {
-                uint4* c4 = reinterpret_cast<uint4*>(s_cnt) + lane * 4u;
-                const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-                c4[0] = z4; c4[1] = z4; c4[2] = z4; c4[3] = z4;
-                if (lane == 0) s_cnt[kCntWords] = 0u;
-                if (!direct) for (uint32_t i = lane; i < words; i += kWave) bitmap[i] = 0u;
-                if (!ORDERED) { s_match[lane] = 0ull; if (lane < 32u) s_match[64u + lane] = 0ull; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint32_t id[kSlots];   // low half: the voxel id (0xFFFF: no record here); high half: the record's place in its voxel's run
-            bool bad = false;
+    for (uint32_t j = 0; j < kItemsB; ++j) {
+        lk[j] = key(rec[j]) - key_lo;
+        act[j] = !bad && pbase + j * kWave < cnt;
+        if (act[j] && lk[j] >= span) { bad = true; act[j] = false; }
+        id[j] = act[j] ? lk[j] : 0u;
+    }
+    bad = __syncthreads_or(bad ? 1 : 0) != 0;
+    PCOP_STAMP(F, 2, 1, 150);
+    if (bad) { failed = true; break; }
+    uint32_t nid = span;   // ids in use: the keys spanned, or the occupied voxels
+    if (!direct) {
 #pragma unroll
-            for (uint32_t j = 0; j < kSlots; ++j) {
-                const uint32_t lk = key(rec[j]) - key_lo;
-                const bool act = j * kWave + lane < cnt;
-                if (act && lk >= span) bad = true;
-                id[j] = (act && lk < span) ? lk : 0xFFFFFFFFu;
-            }
-            if (__ballot(bad)) { failed = true; break; }
-            uint32_t nid = span;
-            if (!direct) {
+        for (uint32_t j = 0; j < kItemsB; ++j)
+            if (act[j]) atomicOr(&bitmap[lk[j] >> 5], 1u << (lk[j] & 31u));
+        __syncthreads();
+    PCOP_STAMP(F, 2, 2, 150);
+        // running count of the occupied cells: thread t owns the perw consecutive words from t * perw
+        const uint32_t perw = (words + kBlock - 1u) / kBlock;   // 1 .. 16
+        uint32_t wv[kPerW];
+        uint32_t c = 0u;
 #pragma unroll
-                for (uint32_t j = 0; j < kSlots; ++j)
-                    if (id[j] != 0xFFFFFFFFu) atomicOr(&bitmap[id[j] >> 5], 1u << (id[j] & 31u));
-                __builtin_amdgcn_wave_barrier();
-                // running count of the occupied voxels: lane l owns the perw consecutive words from l * perw
-                const uint32_t perw = (words + kWave - 1u) / kWave;   // 1 .. 64
-                uint32_t c = 0u;
-                for (uint32_t k = 0; k < perw; ++k) { const uint32_t wi = lane * perw + k; c += wi < words ? __popc(bitmap[wi]) : 0u; }
-                const uint32_t incl = wave_incl_scan(c);
-                uint32_t run = incl - c;
-                for (uint32_t k = 0; k < perw; ++k) {
-                    const uint32_t wi = lane * perw + k;
-                    if (wi < words) { wpre[wi] = (uint16_t)run; run += __popc(bitmap[wi]); }
-                }
-                nid = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (uint32_t j = 0; j < kSlots; ++j) {   // id = occupied voxels of the bucket before this one
-                    if (id[j] != 0xFFFFFFFFu) {
-                        const uint32_t wi = id[j] >> 5;
-                        id[j] = (uint32_t)wpre[wi] + __popc(bitmap[wi] & ((1u << (id[j] & 31u)) - 1u));
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();   // the occupancy words are done with: the staging area may be written from here on
-            }
-            // places inside the runs: steps in order, lanes in order
-            if constexpr (ORDERED) {
-#pragma unroll
-                for (uint32_t j = 0; j < kSlots; ++j) {
-                    if (id[j] != 0xFFFFFFFFu) {
-                        const uint32_t sh = 16u * (id[j] & 1u);
-                        const uint32_t old = atomicAdd(&s_cnt[id[j] >> 1], 1u << sh);
-                        id[j] |= ((old >> sh) & 0xFFFFu) << 16;
-                    }
-                }
-            } else {
-                unsigned long long* m_lo = s_match;
-                unsigned long long* m_hi = s_match + 64u;
-#pragma unroll
-                for (uint32_t j = 0; j < kSlots; ++j) {
-                    const bool act = id[j] != 0xFFFFFFFFu;
-                    const uint32_t d = act ? id[j] : 0u;
-                    const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 31u, act);   // d < 2048
-                    const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
-                    const uint32_t sh = 16u * (d & 1u);
-                    uint32_t old = 0u;
-                    if (act && lr == 0u) old = atomicAdd(&s_cnt[d >> 1], (uint32_t)__popcll(peers) << sh);   // (the leader adds for its peers; the wave is alone on these words)
-                    const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
-                    old = __shfl(old, leader, kWave);
-                    if (act) id[j] |= (((old >> sh) & 0xFFFFu) + lr) << 16;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // counts -> run starts: lane l owns the ids 32 l .. 32 l + 31 (sixteen words), one wave scan joins the lanes; the voxels
-            // (ids with a run) are counted on the way
-            uint32_t nvox;
-            {
-                uint4* c4 = reinterpret_cast<uint4*>(s_cnt) + lane * 4u;
-                const uint4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3];
-                uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-                uint32_t tot = 0u, occ = 0u;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16; tot += lo + hi; occ += (lo ? 1u : 0u) + (hi ? 1u : 0u); }
-                const uint32_t incl = wave_incl_scan(tot | (occ << 16));   // (at most 2048 of either: no carry between the halves)
-                uint32_t run = (incl & 0xFFFFu) - tot;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16; w[k] = run | ((run + lo) << 16); run += lo + hi; }
-                c4[0] = make_uint4(w[0], w[1], w[2], w[3]); c4[1] = make_uint4(w[4], w[5], w[6], w[7]);
-                c4[2] = make_uint4(w[8], w[9], w[10], w[11]); c4[3] = make_uint4(w[12], w[13], w[14], w[15]);
-                const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-                nvox = all >> 16;
-                if (lane == 0) s_cnt[kCntWords] = all & 0xFFFFu;   // the end of the last run, for an id of kBucketCap - 1
-            }
-            // the bucket's voxel count goes out as early as it is known (a heavy bucket's: with its last part)
-            if (lane == 0 && (!heavy || part + 1u == nparts)) st_agent(bucket_pub + b, nv_acc + nvox + 1u);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (uint32_t j = 0; j < kSlots; ++j) {
-                if (id[j] != 0xFFFFFFFFu) {
-                    const uint32_t slot = (uint32_t)start16[id[j] & 0xFFFFu] + (id[j] >> 16);
-                    stage_x[slot] = rec[j].x; stage_y[slot] = rec[j].y; stage_z[slot] = rec[j].z;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (!have_before) {   // voxels of the lower buckets (a few hundred words; published early, needed only now)
-                uint32_t sum = 0u;
-                for (uint32_t i = lane; i < b0; i += kWave) {
-                    uint32_t v = ld_agent(bucket_pub + i), spins = 0u;
-                    while (v == 0u) {
-                        if (++spins > spin_limit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
-                        __builtin_amdgcn_s_sleep(2);
-                        v = ld_agent(bucket_pub + i);
-                    }
-                    sum += v - 1u;
-                }
-                before = wave_sum(sum);
-                have_before = true;
-            }
-            // one lane per id: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count); the v-th voxel of
-            // the frame goes to place v of the centroid planes and marks its grid cell
-            const uint32_t out0 = before + run_nv + nv_acc;
-            uint32_t occ_before = 0u;
-            for (uint32_t i0 = 0; i0 < nid; i0 += kWave) {
-                const uint32_t i = i0 + lane;
-                uint32_t s0 = 0u, e0 = 0u;
-                if (i < nid) { s0 = start16[i]; e0 = start16[i + 1u]; }
-                const bool has = e0 > s0;
-                const uint64_t hm = __ballot(has);
-                if (has) {
-                    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-                    for (uint32_t q = s0; q < e0; q += 4u) {   // four records requested at a time (clamped), added in order
-                        float vx[4], vy[4], vz[4];
-#pragma unroll
-                        for (uint32_t u = 0; u < 4u; ++u) { const uint32_t qq = min(q + u, e0 - 1u); vx[u] = stage_x[qq]; vy[u] = stage_y[qq]; vz[u] = stage_z[qq]; }
-#pragma unroll
-                        for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
-                    }
-                    const float fc = (float)(e0 - s0);
-                    const float ox = sx / fc, oy = sy / fc, oz = sz / fc;
-                    const uint32_t o = out0 + occ_before + (uint32_t)__popcll(hm & lanemask_lt());
-                    if (o < out_cap) {   // (always: M <= the points of the frame; a rank that went wrong must not become a wild store)
-                        cx[o] = ox; cy[o] = oy; cz[o] = oz;
-                        if (cells) pt_pos[o] = mark(st, cflag, ox, oy, oz);
-                    } else atomicOr(&st->err, (uint32_t)kErrInternal);
-                }
-                occ_before += (uint32_t)__popcll(hm);
-            }
-            nv_acc += nvox;
-            __builtin_amdgcn_wave_barrier();   // the next bucket clears and fills the same LDS
+        for (uint32_t k = 0; k < kPerW; ++k) {
+            const uint32_t wi = threadIdx.x * perw + k;
+            wv[k] = (k < perw && wi < words) ? bitmap[wi] : 0u;
+            c += __popc(wv[k]);
         }
-        if (failed) {
-            if (lane == 0) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)kErrInternal); st_agent(bucket_pub + b, 1u); }
-            return;   // (the frame is given up: nothing after this kernel runs on it)
+        uint32_t nocc;
+        uint32_t run = block_excl_scan(c, s_w, &nocc);
+        nid = nocc;
+#pragma unroll
+        for (uint32_t k = 0; k < kPerW; ++k) {
+            const uint32_t wi = threadIdx.x * perw + k;
+            if (k < perw && wi < words) wpre[wi] = (uint16_t)run;
+            run += __popc(wv[k]);
         }
-        run_nv += nv_acc;
-        if (b == nb - 1u) {   // the last bucket knows M (its own look-back is done: it had a record to sum)
-            if (lane == 0) finish_voxel(st, before + run_nv);
+        __syncthreads();
+    PCOP_STAMP(F, 2, 3, 150);
+#pragma unroll
+        for (uint32_t j = 0; j < kItemsB; ++j) {   // id = occupied cells of the bucket before this one
+            const uint32_t wi = act[j] ? lk[j] >> 5 : 0u;
+            id[j] = (uint32_t)wpre[wi] + __popc(bitmap[wi] & ((1u << (lk[j] & 31u)) - 1u));
+        }
+        __syncthreads();   // the occupancy words are done with: the staging area may be written from here on
+    PCOP_STAMP(F, 2, 4, 150);
+    }
+    const uint32_t npass = (nid + kIdsPass - 1u) / kIdsPass;   // 1, or 2
+    const bool late_pub = heavy || npass > 1u;                  // the voxel count goes out after the last pass of the last part
+    late = late_pub;
+    for (uint32_t pass = 0; pass < npass; ++pass) {
+    // this pass takes the ids pass * kIdsPass .. + kIdsPass - 1, as 0 .. kIdsPass - 1
+    bool actp[kItemsB];
+    uint32_t idp[kItemsB];
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) { actp[j] = act[j] && id[j] / kIdsPass == pass; idp[j] = id[j] % kIdsPass; }
+    const uint32_t nidr = min(kIdsPass, (min(nid - pass * kIdsPass, kIdsPass) + kBlock - 1u) / kBlock * kBlock);   // the per-id steps stop here
+    if (pass) {   // (pass 0's counters were cleared while the records were on their way)
+        for (uint32_t v = threadIdx.x; v < kIdsPass; v += kBlock) { s_wc[v] = 0u; s_wc[kIdsPass + v] = 0u; }
+        __syncthreads();
+    }
+    // ranks inside (wave, id)
+    const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
+    if constexpr (ORDERED) {
+#pragma unroll
+        for (uint32_t j = 0; j < kItemsB; ++j) {
+            uint32_t old = 0u;
+            if (actp[j]) old = atomicAdd(&s_wc[wword * kIdsPass + idp[j]], 1u << wshift);
+            rank[j] = (old >> wshift) & 0xFFFFu;
+        }
+    } else {
+    unsigned long long* m_lo = s_match + w * 96u;
+    unsigned long long* m_hi = m_lo + 64u;
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) {
+        const uint32_t d = idp[j];
+        const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 31u, actp[j]);   // d < 1024
+        const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
+        uint32_t old = 0u;
+        if (actp[j] && lr == 0u) old = atomicAdd(&s_wc[wword * kIdsPass + d], (uint32_t)__popcll(peers) << wshift);
+        const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
+        old = __shfl(old, leader, kWave);
+        rank[j] = ((old >> wshift) & 0xFFFFu) + lr;
+    }
+    }
+    __syncthreads();
+    PCOP_STAMP(F, 2, 5, 150);
+    // Thread t owns ids 4 t .. 4 t + 3 (one 16-byte read per count plane): points per id, then - after one scan over the
+    // block that carries the points in its low half and the occupied ids in its high half - every wave's place for every
+    // id (written back over the counts: the staging step then needs one word per record), and the run starts of the
+    // OCCUPIED ids in order (s_vs), so that the sums below give every lane a voxel.
+    uint32_t nvox = 0u;
+    {
+        const bool mine = threadIdx.x * 4u < nidr;
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+        const uint4* wc4 = reinterpret_cast<const uint4*>(s_wc);
+        const uint4 a0 = mine ? wc4[threadIdx.x] : z4;
+        const uint4 q0 = mine ? wc4[kIdsPass / 4u + threadIdx.x] : z4;
+        // cw[2 q] = the word of waves 0, 1 for id 4 t + q, cw[2 q + 1] = that of waves 2, 3
+        uint32_t cw[8] = {a0.x, q0.x, a0.y, q0.y, a0.z, q0.z, a0.w, q0.w};
+        uint32_t tsum = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t c = (cw[2 * q] & 0xFFFFu) + (cw[2 * q] >> 16) + (cw[2 * q + 1] & 0xFFFFu) + (cw[2 * q + 1] >> 16);
+            tsum += c + (c ? 0x10000u : 0u);
+        }
+        uint32_t ttot;
+        uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
+        nvox = ttot >> 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t c0 = cw[2 * q] & 0xFFFFu, c1 = cw[2 * q] >> 16, c2 = cw[2 * q + 1] & 0xFFFFu, c3 = cw[2 * q + 1] >> 16;
+            const uint32_t c = c0 + c1 + c2 + c3;
+            const uint32_t r = srun & 0xFFFFu;
+            if (c) s_vs[srun >> 16] = (uint16_t)r;
+            cw[2 * q] = r | ((r + c0) << 16);
+            cw[2 * q + 1] = (r + c0 + c1) | ((r + c0 + c1 + c2) << 16);
+            srun += c + (c ? 0x10000u : 0u);
+        }
+        if (mine) {
+            uint4* wo4 = reinterpret_cast<uint4*>(s_wc);
+            wo4[threadIdx.x] = make_uint4(cw[0], cw[2], cw[4], cw[6]);
+            wo4[kIdsPass / 4u + threadIdx.x] = make_uint4(cw[1], cw[3], cw[5], cw[7]);
+        }
+        if (threadIdx.x == 0) {
+            s_vs[nvox] = (uint16_t)(ttot & 0xFFFFu);
+            if (!late_pub) st_agent(bucket_pub + b, nvox + 1u);   // the bucket's voxel count goes out as early as it is known
         }
     }
+    // the publish words of the lower buckets are requested now and looked at after the staging step: most are there by then
+    constexpr uint32_t kPre = 4u;
+    uint32_t pv[kPre];
+    if (!have_before) {
+#pragma unroll
+        for (uint32_t q = 0; q < kPre; ++q) { const uint32_t i = threadIdx.x + q * kBlock; pv[q] = ld_agent(bucket_pub + min(i, b)); }   // (clamped, unconditional; word b itself is never used)
+    }
+    __syncthreads();
+    PCOP_STAMP(F, 2, 7, 150);
+#pragma unroll
+    for (uint32_t j = 0; j < kItemsB; ++j) {
+        if (actp[j]) {
+            const uint32_t slot = ((s_wc[wword * kIdsPass + idp[j]] >> wshift) & 0xFFFFu) + rank[j];
+            const uint32_t ps = slot + (slot >> 5);
+            stage_x[ps] = rec[j].x; stage_y[ps] = rec[j].y; stage_z[ps] = rec[j].z;
+        }
+    }
+    __syncthreads();
+    PCOP_STAMP(F, 2, 8, 150);
+#if defined(PCOP_DIAG_REDUCE_NO_LOOKBACK)   // (diagnostic builds, timing only)
+    if (!have_before) { before = b * 200u; have_before = true; }
+#endif
+    if (!have_before) {   // voxels of the lower buckets: a few hundred words, published early and needed only now (bounded wait)
+        uint32_t sum = 0u;
+        auto wait_for = [&](uint32_t i, uint32_t v) -> uint32_t {   // the voxel count of bucket i (v: what an earlier look found)
+            uint32_t spins = 0u;
+            while (v == 0u) {
+                if (++spins > spin_limit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
+                __builtin_amdgcn_s_sleep(2);
+                v = ld_agent(bucket_pub + i);
+            }
+            return v - 1u;
+        };
+#pragma unroll
+        for (uint32_t q = 0; q < kPre; ++q) { const uint32_t i = threadIdx.x + q * kBlock; if (i < b) sum += wait_for(i, pv[q]); }
+        for (uint32_t i = threadIdx.x + kPre * kBlock; i < b; i += kBlock) sum += wait_for(i, ld_agent(bucket_pub + i));
+        before = block_sum(sum, s_w);
+        have_before = true;
+    }
+    // one lane per VOXEL: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count).  The frame's v-th
+    // voxel goes to place v of the centroid planes (voxel key order: the buckets in order, the voxels of a bucket in order) and
+    // marks its grid cell on the way: there is no gather pass and no k_cell_mark launch.
+    for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
+        const uint32_t s0 = s_vs[v], e0 = s_vs[v + 1u];
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (uint32_t q = s0; q < e0; q += 4u) {   // four records requested at a time (clamped), added in order
+            float vx[4], vy[4], vz[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) { const uint32_t qq = min(q + u, e0 - 1u), ps = qq + (qq >> 5); vx[u] = stage_x[ps]; vy[u] = stage_y[ps]; vz[u] = stage_z[ps]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
+        }
+        const float fc = (float)(e0 - s0);
+        const float ox = sx / fc, oy = sy / fc, oz = sz / fc;
+        const uint32_t o = before + nv_acc + v;
+#if defined(PCOP_DIAG_REDUCE_NO_OUT)   // (diagnostic builds, timing only: tools/ab_libs.sh)
+        if (ox == 1.2345e30f) cx[0] = oy + oz;
+#else
+        if (o < out_cap) {   // (always: M <= the points of the frame; a rank that went wrong must not become a wild store)
+            cx[o] = ox; cy[o] = oy; cz[o] = oz;
+#if !defined(PCOP_DIAG_REDUCE_NO_MARK)
+            if (cells) pt_pos[o] = mark(st, cflag, ox, oy, oz);
+#endif
+        } else atomicOr(&st->err, (uint32_t)kErrInternal);
+#endif
+    }
+    nv_acc += nvox;
+    PCOP_STAMP(F, 2, 20, 150);
+    __syncthreads();   // the next pass / part clears and fills the same LDS
+    }   // passes over the id range
+    }   // parts of a heavy bucket
+    if (threadIdx.x == 0) {
+        if (failed) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)kErrInternal); st_agent(bucket_pub + b, 1u); }   // (the frame is given up; nobody waits for this bucket in vain)
+        else if (late) st_agent(bucket_pub + b, nv_acc + 1u);
+        if (!failed && b == nb - 1u) finish_voxel(st, before + nv_acc);   // the last bucket knows M (it had records: its look-back is done)
+    }
+    }
 }
+
 
 // ------------------------------------------------------------------------------------------
 // Occupancy scan of the dense cell grid (pcop_cells_grid.hpp): one byte per cell -> bits + running popcount.

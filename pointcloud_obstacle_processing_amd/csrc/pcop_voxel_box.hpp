@@ -151,7 +151,7 @@ __device__ __forceinline__ void radix_hist_on_box(const Frame& F, uint32_t* s_h,
 }
 
 __device__ __forceinline__ void bin_hist_on_box(Frame& F, uint32_t* s_hist, uint32_t tile_base, uint32_t tile, uint32_t n, uint32_t G, uint32_t cs) {
-    constexpr uint32_t NW = kBinThreads / kWave;
+    constexpr uint32_t NW = kHistThreads / kWave;
     __shared__ uint32_t s_red[NW * 8u];
     DevState* st = &F.st;
     uint16_t* __restrict__ ctab = F.ctab;
@@ -159,17 +159,17 @@ __device__ __forceinline__ void bin_hist_on_box(Frame& F, uint32_t* s_hist, uint
     BoxKey key; key.init(st);
     uint32_t mn0 = 0xFFFFFFFFu, mn1 = 0xFFFFFFFFu, mn2 = 0xFFFFFFFFu, mx0 = 0u, mx1 = 0u, mx2 = 0u;
     uint32_t nbad = 0u, nok = 0u;
-    constexpr int kRound = kBinTileSmall / kBinThreads;   // records in flight per thread: 4
-    for (uint32_t r0 = 0; r0 < tile / kBinThreads; r0 += kRound) {
+    constexpr int kRound = kBinTileSmall / kHistThreads;   // records in flight per thread: 8
+    for (uint32_t r0 = 0; r0 < tile / kHistThreads; r0 += kRound) {
         Rec3 r[kRound];
 #pragma unroll
         for (int k = 0; k < kRound; ++k) {   // clamped, unconditional loads
-            const uint32_t i = min(tile_base + (r0 + k) * kBinThreads + threadIdx.x, n - 1u);
+            const uint32_t i = min(tile_base + (r0 + k) * kHistThreads + threadIdx.x, n - 1u);
             r[k].x = x[i]; r[k].y = y[i]; r[k].z = z[i];
         }
 #pragma unroll
         for (int k = 0; k < kRound; ++k) {
-            const uint32_t i = tile_base + (r0 + k) * kBinThreads + threadIdx.x;
+            const uint32_t i = tile_base + (r0 + k) * kHistThreads + threadIdx.x;
             if (i < n) {
                 if (finite3(r[k].x, r[k].y, r[k].z)) {
                     uint32_t i0, i1, i2;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void bin_hist_on_box(Frame& F, uint32_t* s_hist, uint
         if (ok && (mx[0] >= key.d0 || mx[1] >= key.d1 || mx[2] >= key.d2)) atomicOr(&st->err, (uint32_t)kErrReplanBox);   // a point outside the box
     }
     uint16_t* __restrict__ row = ctab + (size_t)blockIdx.x * G;
-    for (uint32_t b = threadIdx.x; b < G; b += kBinThreads) row[b] = (uint16_t)s_hist[b];   // a tile has at most 2^15 points (kBinTileLarge): fits
+    for (uint32_t b = threadIdx.x; b < G; b += kHistThreads) row[b] = (uint16_t)s_hist[b];   // a tile has at most 2^15 points (kBinTileLarge): fits
 }
 
 // PCL's own grid into DevState, once nothing forms keys any more (k_emit's first block, before it hands DevState to the host):

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <vector>
+#include <math.h>
 
 __device__ uint32_t mul1_rt = 240u, mul2_rt = 57600u;   // (run-time values, as in the library: the compiler must not turn them into shifts)
 constexpr uint32_t kN = 1000000, kFrames = 16, kTile = 32768, kBins = 16384;
@@ -93,11 +94,18 @@ void run(const char* name, const Planes& P, float* sink) {
 
 int main() {
     Planes P;
-    std::vector<float> h(kN);
-    for (uint32_t i = 0; i < kN; ++i) h[i] = (float)((i * 2654435761u) >> 8) / 16777216.0f * 4.5f;
+    // a C3-like cloud: x, y uniform on a 4.5 m field, 80 % of the points on a ground plane (z ~ N(0, 3 mm)), the rest up to 0.6 m above it
+    std::vector<float> h(3 * (size_t)kN);
+    uint64_t sd = 88172645463325252ull;
+    auto rnd = [&]() { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; return (double)(sd >> 11) / 9007199254740992.0; };
+    for (uint32_t i = 0; i < kN; ++i) {
+        h[i] = (float)(rnd() * 4.5); h[kN + i] = (float)(rnd() * 4.5);
+        if (rnd() < 0.8) { const double u1 = rnd() + 1e-12, u2 = rnd(); h[2 * (size_t)kN + i] = (float)(0.003 * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2)); }
+        else h[2 * (size_t)kN + i] = (float)(0.2 + 0.4 * rnd());
+    }
     for (uint32_t f = 0; f < kFrames; ++f) {
         float* d; hipMalloc(&d, 3 * kN * 4);
-        for (int a = 0; a < 3; ++a) hipMemcpy(d + a * kN, h.data(), kN * 4, hipMemcpyHostToDevice);
+        hipMemcpy(d, h.data(), 3 * (size_t)kN * 4, hipMemcpyHostToDevice);
         P.x[f] = d; P.y[f] = d + kN; P.z[f] = d + 2 * kN;
         hipMalloc(&P.tab[f], 32 * kBins * 2); hipMalloc(&P.part[f], 32 * 16 * 4);
     }
