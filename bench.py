@@ -39,7 +39,7 @@ def kernel_alg_bytes(name, n, m, n_cells):
         "k_minmax": 12 * n,                     # read the xyz planes
         "k_bin_hist": 12 * n,                   # read the xyz planes (with the keys on the context's box it also takes the bounds: no k_minmax)
         "k_bin_scatter": 12 * n + 12 * n,       # xyz planes in, packed xyz records out
-        "k_bucket_reduce": 12 * n + 16 * m,     # records in, centroids out at their ranks (+ the grid position of each)
+        "k_bucket_reduce": 12 * n + 12 * m,     # records in, centroids out
         "k_radix_hist": 12 * n,
         "k_radix_scatter": 24 * n,
         "k_voxel_reduce": 12 * n + 12 * m,

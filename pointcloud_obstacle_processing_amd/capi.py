@@ -534,8 +534,9 @@ class Context:
         p, b = C.c_void_p(), C.c_size_t()
         self._chk(self.lib.pcop_debug_buffer(self.h, b"state", C.byref(p), C.byref(b)))
         st = DevState()
-        assert C.sizeof(st) == b.value, (C.sizeof(st), b.value)
-        self._chk(self.lib.pcop_dev_download(self.h, C.addressof(st), p, b.value))
+        if os.environ.get("PCOP_LIB") is None:   # (an experiment build may lay the tail of the struct out differently: its head is read)
+            assert C.sizeof(st) == b.value, (C.sizeof(st), b.value)
+        self._chk(self.lib.pcop_dev_download(self.h, C.addressof(st), p, min(C.sizeof(st), b.value)))
         return st
 
     def stage_times(self):

@@ -163,6 +163,7 @@ struct pcop_ctx {
     // k_cell_flatten; C5: 251 k trees -> 20 k).  Two more launches: not for frames of a few thousand cells.  Chosen from the previous
     // batch's cells (PCOP_HOOK2=0|1 pins it); either choice gives the same result.
     bool hook2 = false, hook2_fixed = false;
+    bool scat_big = true;            // PCOP_SCAT_BIG=0: the partition always in chunks of 4096 points (default: 8192 where the tile and the LDS allow)
     uint32_t ctiles = kCmapCells / 32u / kVmapTile;
     std::map<GraphKey, hipGraphExec_t> graphs;
 
@@ -341,20 +342,24 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             mark(c, "k_bin_plan");
             k_bin_tilecnt<<<bt, kBlock, (bins + 8u) * 2u, s>>>(fr);
             mark(c, "k_bin_tilecnt");
-            if (c->lds_ordered) {
-                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, true><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr, 0u);
-                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, true><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr, 0u);
-                else k_bin_scatter<8, true><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr, 0u);
-            } else {
-                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, false><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr, 0u);
-                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, false><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr, 0u);
-                else k_bin_scatter<8, false><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr, 0u);
-            }
+            // chunks of 8192 points where the tile and the LDS allow (see k_bin_scatter), else of 4096
+            const bool big = c->scat_big && tile % (16u * kScatThreads) == 0u && c->nb_cap <= 4u * kScatThreads;
+            auto scatter = [&](uint32_t alt, bool ordered) {
+                constexpr uint32_t C16 = 16u * kScatThreads;
+                if (ordered) {
+                    if (c->nb_cap <= 2u * kScatThreads) { if (big) k_bin_scatter<2, true, 16><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads, C16), s>>>(fr, alt); else k_bin_scatter<2, true><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr, alt); }
+                    else if (c->nb_cap <= 4u * kScatThreads) { if (big) k_bin_scatter<4, true, 16><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads, C16), s>>>(fr, alt); else k_bin_scatter<4, true><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr, alt); }
+                    else k_bin_scatter<8, true><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr, alt);
+                } else {
+                    if (c->nb_cap <= 2u * kScatThreads) { if (big) k_bin_scatter<2, false, 16><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads, C16), s>>>(fr, alt); else k_bin_scatter<2, false><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr, alt); }
+                    else if (c->nb_cap <= 4u * kScatThreads) { if (big) k_bin_scatter<4, false, 16><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads, C16), s>>>(fr, alt); else k_bin_scatter<4, false><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr, alt); }
+                    else k_bin_scatter<8, false><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr, alt);
+                }
+            };
+            scatter(0u, c->lds_ordered);
             mark(c, "k_bin_scatter");
             if (c->stream_chk) {   // first streamed batch: the same partition once more with ranks from peer masks, byte for byte
-                if (c->nb_cap <= 2u * kScatThreads) k_bin_scatter<2, false><<<bt, kScatThreads, scatter_lds_bytes(2u * kScatThreads), s>>>(fr, 1u);
-                else if (c->nb_cap <= 4u * kScatThreads) k_bin_scatter<4, false><<<bt, kScatThreads, scatter_lds_bytes(4u * kScatThreads), s>>>(fr, 1u);
-                else k_bin_scatter<8, false><<<bt, kScatThreads, scatter_lds_bytes(8u * kScatThreads), s>>>(fr, 1u);
+                scatter(1u, false);
                 k_rec_compare<<<dim3(kReduceBlocks, nf), kBlock, 0, s>>>(fr, c->debug_order_mismatch ? 1u : 0u);
                 mark(c, "k_rec_compare");
             }
@@ -362,10 +367,11 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
                 k_heavy_split<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);
                 mark(c, "k_heavy_split");
             }
-            // the centroids go straight to their ranks and mark the grid cells of a chain frame (marks_cells below)
             if (c->lds_ordered) k_bucket_reduce<true><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
             else k_bucket_reduce<false><<<dim3(div_up(c->nb_cap, kReduceBucketsPerBlock), nf), kBlock, 0, s>>>(fr);
             mark(c, "k_bucket_reduce");
+            k_voxel_gather<<<dim3(c->nb_cap, nf), kBlock, 0, s>>>(fr);   // (also marks the grid cells of a chain frame: see marks_cells below)
+            mark(c, "k_voxel_gather");
         } else {
             for (uint32_t p = 0; p < c->npass_voxel; ++p) {
                 k_radix_hist<MAXB><<<pg, kBlock, 0, s>>>(fr, (int)p);
@@ -394,7 +400,7 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             }
             // a chain frame has its cells marked by the voxel stage's last kernel (same launch sequence, grid set up before
             // the voxel stage)
-            const bool marks_cells = kind == kFrameChain && (parts & kPartVoxel) && !(parts & kPartOwnGridSetup);   // by k_bucket_reduce / k_voxel_reduce
+            const bool marks_cells = kind == kFrameChain && (parts & kPartVoxel) && !(parts & kPartOwnGridSetup);   // by k_voxel_gather / k_voxel_reduce
             if (!marks_cells) {
                 k_cell_mark<<<tg, kBlock, 0, s>>>(fr);
                 mark(c, "k_cell_mark");
@@ -788,8 +794,9 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (!c->hook2_fixed) {   // (with hysteresis, like the choice above)
             uint32_t most = 0;
             for (uint32_t f = 0; f < c->nframes; ++f) if (!c->slots[f].result_trivial) most = std::max(most, c->slots[f].h_state->n_cells);
-            if (most >= (1u << 12)) c->hook2 = true;
-            else if (most < (1u << 11)) c->hook2 = false;
+            // (well-filled cells only: with a point or two to a cell - C5 - the round's pair tests cost what the union saves)
+            if (most >= (1u << 12) && pts >= 3 * cells) c->hook2 = true;
+            else if (most < (1u << 11) || 2 * pts < 5 * cells) c->hook2 = false;
         }
     }
     if (grid_on(c)) {
@@ -1296,6 +1303,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     if (const char* e = getenv("PCOP_FLATTEN_BLOCKS")) c->flatten_blocks = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("PCOP_DEBUG_SKIP_UNION")) c->debug_skip_union = (uint32_t)atoi(e);
     if (const char* e = getenv("PCOP_HOOK2")) { c->hook2 = atoi(e) != 0; c->hook2_fixed = true; }
+    if (const char* e = getenv("PCOP_SCAT_BIG")) c->scat_big = atoi(e) != 0;
     const size_t nbk = bucket_of(c, (uint32_t)max_points);           // launch sizes round up to this
     const size_t n = std::max<size_t>(max_points, nbk);
     const size_t ntiles = (n + kTile - 1) / kTile + 1;

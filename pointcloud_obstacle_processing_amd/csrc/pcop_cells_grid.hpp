@@ -17,7 +17,7 @@ namespace pcop {
 //     per-cell array and the lanes of a wave (64 consecutive cells) touch the same cache lines.
 //   k_cgrid_setup   grid origin / size from the bounding box (margins added), or "replan"
 //   k_cell_mark     grid position of every point; one byte per occupied cell (a chain frame's centroids mark theirs as
-//                   k_bucket_reduce / k_voxel_reduce write them: no launch of this kernel)
+//                   k_voxel_gather / k_voxel_reduce write them: no launch of this kernel)
 //   k_occ_scan      bytes -> occupancy bits + running popcount => cell ids, n_cells
 //   k_cell_count    points per cell, rank inside the cell, smallest point index (= priority)
 //   k_cell_starts   exclusive scan of the counts; per-cell metadata; union-find init
@@ -75,6 +75,48 @@ __global__ __launch_bounds__(kBlock) void k_cell_mark(Frame* frames) {
     const uint32_t n = st->c_n;
     CellMarker mark; mark.init(st);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
+}
+
+// End of the streaming voxel path and start of the cell stage in one pass over the voxels: the centroids k_bucket_reduce left
+// at their buckets' places go to their ranks (output order = voxel key order), and each marks its grid cell on the way,
+// so the chain has no k_cell_mark launch.  One block per bucket.  A frame the voxel grid passed through (or gave no voxels)
+// has no buckets: its cell stage sees the input cloud, marked here by all blocks together.
+__global__ __launch_bounds__(kBlock) void k_voxel_gather(Frame* frames) {
+    __shared__ uint32_t s_w[kWavesPerBlock + 1];
+    Frame& F = frames[blockIdx.y];
+    DevState* st = &F.st;
+    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
+    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
+    if (st->err || st->kind == kFrameClusterOnly) return;
+    const bool cells = !cgrid_off(st);
+    CellMarker mark;
+    if (cells) mark.init(st);
+    if (st->vpath && st->n_valid && !st->passthrough) {
+        const uint32_t b = blockIdx.x, nb = st->nbuckets;
+        if (b >= nb) return;
+        const uint32_t* __restrict__ bucket_pub = F.bucket_pub;
+        // output rank of the bucket's first voxel = voxels of the buckets before it (a few hundred words: every block adds
+        // them up for itself rather than wait for a scan kernel); the last bucket's block knows M
+        uint32_t before = 0;
+        for (uint32_t i = threadIdx.x; i < b; i += kBlock) before += bucket_pub[i];
+        const uint32_t base = block_sum(before, s_w);
+        const float4* __restrict__ scratch = F.rec_b;
+        const uint32_t first = F.binfo[b].x, nvox = bucket_pub[b];
+        if (b == nb - 1u && threadIdx.x == 0) finish_voxel(st, base + nvox);
+        for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
+            const float4 p = scratch[first + v];
+            const uint32_t i = base + v;
+            cx[i] = p.x; cy[i] = p.y; cz[i] = p.z;
+            if (cells) pt_pos[i] = mark(st, cflag, p.x, p.y, p.z);
+        }
+    } else if (cells) {
+        const bool from_in = st->c_from_input != 0;
+        const float* __restrict__ x = from_in ? st->src_x.get() : cx;
+        const float* __restrict__ y = from_in ? st->src_y.get() : cy;
+        const float* __restrict__ z = from_in ? st->src_z.get() : cz;
+        const uint32_t n = st->c_n;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
+    }
 }
 
 // id of the occupied cell at grid position pos

@@ -11,9 +11,10 @@
 //     k_bin_tilecnt           per (tile, bucket): the tile's points in the bucket (k_bin_scatter adds up the lower tiles itself)
 //     k_bin_scatter           ONE stable partition of packed 12-byte xyz records by bucket
 //     k_heavy_split           (only once a frame needed it) a coarse bin above a bucket, cut into buckets along the keys
-//     k_bucket_reduce         one wave per bucket: local voxel ids, stable LDS counting sort, one lane per voxel sums
-//                             its run in order; the buckets' voxel counts -> output ranks, M; centroids straight to
-//                             their ranks (and, in a chain frame on the dense cell grid, each marks its grid cell)
+//     k_bucket_reduce         per bucket: occupancy bits in LDS -> local voxel ids, stable LDS counting
+//                             sort, one lane per voxel sums its run in order -> the bucket's centroids
+//     k_voxel_gather          buckets' voxel counts -> output ranks, M; centroids to their ranks (and, in a
+//                             chain frame on the dense cell grid, each marks its grid cell on the way)
 //    sort path (single frames - the shorter chain of launches - and clouds the streaming path does not cover):
 //     k_radix_hist / k_table_scan / k_radix_scatter   (x passes) stable LSD radix partition of
 //                             packed xyz records by PCL's linear voxel index
@@ -78,7 +79,7 @@ constexpr uint32_t kBinThreads = 1024;          // threads of k_bin_plan
 // (tools/probes/stream_read.hip: 59 us either way).
 constexpr uint32_t kHistThreads = PCOP_HIST_THREADS;
 constexpr uint32_t kBinBitsMin = 11, kBinBitsMax = 14;   // coarse key bins per frame: 2^11 .. 2^14 (a host hint; any value gives the same result)
-constexpr uint32_t kBucketCap = 2048;           // points per bucket (k_bucket_reduce: one wave x 32 records a lane, all in LDS)
+constexpr uint32_t kBucketCap = 2048;           // points per bucket (k_bucket_reduce: 256 threads x 8 records, all in LDS)
 constexpr uint32_t kBucketCells = 1u << 17;     // grid cells a bucket may span (bits of its LDS occupancy map)
 constexpr uint32_t kHeavyMax = 4u * 2048u;       // points of a coarse bin that holds more than a bucket and is split by k_heavy_split (beyond: sort path)
 constexpr uint32_t kHeavyGroups = 16;           // ... into at most this many buckets

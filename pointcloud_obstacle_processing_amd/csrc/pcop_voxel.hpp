@@ -581,12 +581,10 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 // publishes its own count (plus one) as soon as it knows it and reads the counts of the lower tiles
 // after its sums are done; a lower tile never waits for a higher one and blocks are dispatched in
 // index order, so the lower tiles are always running or finished (the wait is bounded anyway).
-// k_bucket_reduce: ONE bucket per block.  A bucket waits for the voxel counts of all lower buckets, and a wait is only safe on
-// LOWER BLOCK INDICES (they are dispatched first, so they are running or done whatever else shares the GPU).  Two consecutive
-// buckets per block would make every block wait for the second bucket of the block before it - a chain through the frame (measured
-// with the one-wave kernel: 6.9 ms a batch); two interleaved ones (k, k + H) would make a block's second round wait for first
-// rounds of higher blocks, which may not have been dispatched yet while the waiting blocks hold the slots they need.
-constexpr uint32_t kReduceBucketsPerBlock = 1u;
+#ifndef PCOP_REDUCE_BPB
+#define PCOP_REDUCE_BPB 2
+#endif
+constexpr uint32_t kReduceBucketsPerBlock = PCOP_REDUCE_BPB;   // k_bucket_reduce: consecutive buckets per block (2: measured against 1, 3 and 4, tools/ab_build.sh)
 
 // mark_cells: a chain frame on the dense cell grid (set up by k_voxel_setup): every centroid marks its grid cell as it is
 // written, so the cell stage has no k_cell_mark launch (k_voxel_gather does the same on the streaming path).
@@ -719,10 +717,11 @@ __global__ __launch_bounds__(kBlock) void k_voxel_reduce(Frame* frames, uint32_t
 //   k_bin_scatter   : ONE stable partition of packed 12-byte xyz records by bucket (ranks from lane-ordered LDS atomics or peer
 //                     masks, per-wave counts, chunks of kScatChunk points staged in LDS so that stores are contiguous); a tile adds up
 //                     the counts of the lower tiles for itself
-//   k_bucket_reduce : ONE WAVE per bucket, the bucket in its registers and LDS: local voxel ids (the key itself, or its rank in an
-//                     occupancy map), stable counting sort by id, one lane per voxel sums its run in order from 0.0f and divides
-//                     by float(count); the voxels of the lower buckets added up (publish + look-back) -> output rank of the
-//                     bucket's first voxel, M; centroids straight to their ranks = voxel key order, grid cells marked on the way
+//   k_bucket_reduce : a bucket lives in LDS: occupancy bits of its key range -> local voxel ids (rank of the key),
+//                     stable counting sort by id, one lane per voxel sums its run in order from 0.0f and divides
+//                     by float(count); the centroids stay at the bucket's place, the bucket leaves its voxel count
+//   k_voxel_gather  : (pcop_cells_grid.hpp) the voxels of the lower buckets added up -> output rank of the bucket's first
+//                     voxel, M; centroids to their ranks = voxel key order, grid cells marked on the way
 // Same float operations in the same order as the sort path.  No global atomics, no scattered global access: the
 // cloud is read three times (bounds, histogram, partition), written once and read once as 12-byte records.
 // Any bucket plan that respects the two limits gives the same result, so the host may tune gbits freely.
@@ -1117,18 +1116,22 @@ __global__ __launch_bounds__(kBlock) void k_lds_order_probe(uint32_t* __restrict
     if (bad) atomicAdd(violations, bad);
 }
 
-// Dynamic LDS of k_bin_scatter for nbc buckets.
-__host__ __device__ constexpr size_t scatter_lds_bytes(uint32_t nbc) {
-    return (size_t)kScatChunk * 12u + (size_t)kScatChunk * 2u + (size_t)nbc * (4u + 16u) + 8u + 4u * (kScatThreads / kWave + 1u);
+// Dynamic LDS of k_bin_scatter for nbc buckets and chunks of `chunk` points.
+__host__ __device__ constexpr size_t scatter_lds_bytes(uint32_t nbc, uint32_t chunk = kScatChunk) {
+    return (size_t)chunk * 12u + (size_t)chunk * 2u + (size_t)nbc * (4u + 16u) + 8u + 4u * (kScatThreads / kWave + 1u);
 }
 
 // ORDERED: the device hands out the old values of an LDS atomic add in lane order among the lanes of a wave
 // instruction that hit the same word (k_lds_order_probe checked it when the context was made): the rank of a point
 // inside (wave, bucket) is then the value one atomic returns.  Otherwise the ranks come from peer masks.
-template <uint32_t PB, bool ORDERED>   // PB: buckets per thread in the per-bucket steps: the launch provides for PB * 512 buckets
+// IT: records a thread holds = a chunk of IT * 512 points.  8 (chunks of 4096, two blocks to a CU) or 16 (chunks of 8192: one block to a CU -
+// half the barriers per point, runs twice as long in the stores, half the wave slots left to other contexts' kernels: measured 114 against
+// 117 us for the pass and + 5 % on the bench line; needs a tile of a multiple of 8192 points and at most 2048 buckets: 155 KB of LDS).
+template <uint32_t PB, bool ORDERED, uint32_t IT = kScatItems>   // PB: buckets per thread in the per-bucket steps: the launch provides for PB * 512 buckets
 __global__ __launch_bounds__(kScatThreads) void k_bin_scatter(Frame* frames, uint32_t alt) {   // alt: write to rec_b (the order self-check's second opinion)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    constexpr uint32_t NW = kScatThreads / kWave;   // 8 waves; a wave ranks 512 consecutive points of a chunk
+    constexpr uint32_t kScatItems = IT, kScatChunk = kScatThreads * IT;   // (shadow the defaults of pcop_device.hpp)
+    constexpr uint32_t NW = kScatThreads / kWave;   // 8 waves; a wave ranks IT * 64 consecutive points of a chunk
     constexpr uint32_t kMatchWords = 128u;          // per wave: 64 words for the low 6 bits of the bucket, 64 for the high 6
     static_assert(NW == 8u && kScatChunk <= 65535u, "per bucket: eight 16-bit fields, one per wave");
     static_assert(NW * kMatchWords * 8u <= kScatChunk * 12u, "the peer masks fit the staging area");
@@ -1313,7 +1316,7 @@ __global__ __launch_bounds__(kBlock) void k_rec_compare(Frame* frames, uint32_t 
 
 // A bucket with more than kBucketCap points (a single coarse bin, k_bin_plan) is cut into buckets that fit: counts of up
 // to kHeavySub equal key sub-ranges, sub-ranges packed greedily into groups of at most kBucketCap points, the records
-// partitioned by group - stably, so that index order survives - through the centroid planes (idle until k_bucket_reduce writes the centroids)
+// partitioned by group - stably, so that index order survives - through the centroid planes (idle until k_voxel_gather)
 // and written back over the bucket's records.  hsub[b][g] then describes group g the way binfo describes a bucket, and
 // k_bucket_reduce runs them one after the other.  One block per bucket; blocks of ordinary buckets return at once.
 __global__ __launch_bounds__(kBlock) void k_heavy_split(Frame* frames) {
@@ -1446,16 +1449,17 @@ __global__ __launch_bounds__(kBlock) void k_heavy_split(Frame* frames) {
     if (threadIdx.x == 0) F.hparts[b] = ng;
 }
 
-// A bucket lives in LDS, a block of four waves works on it.  What used to be the next kernel (k_voxel_gather) happens here as
-// well: a bucket publishes its voxel count as soon as it has it, adds up the counts of the buckets before it (publish + look-back:
-// lower buckets never wait on higher ones and are dispatched first; the wait is bounded) and writes its centroids straight to
-// their output ranks - voxel key order - each marking its grid cell on the way.  The last bucket knows M.  The centroids no
-// longer travel through the scratch records, and a launch is gone.
-// (Round 4 also tried ONE WAVE per bucket - no barriers at all, 28 KB of LDS, all 2048 records in one wave's registers: bit-exact,
-//  and slower: 176 us a batch against 105 + 35.  Five independent waves to a CU are too few instruction streams to hide a chain of
-//  LDS round trips that four waves with barriers between them hide better)
+// A bucket lives in LDS, a block of four waves works on it (two consecutive buckets per block, the second one's records requested
+// while the first is worked on).  The centroids stay at the bucket's place in the scratch records, the bucket leaves its voxel count in
+// bucket_pub; k_voxel_gather (the next launch) adds the counts up and moves the centroids to their ranks.
+// Round 4 built two other forms of this kernel, bit-exact both, and measured them slower: ONE WAVE per bucket (no
+// barriers, 28 KB of LDS: 176 us a batch against 105 + 35 for this kernel and the gather), and this kernel FUSED with the gather
+// (the bucket publishes its voxel count, looks back over the lower buckets' counts and writes its centroids straight to their ranks:
+// 144-153 us, and - 6 % on the bench line in the same run): a device-scope load of another block's word is served past the XCD's
+// L2, a fabric round trip of a microsecond or two that sits in every block's critical path (a block of this kernel takes 8.4 k cycles
+// by its stamps, the fused one 19.9 k), while the gather's plain loads after a kernel boundary hit the L2.
 template <bool ORDERED>   // ORDERED: as in k_bin_scatter
-__global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   // (four blocks to a CU, as its 35.7 KB of LDS allow: at most 128 registers)
+__global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     constexpr uint32_t NW = kBlock / kWave;                    // 4 waves; a wave ranks 512 consecutive points of the bucket
     constexpr uint32_t kItemsB = kBucketCap / kBlock;          // 8
     constexpr uint32_t kBucketsPerBlock = kReduceBucketsPerBlock;
@@ -1465,11 +1469,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
     static_assert(kHeavyGroups <= 128u, "k_heavy_split matches groups on 7 bits");
     static_assert(kPlane * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPlane * 12u];   // occupancy bits + running counts, then the staged records (three planes)
-    // The per-id tables provide for kIdsPass ids; a bucket with more (rare: nearly every record a voxel of its own) is taken in passes
-    // over its id range, the records staying in registers.  That keeps the block at 35.7 KB of LDS: four blocks to a CU instead of three.
-    constexpr uint32_t kIdsPass = kBucketCap / 2u;             // 1024
-    __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kIdsPass];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3; then the waves' places
-    __shared__ __attribute__((aligned(16))) uint16_t s_vs[kIdsPass + 8u];   // per occupied voxel id, in order: where its run starts in the staged pass; then the end of the last run
+    __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kBucketCap];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3; then the waves' places
+    __shared__ __attribute__((aligned(16))) uint16_t s_vs[kBucketCap + 8u];   // per occupied voxel id, in order: where its run starts in the staged bucket; then the end of the last run
     __shared__ unsigned long long s_match[ORDERED ? 1u : NW * 96u];   // per wave: 64 + 32 peer-mask words (voxel ids below 2048)
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     Frame& F = frames[blockIdx.y];
@@ -1477,29 +1478,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
     const uint4* __restrict__ binfo = F.binfo;
     const Rec3* __restrict__ recs = reinterpret_cast<const Rec3*>(F.rec_a.get());
     uint32_t* __restrict__ bucket_pub = F.bucket_pub;
-    float* __restrict__ cx = F.cen_x; float* __restrict__ cy = F.cen_y; float* __restrict__ cz = F.cen_z;
-    uint8_t* __restrict__ cflag = F.cflag; uint32_t* __restrict__ pt_pos = F.pt_root;
-    if (st->err || st->kind == kFrameClusterOnly) return;
-    const bool cells = !cgrid_off(st);
-    CellMarker mark;
-    if (cells) mark.init(st);
-    if (!(st->vpath && st->n_valid && !st->passthrough)) {
-        if (cells) {   // a frame without buckets (passed through, or nothing valid): the cell stage's cloud is the input, marked by all blocks together
-            const bool from_in = st->c_from_input != 0;
-            const float* __restrict__ x = from_in ? st->src_x.get() : F.cen_x.get();
-            const float* __restrict__ y = from_in ? st->src_y.get() : F.cen_y.get();
-            const float* __restrict__ z = from_in ? st->src_z.get() : F.cen_z.get();
-            const uint32_t n = st->c_n;
-            for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) pt_pos[i] = mark(st, cflag, x[i], y[i], z[i]);
-        }
-        return;
-    }
+    float4* __restrict__ scratch = F.rec_b;
+    if (stream_off(st)) return;
     const uint32_t nb = st->nbuckets;
-    static_assert(kBucketsPerBlock == 1u, "a block may only wait on lower block indices: one bucket per block (see kReduceBucketsPerBlock)");
-    const uint32_t nblk = nb;   // blocks with work: <= gridDim.x (the launch covers nb_cap buckets)
     const uint32_t blk = blockIdx.x;
-    if (blk >= nblk) return;
-    const uint32_t spin_limit = st->spin_limit, out_cap = F.cap;
+    if (blk * kBucketsPerBlock >= nb) return;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(s_mem);
     uint16_t* wpre = reinterpret_cast<uint16_t*>(s_mem + kMapWords * 4u);
     float* stage_x = reinterpret_cast<float*>(s_mem); float* stage_y = stage_x + kPlane; float* stage_z = stage_y + kPlane;
@@ -1509,7 +1492,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
     // A block takes kBucketsPerBlock consecutive buckets, one after the other; the records of the next one are requested
     // before the current one is worked on, so only the first bucket's load latency is exposed.
     Rec3 rec[kItemsB], recn[kItemsB];
-    uint4 info_n = binfo[blk];
+    uint4 info_n = binfo[blk * kBucketsPerBlock];
     auto request = [&](Rec3* r, const uint4& inf) {
         const uint32_t lastr = inf.y ? min(inf.y, kBucketCap) - 1u : 0u;
 #pragma unroll
@@ -1517,23 +1500,21 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
     };
     request(recn, info_n);
     for (uint32_t it = 0; it < kBucketsPerBlock; ++it) {
-    const uint32_t b = blk + it * nblk;
+    const uint32_t b = blk * kBucketsPerBlock + it;
     if (b >= nb) break;
     const uint4 info_b = info_n;   // {first record, records, first key, keys spanned}
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) rec[j] = recn[j];
-    if (it + 1u < kBucketsPerBlock && b + nblk < nb) {
-        info_n = binfo[b + nblk];
+    if (it + 1u < kBucketsPerBlock && b + 1u < nb) {
+        info_n = binfo[b + 1u];
         request(recn, info_n);
     }
-    // a heavy bucket comes as the buckets k_heavy_split cut it into, taken one after the other; their voxels follow each other
+    // a heavy bucket comes as the buckets k_heavy_split cut it into, taken one after the other; their voxels follow each
+    // other in the bucket's part of the scratch records
     const bool heavy = info_b.y > kBucketCap;
     const uint32_t nparts = heavy ? min(F.hparts[b], kHeavyGroups) : 1u;
     uint32_t nv_acc = 0u;
-    bool failed = heavy && nparts == 0u, late = heavy;   // late: the voxel count is published at the end, not from inside the first pass
-    // voxels of the lower buckets (asked for once per bucket, after this bucket has published its own count)
-    uint32_t before = 0u;
-    bool have_before = false;
+    bool failed = heavy && nparts == 0u;
     for (uint32_t part = 0; part < nparts && !failed; ++part) {
     uint4 info = info_b;
     if (heavy) {
@@ -1544,7 +1525,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
     const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
     // A bucket that spans at most kBucketCap cells sorts by the cell itself (ids of empty cells get empty runs);
     // a wider one first ranks its occupied cells through an occupancy map, so that ids stay below the point count.
-    const bool direct = span <= kBucketCap / 2u;   // (= kIdsPass: the ids of one pass)
+    const bool direct = span <= kBucketCap;
     const uint32_t words = (span + 31u) / 32u;
     bool bad = cnt == 0u || cnt > kBucketCap || span > kBucketCells;   // never: k_bin_plan keeps both limits
     uint32_t lk[kItemsB], id[kItemsB], rank[kItemsB];
@@ -1552,8 +1533,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
     PCOP_STAMP(F, 2, 0, 150);
     // (the LDS is cleared while the records are on their way)
     if (!direct) for (uint32_t i = threadIdx.x; i < min(words, kMapWords); i += kBlock) bitmap[i] = 0u;
-    // (pass 0's counters: cleared here as well; the id count is not known yet for a bucket that ranks its voxels: all of them)
-    for (uint32_t v = threadIdx.x; v < kIdsPass; v += kBlock) { s_wc[v] = 0u; s_wc[kIdsPass + v] = 0u; }
+    // ids stay below nidr (the cells spanned, or the points, rounded up to a multiple of the block): the per-id steps stop there
+    const uint32_t nidr = min(kBucketCap, ((direct ? span : cnt) + kBlock - 1u) / kBlock * kBlock);
+    for (uint32_t v = threadIdx.x; v < nidr; v += kBlock) { s_wc[v] = 0u; s_wc[kBucketCap + v] = 0u; }
     if (!ORDERED) for (uint32_t i = threadIdx.x; i < NW * 96u; i += kBlock) s_match[i] = 0ull;
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
@@ -1565,7 +1547,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
     bad = __syncthreads_or(bad ? 1 : 0) != 0;
     PCOP_STAMP(F, 2, 1, 150);
     if (bad) { failed = true; break; }
-    uint32_t nid = span;   // ids in use: the keys spanned, or the occupied voxels
     if (!direct) {
 #pragma unroll
         for (uint32_t j = 0; j < kItemsB; ++j)
@@ -1584,7 +1565,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
         }
         uint32_t nocc;
         uint32_t run = block_excl_scan(c, s_w, &nocc);
-        nid = nocc;
 #pragma unroll
         for (uint32_t k = 0; k < kPerW; ++k) {
             const uint32_t wi = threadIdx.x * perw + k;
@@ -1601,27 +1581,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
         __syncthreads();   // the occupancy words are done with: the staging area may be written from here on
     PCOP_STAMP(F, 2, 4, 150);
     }
-    const uint32_t npass = (nid + kIdsPass - 1u) / kIdsPass;   // 1, or 2
-    const bool late_pub = heavy || npass > 1u;                  // the voxel count goes out after the last pass of the last part
-    late = late_pub;
-    for (uint32_t pass = 0; pass < npass; ++pass) {
-    // this pass takes the ids pass * kIdsPass .. + kIdsPass - 1, as 0 .. kIdsPass - 1
-    bool actp[kItemsB];
-    uint32_t idp[kItemsB];
-#pragma unroll
-    for (uint32_t j = 0; j < kItemsB; ++j) { actp[j] = act[j] && id[j] / kIdsPass == pass; idp[j] = id[j] % kIdsPass; }
-    const uint32_t nidr = min(kIdsPass, (min(nid - pass * kIdsPass, kIdsPass) + kBlock - 1u) / kBlock * kBlock);   // the per-id steps stop here
-    if (pass) {   // (pass 0's counters were cleared while the records were on their way)
-        for (uint32_t v = threadIdx.x; v < kIdsPass; v += kBlock) { s_wc[v] = 0u; s_wc[kIdsPass + v] = 0u; }
-        __syncthreads();
-    }
     // ranks inside (wave, id)
     const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
     if constexpr (ORDERED) {
 #pragma unroll
         for (uint32_t j = 0; j < kItemsB; ++j) {
             uint32_t old = 0u;
-            if (actp[j]) old = atomicAdd(&s_wc[wword * kIdsPass + idp[j]], 1u << wshift);
+            if (act[j]) old = atomicAdd(&s_wc[wword * kBucketCap + id[j]], 1u << wshift);
             rank[j] = (old >> wshift) & 0xFFFFu;
         }
     } else {
@@ -1629,11 +1595,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
     unsigned long long* m_hi = m_lo + 64u;
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
-        const uint32_t d = idp[j];
-        const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 31u, actp[j]);   // d < 1024
+        const uint32_t d = id[j];
+        const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 31u, act[j]);   // d < 2048
         const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
         uint32_t old = 0u;
-        if (actp[j] && lr == 0u) old = atomicAdd(&s_wc[wword * kIdsPass + d], (uint32_t)__popcll(peers) << wshift);
+        if (act[j] && lr == 0u) old = atomicAdd(&s_wc[wword * kBucketCap + d], (uint32_t)__popcll(peers) << wshift);
         const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
         old = __shfl(old, leader, kWave);
         rank[j] = ((old >> wshift) & 0xFFFFu) + lr;
@@ -1641,22 +1607,22 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
     }
     __syncthreads();
     PCOP_STAMP(F, 2, 5, 150);
-    // Thread t owns ids 4 t .. 4 t + 3 (one 16-byte read per count plane): points per id, then - after one scan over the
+    // Thread t owns ids 8 t .. 8 t + 7 (two 16-byte reads per count plane): points per id, then - after one scan over the
     // block that carries the points in its low half and the occupied ids in its high half - every wave's place for every
     // id (written back over the counts: the staging step then needs one word per record), and the run starts of the
     // OCCUPIED ids in order (s_vs), so that the sums below give every lane a voxel.
     uint32_t nvox = 0u;
     {
-        const bool mine = threadIdx.x * 4u < nidr;
+        const bool mine = threadIdx.x * kItemsB < nidr;
         const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
         const uint4* wc4 = reinterpret_cast<const uint4*>(s_wc);
-        const uint4 a0 = mine ? wc4[threadIdx.x] : z4;
-        const uint4 q0 = mine ? wc4[kIdsPass / 4u + threadIdx.x] : z4;
-        // cw[2 q] = the word of waves 0, 1 for id 4 t + q, cw[2 q + 1] = that of waves 2, 3
-        uint32_t cw[8] = {a0.x, q0.x, a0.y, q0.y, a0.z, q0.z, a0.w, q0.w};
+        const uint4 a0 = mine ? wc4[threadIdx.x * 2u] : z4, a1 = mine ? wc4[threadIdx.x * 2u + 1u] : z4;
+        const uint4 q0 = mine ? wc4[kBucketCap / 4u + threadIdx.x * 2u] : z4, q1 = mine ? wc4[kBucketCap / 4u + threadIdx.x * 2u + 1u] : z4;
+        // cw[2 q] = the word of waves 0, 1 for id 8 t + q, cw[2 q + 1] = that of waves 2, 3
+        uint32_t cw[16] = {a0.x, q0.x, a0.y, q0.y, a0.z, q0.z, a0.w, q0.w, a1.x, q1.x, a1.y, q1.y, a1.z, q1.z, a1.w, q1.w};
         uint32_t tsum = 0u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const uint32_t c = (cw[2 * q] & 0xFFFFu) + (cw[2 * q] >> 16) + (cw[2 * q + 1] & 0xFFFFu) + (cw[2 * q + 1] >> 16);
             tsum += c + (c ? 0x10000u : 0u);
         }
@@ -1664,7 +1630,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
         uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
         nvox = ttot >> 16;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const uint32_t c0 = cw[2 * q] & 0xFFFFu, c1 = cw[2 * q] >> 16, c2 = cw[2 * q + 1] & 0xFFFFu, c3 = cw[2 * q + 1] >> 16;
             const uint32_t c = c0 + c1 + c2 + c3;
             const uint32_t r = srun & 0xFFFFu;
@@ -1675,56 +1641,26 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
         }
         if (mine) {
             uint4* wo4 = reinterpret_cast<uint4*>(s_wc);
-            wo4[threadIdx.x] = make_uint4(cw[0], cw[2], cw[4], cw[6]);
-            wo4[kIdsPass / 4u + threadIdx.x] = make_uint4(cw[1], cw[3], cw[5], cw[7]);
+            wo4[threadIdx.x * 2u] = make_uint4(cw[0], cw[2], cw[4], cw[6]); wo4[threadIdx.x * 2u + 1u] = make_uint4(cw[8], cw[10], cw[12], cw[14]);
+            wo4[kBucketCap / 4u + threadIdx.x * 2u] = make_uint4(cw[1], cw[3], cw[5], cw[7]); wo4[kBucketCap / 4u + threadIdx.x * 2u + 1u] = make_uint4(cw[9], cw[11], cw[13], cw[15]);
         }
-        if (threadIdx.x == 0) {
-            s_vs[nvox] = (uint16_t)(ttot & 0xFFFFu);
-            if (!late_pub) st_agent(bucket_pub + b, nvox + 1u);   // the bucket's voxel count goes out as early as it is known
-        }
-    }
-    // the publish words of the lower buckets are requested now and looked at after the staging step: most are there by then
-    constexpr uint32_t kPre = 4u;
-    uint32_t pv[kPre];
-    if (!have_before) {
-#pragma unroll
-        for (uint32_t q = 0; q < kPre; ++q) { const uint32_t i = threadIdx.x + q * kBlock; pv[q] = ld_agent(bucket_pub + min(i, b)); }   // (clamped, unconditional; word b itself is never used)
+        if (threadIdx.x == 0) s_vs[nvox] = (uint16_t)(ttot & 0xFFFFu);
     }
     __syncthreads();
     PCOP_STAMP(F, 2, 7, 150);
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
-        if (actp[j]) {
-            const uint32_t slot = ((s_wc[wword * kIdsPass + idp[j]] >> wshift) & 0xFFFFu) + rank[j];
+        if (act[j]) {
+            const uint32_t slot = ((s_wc[wword * kBucketCap + id[j]] >> wshift) & 0xFFFFu) + rank[j];
             const uint32_t ps = slot + (slot >> 5);
             stage_x[ps] = rec[j].x; stage_y[ps] = rec[j].y; stage_z[ps] = rec[j].z;
         }
     }
     __syncthreads();
     PCOP_STAMP(F, 2, 8, 150);
-#if defined(PCOP_DIAG_REDUCE_NO_LOOKBACK)   // (diagnostic builds, timing only)
-    if (!have_before) { before = b * 200u; have_before = true; }
-#endif
-    if (!have_before) {   // voxels of the lower buckets: a few hundred words, published early and needed only now (bounded wait)
-        uint32_t sum = 0u;
-        auto wait_for = [&](uint32_t i, uint32_t v) -> uint32_t {   // the voxel count of bucket i (v: what an earlier look found)
-            uint32_t spins = 0u;
-            while (v == 0u) {
-                if (++spins > spin_limit) { atomicOr(&st->err, (uint32_t)kErrInternal); v = 1u; break; }
-                __builtin_amdgcn_s_sleep(2);
-                v = ld_agent(bucket_pub + i);
-            }
-            return v - 1u;
-        };
-#pragma unroll
-        for (uint32_t q = 0; q < kPre; ++q) { const uint32_t i = threadIdx.x + q * kBlock; if (i < b) sum += wait_for(i, pv[q]); }
-        for (uint32_t i = threadIdx.x + kPre * kBlock; i < b; i += kBlock) sum += wait_for(i, ld_agent(bucket_pub + i));
-        before = block_sum(sum, s_w);
-        have_before = true;
-    }
-    // one lane per VOXEL: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count).  The frame's v-th
-    // voxel goes to place v of the centroid planes (voxel key order: the buckets in order, the voxels of a bucket in order) and
-    // marks its grid cell on the way: there is no gather pass and no k_cell_mark launch.
+    // one lane per VOXEL: the run in order, from 0.0f (voxel_grid.hpp "Fourth pass"), divided by float(count).  The centroid
+    // of the bucket's v-th voxel goes to place (first record of the bucket + v) of the scratch records: a bucket has at
+    // least as many records as voxels, so the places of different buckets do not meet; k_voxel_gather moves them to their ranks.
     for (uint32_t v = threadIdx.x; v < nvox; v += kBlock) {
         const uint32_t s0 = s_vs[v], e0 = s_vs[v + 1u];
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
@@ -1736,28 +1672,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   
             for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
         }
         const float fc = (float)(e0 - s0);
-        const float ox = sx / fc, oy = sy / fc, oz = sz / fc;
-        const uint32_t o = before + nv_acc + v;
-#if defined(PCOP_DIAG_REDUCE_NO_OUT)   // (diagnostic builds, timing only: tools/ab_libs.sh)
-        if (ox == 1.2345e30f) cx[0] = oy + oz;
-#else
-        if (o < out_cap) {   // (always: M <= the points of the frame; a rank that went wrong must not become a wild store)
-            cx[o] = ox; cy[o] = oy; cz[o] = oz;
-#if !defined(PCOP_DIAG_REDUCE_NO_MARK)
-            if (cells) pt_pos[o] = mark(st, cflag, ox, oy, oz);
-#endif
-        } else atomicOr(&st->err, (uint32_t)kErrInternal);
-#endif
+        scratch[info_b.x + nv_acc + v] = make_float4(sx / fc, sy / fc, sz / fc, 0.0f);
     }
     nv_acc += nvox;
     PCOP_STAMP(F, 2, 20, 150);
-    __syncthreads();   // the next pass / part clears and fills the same LDS
-    }   // passes over the id range
-    }   // parts of a heavy bucket
-    if (threadIdx.x == 0) {
-        if (failed) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)kErrInternal); st_agent(bucket_pub + b, 1u); }   // (the frame is given up; nobody waits for this bucket in vain)
-        else if (late) st_agent(bucket_pub + b, nv_acc + 1u);
-        if (!failed && b == nb - 1u) finish_voxel(st, before + nv_acc);   // the last bucket knows M (it had records: its look-back is done)
+    __syncthreads();   // the next bucket clears and fills the same LDS
+    }
+    if (threadIdx.x == 0) {   // k_voxel_gather adds the counts up to output ranks
+        if (failed) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)kErrInternal); bucket_pub[b] = 0u; }
+        else bucket_pub[b] = nv_acc;
     }
     }
 }

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 v=$1; vals=${2:-"0 1"}; pat=${3:-scatter}
 for rep in 1 2; do
   for x in $vals; do
-    env $v=$x python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end > gpurun_out/ab_${v}_${x}_$rep.json 2>gpurun_out/ab_${v}_${x}_$rep.err
+    env $v=$x python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary > gpurun_out/ab_${v}_${x}_$rep.json 2>gpurun_out/ab_${v}_${x}_$rep.err
     python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab_${v}_${x}_$rep.json").read().strip().splitlines()[-1])

@@ -13,8 +13,9 @@ if [ "$cmd" = build ]; then
   exit 0
 fi
 pat=${1:-reduce}; shift
+EXTRA_ARGS="$*"
 run() {  # tag lib
-  PCOP_LIB=$2 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary "$@" > gpurun_out/abl_$1.json 2> gpurun_out/abl_$1.err || { echo "bench failed ($1)"; tail -3 gpurun_out/abl_$1.err; return 0; }
+  PCOP_LIB=$2 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary $EXTRA_ARGS > gpurun_out/abl_$1.json 2> gpurun_out/abl_$1.err || { echo "bench failed ($1)"; tail -3 gpurun_out/abl_$1.err; return 0; }
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/abl_$1.json").read().strip().splitlines()[-1])
