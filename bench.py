@@ -63,8 +63,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rounds", type=int, default=20, help="rounds (every resident frame once) per step")
-    ap.add_argument("--batch", type=int, default=16, help="frames per context, processed in the same launches")
+    ap.add_argument("--rounds", type=int, default=10, help="rounds (every resident frame once) per step")
+    ap.add_argument("--batch", type=int, default=32, help="frames per context, processed in the same launches (32: + 6 %% over 16 in one run on one box, for twice a batch's latency; BASELINE.md 5)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) in flight per GPU")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and the parity check that uses its results)")

@@ -751,8 +751,11 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
                 widened(sh, l, h, &cells);
                 if (bits_of(cells) == bits_of(cells_tight)) break;
             }
+            // The kernels form keys as floor(p * inv) - (float)box_lo: exact while the box's voxel coordinates are floats' integers, i.e. within
+            // +-2^24 (beyond, (float)box_lo rounds and min_b = box_lo + i0 could be off by one); its spans then fit 32 bits with room to
+            // spare.  A cloud that far from the origin (in voxels) keeps its bounds pass: no box.
             bool fits = true;
-            for (int a = 0; a < 3; ++a) if (l[a] < -(1ll << 30) || h[a] > (1ll << 30)) fits = false;
+            for (int a = 0; a < 3; ++a) if (l[a] < -(1ll << 24) || h[a] > (1ll << 24)) fits = false;
             c->box_valid = fits;
             if (fits) for (int a = 0; a < 3; ++a) { c->box_lo[a] = (int32_t)l[a]; c->box_hi[a] = (int32_t)h[a]; }
         }

@@ -237,20 +237,22 @@ def test_box_path_single_frames_on_the_sort_path(capi, oracle):
 
 
 def test_the_configuration_the_bench_times(capi, oracle):
-    """The bench line's configuration at its full size (bench.py: a context of 16 slots, 16 distinct 1 M-point C3 clouds resident in
-    HBM, three submit_batch_device rounds: the bounds pass first, then twice with the keys on the context's box, 2^15 points a tile):
-    frames 0, 7 and 15 of every round bit-exact against the oracle.  Reference call sites: od.cpp:740-741, 791-797."""
+    """The bench line's configuration at its full size (bench.py: a context of 32 slots, 32 distinct 1 M-point C3 clouds resident in
+    HBM, three submit_batch_device rounds: the bounds pass first, then twice with the keys on the context's box, 2^15 points a tile, the
+    partition in chunks of 8192 points): frames 0, 15 and 31 of every round bit-exact against the oracle.  Reference call sites:
+    od.cpp:740-741, 791-797."""
     p = synth.params_of("C3")
     n = synth.CONFIGS["C3"]["n"]
-    seeds = [3000 + i for i in range(16)]
-    c = capi.Context(n, max_frames=16)
+    B = 32
+    seeds = [3000 + i for i in range(B)]
+    c = capi.Context(n, max_frames=B)
     c.set_params(publish_clouds=1, **p)
     ptrs, ns, refs = [], [], {}
     for i, s in enumerate(seeds):
         cloud = synth.make_cloud("C3", seed=s)
         q, k = c.upload_soa(cloud)
         ptrs.append(q); ns.append(k)
-        if i in (0, 7, 15):
+        if i in (0, 15, B - 1):
             refs[i] = oracle.process_xyz(cloud, **p)
         del cloud
     for rnd in range(3):
@@ -285,4 +287,21 @@ def test_single_frames_on_a_box_one_key_bit_longer_do_not_replan_every_call(capi
     st = c.debug_state()
     assert tuple(st.div_b) == (40, 40, 40) and st.sbox == 1
     assert seen[-1] == seen[2], seen   # (the first boxed frame may move the pass count once; after that nothing moves)
+    c.close()
+
+
+def test_cloud_far_from_the_origin_keeps_its_bounds_pass(capi, oracle):
+    """Voxel coordinates beyond +-2^24 are not exact as floats: (float)box_lo would round and a key formed against the box could be off by
+    one.  Such a cloud never gets a box (DevState::sbox stays 0, the bounds pass runs every time) and still equals the oracle."""
+    rng = np.random.default_rng(17)
+    leaf = 0.001
+    base = np.array([17000.0, -17500.0, 16900.0], dtype=np.float64)     # |x / leaf| about 1.7e7 > 2^24 = 1.68e7
+    pts = (base + rng.uniform(0.0, 0.35, (40_000, 3))).astype(f32)
+    p = dict(leaf=leaf, tol=0.02, min_cluster=1, max_cluster=100000)
+    ref = oracle.process_xyz(pts, **p)
+    c = capi.Context(len(pts), max_frames=2)
+    c.set_params(publish_clouds=1, **p)
+    for rep in range(3):
+        st = run(c, [pts, pts[::-1].copy()], [ref, oracle.process_xyz(pts[::-1].copy(), **p)])
+        assert st.sbox == 0, rep
     c.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run locally after `gpurun -- bash tools/refresh_profiles.sh <tag> <batch>`: copies the reduced files from gpurun_out/ into profiles/.
 set -e
-tag=${1:-r02}; B=${2:-16}
+tag=${1:-r02}; B=${2:-32}
 O=gpurun_out/refresh_$tag
 cp $O/bench.json profiles/${tag}_bench_n1.json
 cp $O/rocprofv3_kernel_stats.csv profiles/${tag}_rocprofv3_kernel_stats.csv

@@ -3,7 +3,7 @@
 # same command, reduced to the files kept under profiles/.  usage: tools/refresh_profiles.sh <round tag, e.g. r02> [batch]
 set -e
 tag=${1:-r02}
-B=${2:-16}
+B=${2:-32}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh_$tag
 rm -rf $O; mkdir -p $O

@@ -3,7 +3,7 @@ set -e
 mkdir -p gpurun_out
 for b in ${1:-16 24 32}; do
   for c in ${2:-2 3}; do
-    python bench.py --batch $b --contexts $c --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end > gpurun_out/sw_${b}_${c}.json 2>gpurun_out/sw_${b}_${c}.err
+    python bench.py --batch $b --contexts $c --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary > gpurun_out/sw_${b}_${c}.json 2>gpurun_out/sw_${b}_${c}.err
     python - <<PY
 import json
 d=json.loads(open("gpurun_out/sw_${b}_${c}.json").read().strip().splitlines()[-1])
