@@ -1459,11 +1459,7 @@ __global__ __launch_bounds__(kBlock) void k_heavy_split(Frame* frames) {
 // L2, a fabric round trip of a microsecond or two that sits in every block's critical path (a block of this kernel takes 8.4 k cycles
 // by its stamps, the fused one 19.9 k), while the gather's plain loads after a kernel boundary hit the L2.
 template <bool ORDERED>   // ORDERED: as in k_bin_scatter
-#ifdef PCOP_REDUCE_DIET
-__global__ __launch_bounds__(kBlock, 4) void k_bucket_reduce(Frame* frames) {   // (four blocks to a CU, as its 35.7 KB of LDS allow: at most 128 registers)
-#else
 __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
-#endif
     constexpr uint32_t NW = kBlock / kWave;                    // 4 waves; a wave ranks 512 consecutive points of the bucket
     constexpr uint32_t kItemsB = kBucketCap / kBlock;          // 8
     constexpr uint32_t kBucketsPerBlock = kReduceBucketsPerBlock;
@@ -1473,17 +1469,8 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     static_assert(kHeavyGroups <= 128u, "k_heavy_split matches groups on 7 bits");
     static_assert(kPlane * 12u >= kMapWords * 4u + kMapWords * 2u, "occupancy words + their running counts fit the staging area");
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kPlane * 12u];   // occupancy bits + running counts, then the staged records (three planes)
-    // The per-id tables provide for kIdsPass ids; with PCOP_REDUCE_DIET that is half a bucket's capacity and a bucket with more ids (rare:
-    // nearly every record a voxel of its own) is taken in passes over its id range, the records staying in registers: 35.7 KB of LDS a
-    // block instead of 45.6, four blocks to a CU instead of three.
-#ifdef PCOP_REDUCE_DIET
-    constexpr uint32_t kIdsPass = kBucketCap / 2u;             // 1024
-#else
-    constexpr uint32_t kIdsPass = kBucketCap;                  // every id in one pass
-#endif
-    constexpr uint32_t kPerT = kIdsPass / kBlock;              // ids a thread owns in the per-id steps: 4 or 8
-    __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kIdsPass];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3; then the waves' places
-    __shared__ __attribute__((aligned(16))) uint16_t s_vs[kIdsPass + 8u];   // per occupied voxel id, in order: where its run starts in the staged pass; then the end of the last run
+    __shared__ __attribute__((aligned(16))) uint32_t s_wc[2u * kBucketCap];   // per voxel id: counts of waves 0,1 (low / high half) and of waves 2,3; then the waves' places
+    __shared__ __attribute__((aligned(16))) uint16_t s_vs[kBucketCap + 8u];   // per occupied voxel id, in order: where its run starts in the staged bucket; then the end of the last run
     __shared__ unsigned long long s_match[ORDERED ? 1u : NW * 96u];   // per wave: 64 + 32 peer-mask words (voxel ids below 2048)
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     Frame& F = frames[blockIdx.y];
@@ -1538,7 +1525,7 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     const uint32_t cnt = info.y, key_lo = info.z, span = info.w;
     // A bucket that spans at most kBucketCap cells sorts by the cell itself (ids of empty cells get empty runs);
     // a wider one first ranks its occupied cells through an occupancy map, so that ids stay below the point count.
-    const bool direct = span <= kIdsPass;
+    const bool direct = span <= kBucketCap;
     const uint32_t words = (span + 31u) / 32u;
     bool bad = cnt == 0u || cnt > kBucketCap || span > kBucketCells;   // never: k_bin_plan keeps both limits
     uint32_t lk[kItemsB], id[kItemsB], rank[kItemsB];
@@ -1546,8 +1533,9 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     PCOP_STAMP(F, 2, 0, 150);
     // (the LDS is cleared while the records are on their way)
     if (!direct) for (uint32_t i = threadIdx.x; i < min(words, kMapWords); i += kBlock) bitmap[i] = 0u;
-    // (pass 0's counters: cleared here, while the records are on their way; the id count of a bucket that ranks its voxels is not known yet: all)
-    for (uint32_t v = threadIdx.x; v < kIdsPass; v += kBlock) { s_wc[v] = 0u; s_wc[kIdsPass + v] = 0u; }
+    // ids stay below nidr (the cells spanned, or the points, rounded up to a multiple of the block): the per-id steps stop there
+    const uint32_t nidr = min(kBucketCap, ((direct ? span : cnt) + kBlock - 1u) / kBlock * kBlock);
+    for (uint32_t v = threadIdx.x; v < nidr; v += kBlock) { s_wc[v] = 0u; s_wc[kBucketCap + v] = 0u; }
     if (!ORDERED) for (uint32_t i = threadIdx.x; i < NW * 96u; i += kBlock) s_match[i] = 0ull;
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
@@ -1559,7 +1547,6 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     bad = __syncthreads_or(bad ? 1 : 0) != 0;
     PCOP_STAMP(F, 2, 1, 150);
     if (bad) { failed = true; break; }
-    uint32_t nid = span;   // ids in use: the keys spanned, or the occupied voxels
     if (!direct) {
 #pragma unroll
         for (uint32_t j = 0; j < kItemsB; ++j)
@@ -1578,7 +1565,6 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
         }
         uint32_t nocc;
         uint32_t run = block_excl_scan(c, s_w, &nocc);
-        nid = nocc;
 #pragma unroll
         for (uint32_t k = 0; k < kPerW; ++k) {
             const uint32_t wi = threadIdx.x * perw + k;
@@ -1595,25 +1581,13 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
         __syncthreads();   // the occupancy words are done with: the staging area may be written from here on
     PCOP_STAMP(F, 2, 4, 150);
     }
-    const uint32_t npass = (nid + kIdsPass - 1u) / kIdsPass;   // 1 (always, without the diet), or 2
-    for (uint32_t pass = 0; pass < npass; ++pass) {
-    // this pass takes the ids pass * kIdsPass .. + kIdsPass - 1, as 0 .. kIdsPass - 1
-    bool actp[kItemsB];
-    uint32_t idp[kItemsB];
-#pragma unroll
-    for (uint32_t j = 0; j < kItemsB; ++j) { actp[j] = act[j] && id[j] / kIdsPass == pass; idp[j] = id[j] % kIdsPass; }
-    const uint32_t nidr = min(kIdsPass, (min(nid - pass * kIdsPass, kIdsPass) + kBlock - 1u) / kBlock * kBlock);   // the per-id steps stop here
-    if (pass) {   // (pass 0's counters were cleared while the records were on their way)
-        for (uint32_t v = threadIdx.x; v < kIdsPass; v += kBlock) { s_wc[v] = 0u; s_wc[kIdsPass + v] = 0u; }
-        __syncthreads();
-    }
     // ranks inside (wave, id)
     const uint32_t wword = w >> 1, wshift = 16u * (w & 1u);
     if constexpr (ORDERED) {
 #pragma unroll
         for (uint32_t j = 0; j < kItemsB; ++j) {
             uint32_t old = 0u;
-            if (actp[j]) old = atomicAdd(&s_wc[wword * kIdsPass + idp[j]], 1u << wshift);
+            if (act[j]) old = atomicAdd(&s_wc[wword * kBucketCap + id[j]], 1u << wshift);
             rank[j] = (old >> wshift) & 0xFFFFu;
         }
     } else {
@@ -1621,11 +1595,11 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     unsigned long long* m_hi = m_lo + 64u;
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
-        const uint32_t d = idp[j];
-        const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 31u, actp[j]);   // d < 2048
+        const uint32_t d = id[j];
+        const uint64_t peers = match_split_lds(m_lo, m_hi, d & 63u, ((d >> 6) + d) & 31u, act[j]);   // d < 2048
         const uint32_t lr = (uint32_t)__popcll(peers & lanemask_lt());
         uint32_t old = 0u;
-        if (actp[j] && lr == 0u) old = atomicAdd(&s_wc[wword * kIdsPass + d], (uint32_t)__popcll(peers) << wshift);
+        if (act[j] && lr == 0u) old = atomicAdd(&s_wc[wword * kBucketCap + d], (uint32_t)__popcll(peers) << wshift);
         const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
         old = __shfl(old, leader, kWave);
         rank[j] = ((old >> wshift) & 0xFFFFu) + lr;
@@ -1633,52 +1607,42 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     }
     __syncthreads();
     PCOP_STAMP(F, 2, 5, 150);
-    // Thread t owns the ids kPerT t .. kPerT t + kPerT - 1 (16-byte reads of each count plane): points per id, then - after one scan over
-    // the block that carries the points in its low half and the occupied ids in its high half - every wave's place for every
+    // Thread t owns ids 8 t .. 8 t + 7 (two 16-byte reads per count plane): points per id, then - after one scan over the
+    // block that carries the points in its low half and the occupied ids in its high half - every wave's place for every
     // id (written back over the counts: the staging step then needs one word per record), and the run starts of the
     // OCCUPIED ids in order (s_vs), so that the sums below give every lane a voxel.
     uint32_t nvox = 0u;
     {
-        const bool mine = threadIdx.x * kPerT < nidr;
+        const bool mine = threadIdx.x * kItemsB < nidr;
         const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
         const uint4* wc4 = reinterpret_cast<const uint4*>(s_wc);
-        constexpr uint32_t kV = kPerT / 4u;   // 16-byte words per plane and thread: 1 or 2
-        uint4 a[kV], q[kV];
-#pragma unroll
-        for (uint32_t u = 0; u < kV; ++u) { a[u] = mine ? wc4[threadIdx.x * kV + u] : z4; q[u] = mine ? wc4[kIdsPass / 4u + threadIdx.x * kV + u] : z4; }
-        // cw[2 i] = the word of waves 0, 1 for the thread's i-th id, cw[2 i + 1] = that of waves 2, 3
-        uint32_t cw[2u * kPerT];
-#pragma unroll
-        for (uint32_t u = 0; u < kV; ++u) {
-            cw[8u * u + 0u] = a[u].x; cw[8u * u + 1u] = q[u].x; cw[8u * u + 2u] = a[u].y; cw[8u * u + 3u] = q[u].y;
-            cw[8u * u + 4u] = a[u].z; cw[8u * u + 5u] = q[u].z; cw[8u * u + 6u] = a[u].w; cw[8u * u + 7u] = q[u].w;
-        }
+        const uint4 a0 = mine ? wc4[threadIdx.x * 2u] : z4, a1 = mine ? wc4[threadIdx.x * 2u + 1u] : z4;
+        const uint4 q0 = mine ? wc4[kBucketCap / 4u + threadIdx.x * 2u] : z4, q1 = mine ? wc4[kBucketCap / 4u + threadIdx.x * 2u + 1u] : z4;
+        // cw[2 q] = the word of waves 0, 1 for id 8 t + q, cw[2 q + 1] = that of waves 2, 3
+        uint32_t cw[16] = {a0.x, q0.x, a0.y, q0.y, a0.z, q0.z, a0.w, q0.w, a1.x, q1.x, a1.y, q1.y, a1.z, q1.z, a1.w, q1.w};
         uint32_t tsum = 0u;
 #pragma unroll
-        for (uint32_t i = 0; i < kPerT; ++i) {
-            const uint32_t c = (cw[2 * i] & 0xFFFFu) + (cw[2 * i] >> 16) + (cw[2 * i + 1] & 0xFFFFu) + (cw[2 * i + 1] >> 16);
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t c = (cw[2 * q] & 0xFFFFu) + (cw[2 * q] >> 16) + (cw[2 * q + 1] & 0xFFFFu) + (cw[2 * q + 1] >> 16);
             tsum += c + (c ? 0x10000u : 0u);
         }
         uint32_t ttot;
         uint32_t srun = block_excl_scan(tsum, s_w, &ttot);
         nvox = ttot >> 16;
 #pragma unroll
-        for (uint32_t i = 0; i < kPerT; ++i) {
-            const uint32_t c0 = cw[2 * i] & 0xFFFFu, c1 = cw[2 * i] >> 16, c2 = cw[2 * i + 1] & 0xFFFFu, c3 = cw[2 * i + 1] >> 16;
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t c0 = cw[2 * q] & 0xFFFFu, c1 = cw[2 * q] >> 16, c2 = cw[2 * q + 1] & 0xFFFFu, c3 = cw[2 * q + 1] >> 16;
             const uint32_t c = c0 + c1 + c2 + c3;
             const uint32_t r = srun & 0xFFFFu;
             if (c) s_vs[srun >> 16] = (uint16_t)r;
-            cw[2 * i] = r | ((r + c0) << 16);
-            cw[2 * i + 1] = (r + c0 + c1) | ((r + c0 + c1 + c2) << 16);
+            cw[2 * q] = r | ((r + c0) << 16);
+            cw[2 * q + 1] = (r + c0 + c1) | ((r + c0 + c1 + c2) << 16);
             srun += c + (c ? 0x10000u : 0u);
         }
         if (mine) {
             uint4* wo4 = reinterpret_cast<uint4*>(s_wc);
-#pragma unroll
-            for (uint32_t u = 0; u < kV; ++u) {
-                wo4[threadIdx.x * kV + u] = make_uint4(cw[8u * u + 0u], cw[8u * u + 2u], cw[8u * u + 4u], cw[8u * u + 6u]);
-                wo4[kIdsPass / 4u + threadIdx.x * kV + u] = make_uint4(cw[8u * u + 1u], cw[8u * u + 3u], cw[8u * u + 5u], cw[8u * u + 7u]);
-            }
+            wo4[threadIdx.x * 2u] = make_uint4(cw[0], cw[2], cw[4], cw[6]); wo4[threadIdx.x * 2u + 1u] = make_uint4(cw[8], cw[10], cw[12], cw[14]);
+            wo4[kBucketCap / 4u + threadIdx.x * 2u] = make_uint4(cw[1], cw[3], cw[5], cw[7]); wo4[kBucketCap / 4u + threadIdx.x * 2u + 1u] = make_uint4(cw[9], cw[11], cw[13], cw[15]);
         }
         if (threadIdx.x == 0) s_vs[nvox] = (uint16_t)(ttot & 0xFFFFu);
     }
@@ -1686,8 +1650,8 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     PCOP_STAMP(F, 2, 7, 150);
 #pragma unroll
     for (uint32_t j = 0; j < kItemsB; ++j) {
-        if (actp[j]) {
-            const uint32_t slot = ((s_wc[wword * kIdsPass + idp[j]] >> wshift) & 0xFFFFu) + rank[j];
+        if (act[j]) {
+            const uint32_t slot = ((s_wc[wword * kBucketCap + id[j]] >> wshift) & 0xFFFFu) + rank[j];
             const uint32_t ps = slot + (slot >> 5);
             stage_x[ps] = rec[j].x; stage_y[ps] = rec[j].y; stage_z[ps] = rec[j].z;
         }
@@ -1712,9 +1676,8 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     }
     nv_acc += nvox;
     PCOP_STAMP(F, 2, 20, 150);
-    __syncthreads();   // the next pass / part / bucket clears and fills the same LDS
-    }   // passes over the id range
-    }   // parts of a heavy bucket
+    __syncthreads();   // the next bucket clears and fills the same LDS
+    }
     if (threadIdx.x == 0) {   // k_voxel_gather adds the counts up to output ranks
         if (failed) { if (!heavy || !st->err) atomicOr(&st->err, (uint32_t)kErrInternal); bucket_pub[b] = 0u; }
         else bucket_pub[b] = nv_acc;

@@ -16,4 +16,5 @@ cp $O/sor.json profiles/${tag}_sor.json
 cp $O/node_chain.json profiles/${tag}_node_chain.json
 cp $O/sq_lds.txt profiles/${tag}_sq_lds.txt
 cp $O/fuzz_stateful.txt profiles/${tag}_fuzz_stateful.txt
+[ -s $O/pool.json ] && cp $O/pool.json profiles/${tag}_pool.json
 ls -la profiles/${tag}_*

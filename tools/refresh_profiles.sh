@@ -4,8 +4,10 @@
 set -e
 tag=${1:-r02}
 B=${2:-32}
+PART=${3:-all}   # all | a (the bench line, the traces, the counters) | b (configs, the steps next to the path, the pool, the fuzzer)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh_$tag
+if [ "$PART" != b ]; then
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
@@ -37,12 +39,18 @@ W=$(dirname $(find $O/pmc_WRITE_SIZE -name pmc_counter_collection.csv | head -1)
 python3 tools/pmc_summary.py $F $W $B $O/pmc_traffic.json > $O/pmc_summary.txt
 python3 tools/pmc_table.py $O/pmc_sq > $O/sq_lds.txt
 head -14 $O/kernel_summary_batch$B.txt; head -10 $O/pmc_summary.txt; tail -3 $O/kernel_summary_single_frame.txt
+python3 - <<PY
+import json; d=json.load(open("$O/bench.json")); print(d["value"], d["latency_ms_single_frame"], d["roofline"], d.get("cpu_baseline"), d.get("end_to_end"), d.get("parity"))
+PY
+fi
+if [ "$PART" != a ]; then
+mkdir -p $O; cd $R
+python3 tools/pool_bench.py 1 512 16 > $O/pool.json 2> $O/pool.err || true
+cat $O/pool.json
 python3 tests/tools/config_report.py > $O/configs.txt 2> $O/configs.err
 python3 tests/tools/occ_bench.py > $O/occupancy.json
 python3 tests/tools/sor_bench.py > $O/sor.json
 python3 tests/tools/node_bench.py > $O/node_chain.json
 python3 tests/tools/fuzz_stateful.py 90 5 2>&1 | grep -v "^  \.\.\." | tail -3 > $O/fuzz_stateful.txt
 echo "configs / occupancy / sor / node chain done"
-python3 - <<PY
-import json; d=json.load(open("$O/bench.json")); print(d["value"], d["latency_ms_single_frame"], d["roofline"], d.get("cpu_baseline"), d.get("end_to_end"), d.get("parity"))
-PY
+fi
