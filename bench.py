@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--rounds", type=int, default=10, help="rounds (every resident frame once) per step")
     ap.add_argument("--batch", type=int, default=32, help="frames per context, processed in the same launches (32: + 6 %% over 16 in one run on one box, for twice a batch's latency; BASELINE.md 5)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) in flight per GPU")
+    ap.add_argument("--feeders", default="threads", choices=["threads", "loop"], help="one host thread per context (default) or one loop over the contexts")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and the parity check that uses its results)")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -265,14 +266,41 @@ def worker(args):
                 pending[ci] = False
         return last_out[0]
 
-    for _ in range(args.warmup * args.rounds):
-        one_round()
-    last = drain()
+    # --feeders threads (the default): one host thread per context, each submitting and collecting its own context's batches - the
+    # structure of the C++ pool (host/pcop_pool: a feeder thread per GPU).  What a context's thread does between two batches - the clusters
+    # of 32 frames put in PCL's order, the next batch's mailboxes, the graph launch: about half a millisecond - then no longer keeps
+    # the other contexts' next batches waiting (the library releases no lock: contexts are independent; ctypes drops the GIL for the call).
+    # --feeders loop: the single-threaded rolling submission of rounds 1-3.
+    def run_rounds(nrounds):
+        if args.feeders == "loop" or NC == 1:
+            for _ in range(nrounds):
+                one_round()
+            return drain()
+        import threading
+        outs = [None] * NC
+        errs = []
+
+        def feed(ci):
+            try:
+                c, (pp, nn) = ctxs[ci], ptrs[ci]
+                for _ in range(nrounds):
+                    c.submit_batch_device(pp, nn)
+                    outs[ci] = c.wait_batch(want_arrays=False)[-1]
+            except Exception as ex:   # (reported by the main thread)
+                errs.append(ex)
+        th = [threading.Thread(target=feed, args=(ci,)) for ci in range(NC)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        if errs:
+            raise errs[0]
+        return outs[-1]
+
+    last = run_rounds(args.warmup * args.rounds)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps * args.rounds):
-        one_round()
-    last = drain()
+    last = run_rounds(args.steps * args.rounds)
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -390,7 +418,7 @@ def worker(args):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-pt ground-plane + 20 boxes (L=4.5 m), leaf %g m, tol %g m, clusters %d..%d"
                        % (args.config, n0, p["leaf"], p["tol"], p["min_cluster"], p["max_cluster"]),
-                       "frames_in_flight_per_gpu": F, "batch_per_launch": B, "contexts_per_gpu": NC, "rounds_per_step": args.rounds,
+                       "frames_in_flight_per_gpu": F, "batch_per_launch": B, "contexts_per_gpu": NC, "host_feeders": ("one thread per context" if args.feeders == "threads" and NC > 1 else "one loop"), "rounds_per_step": args.rounds,
                        "frames_per_step": F * world * args.rounds, "timed_region_s": dt, "voxels_per_frame": int(m_vox),
                        "input": "XYZ SoA resident in HBM", "parallelism": "frame-sharded, %d rank(s)" % world},
             "latency_ms_single_frame": lat_ms,
