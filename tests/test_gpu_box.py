@@ -305,3 +305,40 @@ def test_cloud_far_from_the_origin_keeps_its_bounds_pass(capi, oracle):
         st = run(c, [pts, pts[::-1].copy()], [ref, oracle.process_xyz(pts[::-1].copy(), **p)])
         assert st.sbox == 0, rep
     c.close()
+
+
+def test_contexts_fed_from_threads_of_one_process(capi, oracle):
+    """Three batch contexts of one process, each fed by its own thread (how bench.py and host/pcop_pool.cpp drive a GPU), with
+    batches of different shapes in flight at once: every frame of every round bit-exact against the oracle."""
+    import threading
+    p = synth.params_of("C3")
+    shapes = [(6, 120_000), (4, 200_000), (8, 60_000)]
+    ctxs, work = [], []
+    for t, (B, n) in enumerate(shapes):
+        c = capi.Context(n, max_frames=B)
+        c.set_params(publish_clouds=1, **p)
+        clouds = [synth.make_cloud("C3", seed=7100 + 10 * t + i, n=n) for i in range(B)]
+        refs = [oracle.process_xyz(x, **p) for x in clouds]
+        ctxs.append(c); work.append((clouds, refs))
+    errs = []
+
+    def feed(c, clouds, refs):
+        try:
+            for rnd in range(6):
+                k = len(clouds) if rnd % 3 else max(2, len(clouds) // 2)   # a shorter batch now and then: another graph
+                c.submit_batch_host(clouds[:k])
+                got = c.wait_batch()
+                for g, r in zip(got, refs[:k]):
+                    same(g, r)
+        except BaseException as e:   # noqa: BLE001 - handed to the main thread
+            errs.append(e)
+
+    th = [threading.Thread(target=feed, args=(c, *w)) for c, w in zip(ctxs, work)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for c in ctxs:
+        c.close()
+    if errs:
+        raise errs[0]
