@@ -181,8 +181,13 @@ def worker(args):
         sys.stderr.write("bench.py: WORLD_SIZE (%d) does not match --gpus (%d)\n" % (world, args.gpus))
         sys.exit(2)
     on_gpu = not args.dry
+    bound_cpus = 0
     if on_gpu:
         torch.cuda.set_device(local_rank)
+        if os.environ.get("PCOP_BENCH_NO_BIND") != "1":
+            # this rank's threads and pinned buffers next to its GPU (8 ranks on a two-socket host would otherwise run anywhere)
+            from pointcloud_obstacle_processing_amd import capi as _capi
+            bound_cpus = _capi.bind_thread_near_device(local_rank)
     # PCOP_BENCH_FORCE_DIST=1 exercises the collective path (init, broadcast, barrier, all-reduce) with one rank too
     use_dist = world > 1 or os.environ.get("PCOP_BENCH_FORCE_DIST") == "1"
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
@@ -418,7 +423,7 @@ def worker(args):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-pt ground-plane + 20 boxes (L=4.5 m), leaf %g m, tol %g m, clusters %d..%d"
                        % (args.config, n0, p["leaf"], p["tol"], p["min_cluster"], p["max_cluster"]),
-                       "frames_in_flight_per_gpu": F, "batch_per_launch": B, "contexts_per_gpu": NC, "host_feeders": ("one thread per context" if args.feeders == "threads" and NC > 1 else "one loop"), "rounds_per_step": args.rounds,
+                       "frames_in_flight_per_gpu": F, "batch_per_launch": B, "contexts_per_gpu": NC, "host_feeders": ("one thread per context" if args.feeders == "threads" and NC > 1 else "one loop"), "rounds_per_step": args.rounds, "cpus_bound_near_gpu": bound_cpus,
                        "frames_per_step": F * world * args.rounds, "timed_region_s": dt, "voxels_per_frame": int(m_vox),
                        "input": "XYZ SoA resident in HBM", "parallelism": "frame-sharded, %d rank(s)" % world},
             "latency_ms_single_frame": lat_ms,

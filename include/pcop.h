@@ -314,6 +314,13 @@ int pcop_dev_free(pcop_ctx* ctx, void* dev_ptr);
 int pcop_dev_upload(pcop_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
 int pcop_dev_download(pcop_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
 int pcop_device_count(void);
+/* Keeps the CALLING thread (and the threads it starts afterwards) on the CPUs next to GPU `device_id`
+ * (/sys/bus/pci/devices/<bus id>/local_cpulist, intersected with the CPUs the thread may run on now), so that the pinned buffers it
+ * allocates and first touches - a context's mailboxes and result buffers, a pool's staging slots - sit on the GPU's NUMA node.
+ * Call it before pcop_create on that thread.  Returns the number of CPUs the thread is bound to, 0 when nothing was changed
+ * (no NUMA information, or fewer than four of those CPUs are allowed to this thread), PCOP_ERR_NO_DEVICE for a device that does not exist.
+ * No counterpart in the reference (one GPU-less process, od.cpp:995-1001); used by host/pcop_pool.cpp's workers and bench.py's ranks. */
+int pcop_bind_thread_near_device(int device_id);
 
 /* Test hook: device address and size of a named internal buffer of the last frame
  * ("cen_x", "rec_a", "cell_key", "parent", "label", ... ; "state" = the frame's DevState; "name@k": frame slot k of a batch).
@@ -325,6 +332,8 @@ int pcop_debug_buffer(pcop_ctx* ctx, const char* name, void** dev_ptr, size_t* b
  * ranks come from lane-ordered LDS atomics, 0 once a self-check sent the context back to peer masks; "stream_checked": the
  * streaming voxel path's partition has been verified against the peer-mask ranks). */
 int pcop_debug_counter(pcop_ctx* ctx, const char* name, uint64_t* value);
+/* Test hook: the CPU-list parser behind pcop_bind_thread_near_device ("0-47,96-143"); returns the number of CPUs or PCOP_ERR_ARG. */
+int pcop_debug_parse_cpulist(const char* txt, int32_t* cpus, int32_t cap);
 
 #ifdef __cplusplus
 }

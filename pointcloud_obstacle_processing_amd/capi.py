@@ -22,7 +22,7 @@ EXPORTS = [
     "pcop_dev_alloc", "pcop_dev_free", "pcop_dev_upload", "pcop_dev_download", "pcop_device_count",
     "pcop_set_cloud_layout", "pcop_cluster_cloud", "pcop_process_node", "pcop_process_node_clouds", "pcop_process_node_pointcloud2", "pcop_segment_planes", "pcop_segment_planes_clouds", "pcop_debug_buffer", "pcop_debug_counter", "pcop_create_batch", "pcop_max_frames", "pcop_submit_batch", "pcop_wait_batch",
     "pcop_cluster_summaries_frame", "pcop_occupancy_grid_dims", "pcop_occupancy_filter", "pcop_process_filtered",
-    "pcop_statistical_outlier_removal",
+    "pcop_statistical_outlier_removal", "pcop_bind_thread_near_device", "pcop_debug_parse_cpulist",
 ]
 
 
@@ -198,12 +198,24 @@ def load_library():
     L.pcop_dev_download.argtypes = [vp, C.c_void_p, vp, C.c_size_t]
     L.pcop_device_count.restype = C.c_int
     L.pcop_device_count.argtypes = []
+    L.pcop_bind_thread_near_device.restype = C.c_int
+    L.pcop_bind_thread_near_device.argtypes = [C.c_int]
+    L.pcop_debug_parse_cpulist.restype = C.c_int
+    L.pcop_debug_parse_cpulist.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32]
     L.pcop_debug_counter.restype = C.c_int
     L.pcop_debug_counter.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
     L.pcop_debug_buffer.restype = C.c_int
     L.pcop_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     _lib = L
     return L
+
+
+def bind_thread_near_device(device=0):
+    """pcop_bind_thread_near_device: the calling thread (and those it starts) onto the CPUs next to the GPU; the number of CPUs, 0 = unchanged."""
+    rc = load_library().pcop_bind_thread_near_device(int(device))
+    if rc < 0:
+        raise PcopError(rc, "pcop_bind_thread_near_device")
+    return rc
 
 
 def pack_points(xyz, layout):

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <sched.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -160,8 +161,8 @@ struct pcop_ctx {
     bool crowded_cells = false;
     // A second hook round at tree level (k_cgrid_hook2) before the union: the first round leaves a tree per dozen cells, and the union
     // kernel merges trees pair by pair, by CAS (C3, 16 frames: union 49 -> 14 us for 23 us of hook2 + compress2, and shallower trees for
-    // k_cell_flatten; C5: 251 k trees -> 20 k).  Two more launches: not for frames of a few thousand cells.  Chosen from the previous
-    // batch's cells (PCOP_HOOK2=0|1 pins it); either choice gives the same result.
+    // k_cell_flatten; C5: 251 k trees -> 20 k).  Two more launches: not for frames of a few thousand cells, and not for a frame on its own below
+    // 2^16 cells (C3 alone: union 5.8 -> 4.8 us for 13 us).  Chosen from the previous batch's cells (PCOP_HOOK2=0|1 pins it); either choice gives the same result.
     bool hook2 = false, hook2_fixed = false;
     bool scat_big = true;            // PCOP_SCAT_BIG=0: the partition always in chunks of 4096 points (default: 8192 where the tile and the LDS allow)
     uint32_t ctiles = kCmapCells / 32u / kVmapTile;
@@ -798,8 +799,10 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             uint32_t most = 0;
             for (uint32_t f = 0; f < c->nframes; ++f) if (!c->slots[f].result_trivial) most = std::max(most, c->slots[f].h_state->n_cells);
             // (well-filled cells only: with a point or two to a cell - C5 - the round's pair tests cost what the union saves)
-            if (most >= (1u << 12) && pts >= 3 * cells) c->hook2 = true;
-            else if (most < (1u << 11) || 2 * pts < 5 * cells) c->hook2 = false;
+            // (a frame on its own: the union of a 20 k-cell frame is 6 us, the round's two launches 13 - only far bigger grids get it)
+            const uint32_t on_at = c->nframes > 1 ? (1u << 12) : (1u << 16);
+            if (most >= on_at && pts >= 3 * cells) c->hook2 = true;
+            else if (most < on_at / 2 || 2 * pts < 5 * cells) c->hook2 = false;
         }
     }
     if (grid_on(c)) {
@@ -1253,6 +1256,60 @@ extern "C" {
 int pcop_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// "0-47,96-143" -> CPU numbers (the format of /sys/bus/pci/devices/*/local_cpulist); false on anything else
+static bool parse_cpulist(const char* txt, std::vector<int>* cpus) {
+    cpus->clear();
+    const char* p = txt;
+    while (*p && *p != '\n') {
+        char* end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p || a < 0) return false;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            ++p;
+            b = strtol(p, &end, 10);
+            if (end == p || b < a) return false;
+            p = end;
+        }
+        if (b - a > 1 << 16) return false;
+        for (long v = a; v <= b; ++v) cpus->push_back((int)v);
+        if (*p == ',') ++p;
+        else if (*p && *p != '\n') return false;
+    }
+    return true;
+}
+
+int pcop_debug_parse_cpulist(const char* txt, int32_t* cpus, int32_t cap) {
+    std::vector<int> v;
+    if (!txt || !parse_cpulist(txt, &v)) return PCOP_ERR_ARG;
+    for (size_t i = 0; i < v.size() && (int32_t)i < cap && cpus; ++i) cpus[i] = v[i];
+    return (int)v.size();
+}
+
+int pcop_bind_thread_near_device(int device_id) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device_id) != hipSuccess) return PCOP_ERR_NO_DEVICE;
+    for (char* q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return 0;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    std::vector<int> local;
+    if (!got || !parse_cpulist(line, &local) || local.empty()) return 0;
+    cpu_set_t now, want;
+    CPU_ZERO(&now); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof now, &now) != 0) return 0;
+    int n = 0;
+    for (int cpu : local)
+        if (cpu < CPU_SETSIZE && CPU_ISSET(cpu, &now)) { CPU_SET(cpu, &want); ++n; }
+    if (n < 4) return 0;                        // (almost) none of the GPU's CPUs is ours to run on (a cpuset): stay where we are rather than squeeze a feeder's threads onto one core
+    if (sched_setaffinity(0, sizeof want, &want) != 0) return 0;
     return n;
 }
 

@@ -125,6 +125,7 @@ void GpuPool::run(Worker* w) {
     // its way to the GPU, one being worked on
     const int nslots = 3 * batch_;
     {
+        pcop_bind_thread_near_device(w->device);   // the staging slots and the contexts' pinned buffers on the GPU's NUMA node (0 = stays where it is)
         hipError_t he = hipSetDevice(w->device);
         if (he != hipSuccess) setup_error = hip_msg("hipSetDevice", he);
         for (int s = 0; s < nslots && setup_error.empty(); ++s) {

@@ -69,3 +69,30 @@ def test_root_tools_do_not_touch_the_oracle():
         if f.endswith((".py", ".sh")):
             text = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
             assert "pcop_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_cpu_list_parser_behind_the_numa_binding(lib):
+    """pcop_bind_thread_near_device reads /sys/bus/pci/devices/<bus id>/local_cpulist: the parser on the forms the kernel writes."""
+    from pointcloud_obstacle_processing_amd import capi
+    capi.load_library()
+    buf = (C.c_int32 * 512)()
+
+    def parse(txt):
+        n = lib.pcop_debug_parse_cpulist(txt, buf, 512)
+        return n if n < 0 else list(buf[:n])
+
+    assert parse(b"0-3\n") == [0, 1, 2, 3]
+    assert parse(b"0-47,96-143\n") == list(range(48)) + list(range(96, 144))
+    assert parse(b"5") == [5]
+    assert parse(b"1,3,5-6") == [1, 3, 5, 6]
+    assert parse(b"") == []
+    assert parse(b"3-1") == -1 and parse(b"a-b") == -1 and parse(b"1;2") == -1
+
+
+def test_numa_binding_without_a_device_changes_nothing(lib):
+    if lib.pcop_device_count() > 0:
+        pytest.skip("a GPU is present")
+    before = os.sched_getaffinity(0)
+    lib.pcop_bind_thread_near_device.restype = C.c_int
+    assert lib.pcop_bind_thread_near_device(0) == -3
+    assert os.sched_getaffinity(0) == before
