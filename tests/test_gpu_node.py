@@ -211,3 +211,30 @@ def test_node_harness_pool(oracle, tmp_path, gpus, same):
         assert len(clusters) == len(ref["offsets"]) - 1
         for c, idx in enumerate(clusters):
             assert np.array_equal(idx, ref["indices"][ref["offsets"][c]:ref["offsets"][c + 1]])
+
+
+def test_binding_a_thread_next_to_the_gpu():
+    """pcop_bind_thread_near_device (what host/pcop_pool.cpp's workers and bench.py's ranks call before they allocate pinned memory): a
+    thread of its own is bound to a subset of the CPUs it could run on before - the GPU's local_cpulist - or left alone (0: no NUMA
+    information, or a cpuset that leaves fewer than four of them); the calling process keeps its own mask; a device that does not
+    exist is refused."""
+    import threading
+    from pointcloud_obstacle_processing_amd import capi
+    lib = capi.load_library()
+    before = os.sched_getaffinity(0)
+    seen = {}
+
+    def worker():
+        seen["rc"] = lib.pcop_bind_thread_near_device(0)
+        seen["mask"] = os.sched_getaffinity(0)   # (tid 0 = the calling thread)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert seen["rc"] >= 0
+    if seen["rc"] > 0:
+        assert len(seen["mask"]) == seen["rc"] and seen["mask"] <= before and seen["rc"] >= 4
+    else:
+        assert seen["mask"] == before
+    assert os.sched_getaffinity(0) == before
+    assert lib.pcop_bind_thread_near_device(4096) == -3
