@@ -161,8 +161,8 @@ struct pcop_ctx {
     bool crowded_cells = false;
     // A second hook round at tree level (k_cgrid_hook2) before the union: the first round leaves a tree per dozen cells, and the union
     // kernel merges trees pair by pair, by CAS (C3, 16 frames: union 49 -> 14 us for 23 us of hook2 + compress2, and shallower trees for
-    // k_cell_flatten; C5: 251 k trees -> 20 k).  Two more launches: not for frames of a few thousand cells, and not for a frame on its own below
-    // 2^16 cells (C3 alone: union 5.8 -> 4.8 us for 13 us).  Chosen from the previous batch's cells (PCOP_HOOK2=0|1 pins it); either choice gives the same result.
+    // k_cell_flatten; C5: 251 k trees -> 20 k).  Two more launches: not for frames of a few thousand cells.  Chosen from the previous
+    // batch's cells (PCOP_HOOK2=0|1 pins it); either choice gives the same result.
     bool hook2 = false, hook2_fixed = false;
     bool scat_big = true;            // PCOP_SCAT_BIG=0: the partition always in chunks of 4096 points (default: 8192 where the tile and the LDS allow)
     uint32_t ctiles = kCmapCells / 32u / kVmapTile;
@@ -196,6 +196,7 @@ namespace {
             char buf_[512];                                                                      \
             snprintf(buf_, sizeof(buf_), "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
             (ctx)->err = buf_;                                                                   \
+            (void)hipGetLastError();   /* reported here: not once more after somebody's next launch */ \
             return PCOP_ERR_HIP;                                                                 \
         }                                                                                        \
     } while (0)
@@ -799,10 +800,10 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             uint32_t most = 0;
             for (uint32_t f = 0; f < c->nframes; ++f) if (!c->slots[f].result_trivial) most = std::max(most, c->slots[f].h_state->n_cells);
             // (well-filled cells only: with a point or two to a cell - C5 - the round's pair tests cost what the union saves)
-            // (a frame on its own: the union of a 20 k-cell frame is 6 us, the round's two launches 13 - only far bigger grids get it)
-            const uint32_t on_at = c->nframes > 1 ? (1u << 12) : (1u << 16);
-            if (most >= on_at && pts >= 3 * cells) c->hook2 = true;
-            else if (most < on_at / 2 || 2 * pts < 5 * cells) c->hook2 = false;
+            // (a frame on its own gains as well - tests/tools/hook2_latency.py, one run: C3 0.209 -> 0.201 ms, C3 with L = 10 m 0.283 -> 0.242 ms -
+            //  although the kernel sums say otherwise: the union's walk is a chain of dependent finds, and shallower trees shorten it)
+            if (most >= (1u << 12) && pts >= 3 * cells) c->hook2 = true;
+            else if (most < (1u << 11) || 2 * pts < 5 * cells) c->hook2 = false;
         }
     }
     if (grid_on(c)) {
@@ -1255,7 +1256,7 @@ extern "C" {
 
 int pcop_device_count(void) {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
 
@@ -1292,7 +1293,10 @@ int pcop_debug_parse_cpulist(const char* txt, int32_t* cpus, int32_t cap) {
 
 int pcop_bind_thread_near_device(int device_id) {
     char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device_id) != hipSuccess) return PCOP_ERR_NO_DEVICE;
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device_id) != hipSuccess) {
+        (void)hipGetLastError();   // (the runtime keeps the failure as the thread's last error: it must not surface after somebody's next launch)
+        return PCOP_ERR_NO_DEVICE;
+    }
     for (char* q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);
     const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
     FILE* f = fopen(path.c_str(), "r");
@@ -1333,7 +1337,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     *out = nullptr;
     if (max_points == 0 || max_points > 0x3FFFFFF0ull || max_frames < 1 || max_frames > 1024) return PCOP_ERR_ARG;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PCOP_ERR_NO_DEVICE;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return PCOP_ERR_NO_DEVICE; }
     if (device_id < 0 || device_id >= ndev) return PCOP_ERR_NO_DEVICE;
     pcop_ctx* c = new (std::nothrow) pcop_ctx();
     if (!c) return PCOP_ERR_ARG;
@@ -1370,7 +1374,7 @@ int pcop_create_batch(pcop_ctx** out, int device_id, size_t max_points, int max_
     const size_t hcap = hash_cap_for((uint32_t)n);
     c->hash_cap = hcap;
     const size_t nscan = std::max((n + kScanTile - 1) / kScanTile, hcap / kScanTile) + 1;
-    if (hipSetDevice(device_id) != hipSuccess) { delete c; return PCOP_ERR_NO_DEVICE; }
+    if (hipSetDevice(device_id) != hipSuccess) { (void)hipGetLastError(); delete c; return PCOP_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PCOP_ERR_HIP; }
     int rc = PCOP_OK;
     c->slots.resize(c->max_frames);

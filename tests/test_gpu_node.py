@@ -238,3 +238,24 @@ def test_binding_a_thread_next_to_the_gpu():
         assert seen["mask"] == before
     assert os.sched_getaffinity(0) == before
     assert lib.pcop_bind_thread_near_device(4096) == -3
+
+
+def test_a_refused_call_leaves_no_hip_error_behind_for_the_next_launch(oracle):
+    """The HIP runtime keeps a failed call as the thread's last error, and the library checks hipGetLastError() after its launches: a
+    refused pcop_bind_thread_near_device / pcop_create (a device that does not exist) must not turn the next frame of a healthy context
+    into PCOP_ERR_HIP."""
+    import ctypes as C
+    from pointcloud_obstacle_processing_amd import capi
+    lib = capi.load_library()
+    pts = synth.make_cloud("C1")
+    p = synth.params_of("C1")
+    ref = oracle.process_xyz(pts, **p)
+    c = capi.Context(len(pts))
+    c.set_params(publish_clouds=1, **p)
+    c.process_xyz(pts)
+    assert lib.pcop_bind_thread_near_device(4096) == -3
+    h = C.c_void_p()
+    assert lib.pcop_create(C.byref(h), 4096, 1000) == -3
+    got = c.process_xyz(pts)
+    assert np.array_equal(got["offsets"], ref["offsets"]) and np.array_equal(got["indices"], ref["indices"])
+    c.close()
