@@ -19,7 +19,7 @@ namespace pcop {
 //   k_cell_mark     grid position of every point; one byte per occupied cell (a chain frame's centroids mark theirs as
 //                   k_voxel_gather / k_voxel_reduce write them: no launch of this kernel)
 //   k_occ_scan      bytes -> occupancy bits + running popcount => cell ids, n_cells
-//   k_cell_count    points per cell, rank inside the cell, smallest point index (= priority)
+//   k_cell_count    points per cell, rank inside the cell
 //   k_cell_starts   exclusive scan of the counts; per-cell metadata; union-find init
 //   k_cell_place    (shared with the hash path) records sorted by cell
 //   k_cgrid_hook / k_cell_compress / [k_cgrid_hook2 / k_cell_compress2] / k_cgrid_union   components, lane = cell
@@ -129,14 +129,14 @@ __global__ __launch_bounds__(kBlock) void k_cell_count(Frame* frames) {
     Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
     const uint2* __restrict__ cmap = F.cmap; const uint32_t* __restrict__ pt_pos = F.pt_root;
-    uint32_t* __restrict__ ccount = F.hcount; uint32_t* __restrict__ cmin = F.hmin;
+    uint32_t* __restrict__ ccount = F.hcount;
     uint32_t* __restrict__ pt_slot = F.pt_slot; uint32_t* __restrict__ pt_rank = F.pt_rank;
     uint32_t* __restrict__ cell_pos = F.cell_list;
     if (cgrid_off(st)) return;
     const uint32_t n = st->c_n;
     const uint32_t lane = lane_id();
     const uint32_t nthreads = gridDim.x * blockDim.x;
-    // ccount is all zero and cmin all ones on entry: k_emit leaves the borrowed arrays that way
+    // ccount is all zero on entry (and hmin, which k_cell_flatten uses, all ones): k_emit leaves the borrowed arrays that way
     for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += nthreads) {
         const uint32_t i = base + lane;
         const bool valid = i < n;
@@ -152,7 +152,6 @@ __global__ __launch_bounds__(kBlock) void k_cell_count(Frame* frames) {
             const uint64_t later = lane == 63 ? 0ull : (breaks >> (lane + 1));
             const uint32_t runlen = later ? (uint32_t)__ffsll((unsigned long long)later) : (uint32_t)(kWave - lane);
             rank0 = atomicAdd(ccount + cid, runlen);
-            atomicMin(cmin + cid, i);
             cell_pos[cid] = pos;   // every writer of a cell stores the same value
         }
         const uint64_t le = leaders & (lanemask_lt() | (1ull << lane));
@@ -163,13 +162,17 @@ __global__ __launch_bounds__(kBlock) void k_cell_count(Frame* frames) {
 }
 
 // cell_start = exclusive scan of the counts (tiles publish / add up the lower tiles); per-cell
-// metadata {first record, points, smallest point index, grid position}; union-find init
+// metadata {first record, points, priority, grid position}; union-find init.  The priority of a cell (who becomes whose
+// parent) is its id: ids follow the grid, so the 13 backward cells of a cell all have smaller ones.  The first point of a
+// component - extract()'s discovery order - is taken where the components are known (k_cell_flatten), so no per-cell minimum
+// of point indices is kept (rounds 1-3 kept one: an atomicMin per run of points in k_cell_count, a priority load per root
+// in the hook and union kernels).
 __global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames, uint32_t hook2) {
     __shared__ uint32_t s_w[kWavesPerBlock + 1];
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     unsigned long long* __restrict__ cand = reinterpret_cast<unsigned long long*>(F.cell_info.get());
-    const uint32_t* __restrict__ ccount = F.hcount; const uint32_t* __restrict__ cmin = F.hmin;
+    const uint32_t* __restrict__ ccount = F.hcount;
     const uint32_t* __restrict__ cell_pos = F.cell_list;
     uint32_t* __restrict__ tile_pub = F.tile_b;
     uint32_t* __restrict__ cell_start = F.cell_start; uint32_t* __restrict__ parent = F.parent;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_starts(Frame* frames, uint32_t 
         if (id < nc) {
             cell_start[id] = run;
             parent[id] = id; comp_size[id] = 0u; comp_rank[id] = 0xFFFFFFFFu;
-            slot_meta[id] = make_uint4(run, v[k], cmin[id], cell_pos[id]);
+            slot_meta[id] = make_uint4(run, v[k], id, cell_pos[id]);   // {first record, points, priority = id, grid position}
             if (hook2) cand[id] = ~0ull;   // k_cgrid_hook2's candidate parent of a root: none yet
         }
         run += v[k];
@@ -241,10 +244,10 @@ __device__ __forceinline__ uint32_t row_window(const uint2* __restrict__ cmap, u
     return bits & ((1u << width) - 1u);
 }
 
-// parent[c] = the adjacent cell of smallest priority among the 13 backward cells of the 3x3x3
-// neighbourhood (5 rows), if it has a smaller priority than c.  No atomics: a forest.
+// parent[c] = the adjacent cell of smallest id among the 13 backward cells of the 3x3x3
+// neighbourhood (5 rows; all of them have smaller ids than c).  No atomics: a forest.
 // Two rounds of independent loads (row windows, then the metadata of the 13 neighbour slots; a slot
-// without a neighbour re-reads the cell's own), then pair tests only against cells of smaller priority.
+// without a neighbour re-reads the cell's own), then pair tests only against cells of smaller id than the best so far.
 __global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
     const Frame& F = frames[blockIdx.y];
     const DevState* st = &F.st;
@@ -289,13 +292,11 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_hook(const Frame* frames) {
                 ++slot;
             }
         }
-        unsigned long long best = ~0ull;
+        uint32_t best = c;   // (a slot without a neighbour holds c itself)
 #pragma unroll
-        for (int q = 0; q < 13; ++q) {
-            const unsigned long long key = ((unsigned long long)mb[q].z << 32) | nid[q];
-            if (mb[q].z < ma.z && key < best && lane_cells_hit(rec, ma.x, ma.y, mb[q].x, mb[q].y, r2)) best = key;
-        }
-        if (best != ~0ull) parent[c] = (uint32_t)best;
+        for (int q = 0; q < 13; ++q)
+            if (nid[q] < best && lane_cells_hit(rec, ma.x, ma.y, mb[q].x, mb[q].y, r2)) best = nid[q];
+        if (best != c) parent[c] = best;
     }
 }
 
@@ -315,7 +316,6 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_hook2(const Frame* frames) {
     const uint2* __restrict__ cmap = F.cmap;
     const uint4* __restrict__ slot_meta = F.slot_meta;
     const uint32_t* __restrict__ parent = F.parent;
-    const uint32_t* __restrict__ prio = F.hmin;
     unsigned long long* __restrict__ cand = reinterpret_cast<unsigned long long*>(F.cell_info.get());   // (the hash path's per-cell records: idle on the grid)
     if (cgrid_off(st) || st->debug_skip_union == 1u) return;
     const uint32_t nc = st->n_cells, c_n = st->c_n, grid_cells = st->cmap_words * 32u;
@@ -357,11 +357,11 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_hook2(const Frame* frames) {
 #pragma unroll
         for (int q = 0; q < 13; ++q) any |= rb[q] != ra;
         if (!any) continue;
-        const uint32_t pa = prio[ra];
+        const uint32_t pa = ra;   // (priority = id)
 #pragma unroll 1
         for (int q = 0; q < 13; ++q) {
             if (rb[q] == ra) continue;
-            const uint32_t pb = prio[rb[q]];
+            const uint32_t pb = rb[q];
             const uint32_t hi = pa > pb ? ra : rb[q], lo = pa > pb ? rb[q] : ra;
             const unsigned long long key = ((unsigned long long)min(pa, pb) << 32) | lo;
             if (key >= cand[hi]) continue;   // (a stale read only costs a pair test: the atomicMin decides)
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_union(const Frame* frames, uin
             // some neighbour may be in another set: walk the rows again and look properly at those whose parent word
             // differs from the cell's (roots, pair test, union by CAS)
             const float4* __restrict__ rec = F.rec_a;
-            const uint32_t* __restrict__ prio = F.hmin;
+            const uint32_t* __restrict__ prio = nullptr;   // (priority = id)
             const float r2 = st->r2;
             uint32_t ra = uf_find(parent, c);
 #pragma unroll 1
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_cgrid_fix(const Frame* frames) {
     const float4* __restrict__ rec = F.rec_a;
     const uint2* __restrict__ cmap = F.cmap;
     const uint4* __restrict__ slot_meta = F.slot_meta;
-    const uint32_t* __restrict__ prio = F.hmin;
+    const uint32_t* __restrict__ prio = nullptr;   // (priority = id)
     uint32_t* __restrict__ parent = F.parent;
     const uint32_t* __restrict__ fix_list = F.idx_a;
     if (cgrid_off(st) || st->debug_skip_union || !fix_by_wave(st, 1u)) return;

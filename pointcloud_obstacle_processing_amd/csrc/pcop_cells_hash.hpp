@@ -243,7 +243,7 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, const uint32_t* __res
         a = uf_find(parent, a);
         b = uf_find(parent, b);
         if (a == b) return;
-        if (prio[a] > prio[b]) { const uint32_t t = a; a = b; b = t; }
+        if (prio ? prio[a] > prio[b] : a > b) { const uint32_t t = a; a = b; b = t; }   // (no priority array: the dense grid, where a cell's id is its priority)
         // hang the root of larger priority value b under a
         const uint32_t old = atomicCAS(parent + b, b, a);
         if (old == b) return;

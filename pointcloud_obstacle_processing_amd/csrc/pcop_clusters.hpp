@@ -4,7 +4,8 @@
 
 namespace pcop {
 
-// Root cell of every point; component sizes.  Each wave walks a contiguous chunk of points 64
+// Root cell of every point; component sizes; on the dense grid also the first point of every component (hmin[root]: on the hash
+// path the root is the cell that holds it and has it already).  Each wave walks a contiguous chunk of points 64
 // at a time; lanes whose points share a root add up in registers, and the count of the root a
 // wave is currently running through is carried across steps, so a component that spans a long
 // stretch of points (a ground plane) costs one atomic per wave, not one per step.
@@ -13,8 +14,9 @@ __global__ __launch_bounds__(kBlock) void k_cell_flatten(const Frame* frames) {
     const DevState* st = &F.st;
     const uint32_t* __restrict__ pt_slot = F.pt_slot;
     uint32_t* __restrict__ parent = F.parent; uint32_t* __restrict__ pt_root = F.pt_root;
-    uint32_t* __restrict__ comp_size = F.comp_size;
+    uint32_t* __restrict__ comp_size = F.comp_size; uint32_t* __restrict__ first_pt = F.hmin;
     if (cluster_stage_off(st)) return;
+    const bool firsts = st->cpath != 0;
     const uint32_t n = st->c_n;
     {   // k_kept_apply publishes one 64-bit word per tile of points in `table` (free between the voxel and the CSR passes)
         unsigned long long* __restrict__ tile_pub = reinterpret_cast<unsigned long long*>(F.table.get());
@@ -44,6 +46,8 @@ __global__ __launch_bounds__(kBlock) void k_cell_flatten(const Frame* frames) {
             } else {
                 if (carry_cnt && lane == 0) atomicAdd(comp_size + carry_root, carry_cnt);
                 carry_root = rl; carry_cnt = cnt;
+                // the wave walks its points in index order: the first one of a run is the smallest the wave will see of that root
+                if (firsts && lane == 0) atomicMin(first_pt + rl, sidx * kWave + (uint32_t)leader);
             }
             todo &= ~same;
         }

@@ -802,7 +802,7 @@ def test_cell_grid_ids_and_metadata(capi, oracle, monkeypatch):
     assert np.array_equal(meta[:, 3], upos.astype(np.uint32))                    # grid position
     first = np.full(len(upos), len(pts), dtype=np.int64)
     np.minimum.at(first, ids_ref, np.arange(len(pts)))
-    assert np.array_equal(meta[:, 2], first.astype(np.uint32))                   # priority = smallest point index
+    assert np.array_equal(meta[:, 2], np.arange(len(upos), dtype=np.uint32))     # priority = the cell's id (ids follow the grid)
     assert np.array_equal(meta[:, 0], np.concatenate(([0], np.cumsum(cnt_ref)[:-1])).astype(np.uint32))
     assert not c.debug_buffer("cflag", np.uint8, 1 << 24).any()
     c.close()
