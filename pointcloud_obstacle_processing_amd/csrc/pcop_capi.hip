@@ -799,11 +799,13 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
         if (!c->hook2_fixed) {   // (with hysteresis, like the choice above)
             uint32_t most = 0;
             for (uint32_t f = 0; f < c->nframes; ++f) if (!c->slots[f].result_trivial) most = std::max(most, c->slots[f].h_state->n_cells);
-            // (well-filled cells only: with a point or two to a cell - C5 - the round's pair tests cost what the union saves)
-            // (a frame on its own gains as well - tests/tools/hook2_latency.py, one run: C3 0.209 -> 0.201 ms, C3 with L = 10 m 0.283 -> 0.242 ms -
+            // (a frame on its own gains as well - tests/tools/latency_env.py PCOP_HOOK2 "0 1", one run: C3 0.209 -> 0.201 ms, C3 with L = 10 m 0.283 -> 0.242 ms -
             //  although the kernel sums say otherwise: the union's walk is a chain of dependent finds, and shallower trees shorten it)
-            if (most >= (1u << 12) && pts >= 3 * cells) c->hook2 = true;
-            else if (most < (1u << 11) || 2 * pts < 5 * cells) c->hook2 = false;
+            // Sparse cells (a point or two to a cell) get it on large grids only: C5's three million cells 1.49 -> 1.38 ms a frame, 2.44 -> 2.32 ms a batch
+            // of two (tests/tools/stage_times.py, since the hook kernels load no priorities); C1's nine thousand 0.240 -> 0.243 ms.
+            const bool filled = pts >= 3 * cells, filled_off = 2 * pts < 5 * cells;
+            if ((most >= (1u << 12) && filled) || most >= (1u << 18)) c->hook2 = true;
+            else if (most < (1u << 11) || (filled_off && most < (1u << 17))) c->hook2 = false;
         }
     }
     if (grid_on(c)) {
