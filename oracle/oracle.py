@@ -160,6 +160,7 @@ def voxel_keys(xyz, leaf, is_dense=True, layout=LAYOUT_AOS12):
 
 VARIANT_RECIPROCAL = 1   # centroid = sum * (1.0f / n): PCL 1.7 + Eigen 3.2
 VARIANT_DESCENDING = 2   # equal voxel keys keep descending point index: another order an unstable std::sort may leave
+VARIANT_STDSORT = 4      # equal voxel keys in the order std::sort leaves them when it compares the key alone (PCL's own call, this image's libstdc++)
 
 
 def voxel_downsample(xyz, leaf, is_dense=True, layout=LAYOUT_AOS12, variant=0):

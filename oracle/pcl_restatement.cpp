@@ -299,6 +299,7 @@ int pcop_oracle_voxel_keys(const float* xyz, int layout, size_t n, float leaf, i
 // cluster indices do not depend on them:
 //   bit 0: centroid = sum * (1.0f / n)  (PCL 1.7 + Eigen 3.2: the Vector4f accumulator's "/= n" multiplies by the reciprocal)
 //   bit 1: equal keys keep DESCENDING point index (one of the orders an unstable std::sort may leave)
+//   bit 2: equal keys in the order std::sort leaves them when it compares the key alone, as PCL's call does (this image's libstdc++)
 int pcop_oracle_voxel_downsample_ex(const float* xyz, int layout, size_t n, float leaf, int is_dense, int variant,
                                     float* out_xyz, size_t* out_m, int* passthrough);
 
@@ -327,6 +328,11 @@ int pcop_oracle_voxel_downsample_ex(const float* xyz, int layout, size_t n, floa
     }
     // "Second pass: sort the index_vector" — by key; ties by point index (canonical).
     const bool descending = (variant & 2) != 0;
+    if (variant & 4) {
+        // the call as PCL makes it: std::sort with cloud_point_index_idx::operator< - the key ALONE - so equal keys end up in whatever
+        // order this libstdc++'s introsort leaves them (the order a PCL built with the same library sums a voxel's points in)
+        std::sort(iv.begin(), iv.end(), [](const KeyIdx& a, const KeyIdx& b) { return a.key < b.key; });
+    } else
     std::sort(iv.begin(), iv.end(), [descending](const KeyIdx& a, const KeyIdx& b) {
         return a.key < b.key || (a.key == b.key && (descending ? a.idx > b.idx : a.idx < b.idx));
     });

@@ -25,7 +25,8 @@ def test_cluster_indices_do_not_depend_on_pcl_version_or_sort_order(oracle, cfg,
     pts = synth.make_cloud(cfg, seed=seed, n=n)
     base, pt = oracle.voxel_downsample(pts, p["leaf"])
     off0, idx0 = oracle.euclidean_clusters(base, p["tol"], p["min_cluster"], p["max_cluster"])
-    for variant in (oracle.VARIANT_RECIPROCAL, oracle.VARIANT_DESCENDING, oracle.VARIANT_RECIPROCAL | oracle.VARIANT_DESCENDING):
+    for variant in (oracle.VARIANT_RECIPROCAL, oracle.VARIANT_DESCENDING, oracle.VARIANT_RECIPROCAL | oracle.VARIANT_DESCENDING,
+                    oracle.VARIANT_STDSORT, oracle.VARIANT_STDSORT | oracle.VARIANT_RECIPROCAL):
         vox, pt_v = oracle.voxel_downsample(pts, p["leaf"], variant=variant)
         assert pt_v == pt and vox.shape == base.shape                       # same voxels, same order
         assert np.max(np.abs(vox - base), initial=0.0) < 1e-4               # the north star's centroid bound
@@ -34,6 +35,29 @@ def test_cluster_indices_do_not_depend_on_pcl_version_or_sort_order(oracle, cfg,
     # the reciprocal really is a different rounding somewhere (otherwise this test shows nothing)
     vox1, _ = oracle.voxel_downsample(pts, p["leaf"], variant=oracle.VARIANT_RECIPROCAL)
     assert vox1.tobytes() != base.tobytes() or cfg == "C1"
+
+
+def test_the_order_std_sort_itself_leaves_is_neither_ascending_nor_harmful(oracle):
+    """PCL's own call - std::sort comparing the voxel key alone - with this image's libstdc++: the order of a voxel's points is then
+    what introsort leaves, neither the canonical ascending one (which the GPU path reproduces) nor its reverse.  The sums differ in
+    their last bits from the canonical ones in some voxels (so the variant is a real one), never by the north star's 1e-4, and the
+    voxels, their order and every cluster index are the same."""
+    p = synth.params_of("C3")
+    pts = synth.make_cloud("C3", seed=11, n=300_000)
+    base, _ = oracle.voxel_downsample(pts, p["leaf"])
+    lit, _ = oracle.voxel_downsample(pts, p["leaf"], variant=oracle.VARIANT_STDSORT)
+    desc, _ = oracle.voxel_downsample(pts, p["leaf"], variant=oracle.VARIANT_DESCENDING)
+    assert lit.shape == base.shape
+    differs = np.any(lit != base, axis=1)
+    assert 0 < int(differs.sum()) < len(base)                 # some voxels' sums round differently, not all (single-point voxels cannot)
+    assert lit.tobytes() != desc.tobytes()
+    assert float(np.max(np.abs(lit - base))) < 1e-4
+    # a last-bit difference at most: the same additions in another order (a voxel of C3 holds a handful of points)
+    ulp = np.spacing(np.maximum(np.abs(base), np.float32(1e-3)).astype(np.float32))
+    assert float(np.max(np.abs(lit - base) / ulp)) <= 4.0
+    off0, idx0 = oracle.euclidean_clusters(base, p["tol"], p["min_cluster"], p["max_cluster"])
+    off1, idx1 = oracle.euclidean_clusters(lit, p["tol"], p["min_cluster"], p["max_cluster"])
+    assert np.array_equal(off0, off1) and np.array_equal(idx0, idx1)
 
 
 def test_knife_edge_report_equals_brute_force(oracle):
