@@ -348,6 +348,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_onepass(const Frame* frames) {
 // ------------------------------------------------------------------------------------------
 // end of frame: results -> pinned host memory (zero-copy stores), hash table reset
 // ------------------------------------------------------------------------------------------
+#ifndef PCOP_EMIT_VEC
+#define PCOP_EMIT_VEC 0   // 1 (tuning build, tools/ab_libs.sh): k_emit copies the cluster indices to the host 16 bytes a lane - built at the end of round 4, not measured yet
+#endif
 struct HostOut {
     DevState* state;
     uint32_t* offsets;     // n_kept + 1
@@ -395,7 +398,17 @@ __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t n
     if (st->kind != kFrameVoxelOnly && !st->trivial) {
         const uint32_t k = st->n_kept, np = st->n_kept_pts;
         for (uint32_t i = tid; i <= k; i += nth) out.offsets[i] = d_offsets[i];
+#if PCOP_EMIT_VEC
+        {   // tuning build: four indices a lane (1 KB a wave instruction on the bus instead of 256 bytes); both arrays are allocations of their own, 16-byte aligned
+            const uint32_t np4 = np / 4u;
+            const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(d_indices);
+            uint4* __restrict__ d4 = reinterpret_cast<uint4*>(out.indices);
+            for (uint32_t i = tid; i < np4; i += nth) d4[i] = s4[i];
+            for (uint32_t i = np4 * 4u + tid; i < np; i += nth) out.indices[i] = d_indices[i];
+        }
+#else
         for (uint32_t i = tid; i < np; i += nth) out.indices[i] = d_indices[i];
+#endif
     }
     if (st->emit_cloud) {   // the cloud the cluster indices refer to: the voxel centroids, or the input planes (pass-through; the cloud a filter kept)
         const bool pt = st->c_from_input != 0 && st->kind != kFrameClusterOnly;

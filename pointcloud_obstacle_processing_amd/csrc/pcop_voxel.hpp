@@ -584,6 +584,9 @@ __device__ __forceinline__ void finish_voxel(DevState* st, uint32_t m) {
 #ifndef PCOP_REDUCE_BPB
 #define PCOP_REDUCE_BPB 2
 #endif
+#ifndef PCOP_REDUCE_AOS
+#define PCOP_REDUCE_AOS 0   // 1 (tuning build, tools/ab_libs.sh): k_bucket_reduce stages a bucket as 12-byte records instead of three coordinate planes - built at the end of round 4, not measured yet
+#endif
 constexpr uint32_t kReduceBucketsPerBlock = PCOP_REDUCE_BPB;   // k_bucket_reduce: consecutive buckets per block (2: measured against 1, 3 and 4, tools/ab_build.sh)
 
 // mark_cells: a chain frame on the dense cell grid (set up by k_voxel_setup): every centroid marks its grid cell as it is
@@ -1485,7 +1488,11 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     if (blk * kBucketsPerBlock >= nb) return;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(s_mem);
     uint16_t* wpre = reinterpret_cast<uint16_t*>(s_mem + kMapWords * 4u);
+#if PCOP_REDUCE_AOS
+    Rec3* stage_r = reinterpret_cast<Rec3*>(s_mem);   // tuning build: the staged records as 12-byte records (a stride of three words walks every bank) instead of three planes
+#else
     float* stage_x = reinterpret_cast<float*>(s_mem); float* stage_y = stage_x + kPlane; float* stage_z = stage_y + kPlane;
+#endif
     const uint32_t w = threadIdx.x / kWave, lane = lane_id();
     VoxelKey key; key.init(st);
     const uint32_t pbase = w * (kItemsB * kWave) + lane;   // position in the bucket = index order
@@ -1652,8 +1659,12 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
     for (uint32_t j = 0; j < kItemsB; ++j) {
         if (act[j]) {
             const uint32_t slot = ((s_wc[wword * kBucketCap + id[j]] >> wshift) & 0xFFFFu) + rank[j];
+#if PCOP_REDUCE_AOS
+            stage_r[slot] = rec[j];
+#else
             const uint32_t ps = slot + (slot >> 5);
             stage_x[ps] = rec[j].x; stage_y[ps] = rec[j].y; stage_z[ps] = rec[j].z;
+#endif
         }
     }
     __syncthreads();
@@ -1667,7 +1678,11 @@ __global__ __launch_bounds__(kBlock) void k_bucket_reduce(Frame* frames) {
         for (uint32_t q = s0; q < e0; q += 4u) {   // four records requested at a time (clamped), added in order
             float vx[4], vy[4], vz[4];
 #pragma unroll
+#if PCOP_REDUCE_AOS
+            for (uint32_t u = 0; u < 4u; ++u) { const Rec3 t = stage_r[min(q + u, e0 - 1u)]; vx[u] = t.x; vy[u] = t.y; vz[u] = t.z; }
+#else
             for (uint32_t u = 0; u < 4u; ++u) { const uint32_t qq = min(q + u, e0 - 1u), ps = qq + (qq >> 5); vx[u] = stage_x[ps]; vy[u] = stage_y[ps]; vz[u] = stage_z[ps]; }
+#endif
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) if (q + u < e0) { sx += vx[u]; sy += vy[u]; sz += vz[u]; }
         }
