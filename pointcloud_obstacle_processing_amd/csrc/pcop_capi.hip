@@ -141,6 +141,16 @@ struct pcop_ctx {
     // possible when the GPU is shared so heavily that blocks of one launch are kept apart) costs a re-run, not the frame: the batch is
     // queued once more, by eager launches.  PCOP_DEBUG_SPIN0=1 makes the first batch of a context give up at its first poll (tests).
     bool internal_retry = false;             // the batch in flight is such a re-run
+#if PCOP_DIAG_REUSE_PLAN
+    // Diagnostic build only (tools/ab_libs.sh build reuse "-DPCOP_DIAG_REUSE_PLAN=1"): the UPPER BOUND of what a bucket plan carried from batch to batch can
+    // give.  A batch that hands every slot the same resident cloud as the three clean batches before it - what bench.py does - skips the histogram
+    // pass and the three kernels that turn it into a plan, and partitions by the tables those batches left in the slot (exact for the same cloud; a real stream needs slots).
+    std::vector<const float*> diag_last_src;
+    std::vector<uint32_t> diag_last_n;
+    uint32_t diag_cfg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t diag_same = 0;
+    bool diag_reuse = false;
+#endif
     bool debug_spin0 = false;                // the next batch runs with a spin limit of zero
     bool debug_plane_mismatch = false;       // PCOP_DEBUG_PLANE_MISMATCH=1: the next plane split "disagrees" with the host's selection (tests of the error path)
     uint32_t internal_retries = 0;           // re-runs so far (diagnostics)
@@ -336,6 +346,9 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             const uint32_t tile = tile_for(c, nb, nf);
             const dim3 bt(std::max(1u, div_up(nb, tile)), nf);       // tiles of the coarse histogram and of the partition
             const size_t bins = (size_t)1 << c->gbits;
+#if PCOP_DIAG_REUSE_PLAN
+            if (!(c->diag_reuse && c->sbox_batch)) {   // (the slot's tables of the last batch are this cloud's: see pcop_ctx::diag_reuse)
+#endif
             k_bin_hist<<<bt, kHistThreads, bins * 4u, s>>>(fr);
             mark(c, "k_bin_hist");
             k_bin_colsum<<<dim3((uint32_t)div_up((uint32_t)bins, kWave), nf), kBlock, 0, s>>>(fr);
@@ -344,6 +357,9 @@ void enqueue_launches_t(pcop_ctx* c, uint32_t kind, uint32_t nb, uint32_t nf, ui
             mark(c, "k_bin_plan");
             k_bin_tilecnt<<<bt, kBlock, (bins + 8u) * 2u, s>>>(fr);
             mark(c, "k_bin_tilecnt");
+#if PCOP_DIAG_REUSE_PLAN
+            }
+#endif
             // chunks of 8192 points where the tile and the LDS allow (see k_bin_scatter), else of 4096
             const bool big = c->scat_big && tile % (16u * kScatThreads) == 0u && c->nb_cap <= 4u * kScatThreads;
             auto scatter = [&](uint32_t alt, bool ordered) {
@@ -515,6 +531,22 @@ int enqueue_batch(pcop_ctx* c) {
     c->sbox_batch = sbox_on(c) || sbox_sort_on(c);
     c->stream_chk = c->kind != kFrameClusterOnly && stream_on(c) && c->lds_ordered && !c->stream_checked;
     const uint32_t nb = fill_frame_args(c);
+#if PCOP_DIAG_REUSE_PLAN
+    {
+        const uint32_t cfg[8] = {c->gbits, c->nb_cap, tile_for(c, nb, c->nframes), c->heavy_ok ? 1u : 0u, c->lds_ordered ? 1u : 0u,
+                                 (uint32_t)c->box_lo[0] ^ ((uint32_t)c->box_lo[1] << 10) ^ ((uint32_t)c->box_lo[2] << 20),
+                                 (uint32_t)c->box_hi[0] ^ ((uint32_t)c->box_hi[1] << 10) ^ ((uint32_t)c->box_hi[2] << 20), nb};
+        bool same = c->diag_last_src.size() == c->nframes && std::memcmp(cfg, c->diag_cfg, sizeof cfg) == 0;
+        for (uint32_t f = 0; same && f < c->nframes; ++f) same = c->diag_last_src[f] == c->slots[f].src_x && c->diag_last_n[f] == c->slots[f].n;
+        const bool plain = c->kind == kFrameChain && c->sbox_batch && stream_on(c) && !c->stream_chk && !c->internal_retry && !c->heavy_ok && c->cur_n_dev == nullptr;
+        c->diag_same = (same && plain) ? c->diag_same + 1u : 0u;
+        c->diag_last_src.resize(c->nframes); c->diag_last_n.resize(c->nframes);
+        for (uint32_t f = 0; f < c->nframes; ++f) { c->diag_last_src[f] = c->slots[f].src_x; c->diag_last_n[f] = c->slots[f].n; }
+        std::memcpy(c->diag_cfg, cfg, sizeof cfg);
+        c->diag_reuse = c->diag_same >= 3u;
+        for (uint32_t f = 0; f < c->nframes; ++f) c->slots[f].h_args->pad1 = c->diag_reuse ? 1u : 0u;
+    }
+#endif
     c->ev_used = 0;
     if (c->profiling || !c->use_graph || c->internal_retry) {
         mark(c, "start");
@@ -523,7 +555,11 @@ int enqueue_batch(pcop_ctx* c) {
     } else {
         const bool st_on = stream_on(c);
         const GraphKey key{c->kind, nb, st_on ? 0u : c->npass_voxel, c->npass_csr | ((c->csr_onepass && c->csr_small) ? 0x100u : 0u), c->nframes, st_on ? tile_for(c, nb, c->nframes) : 0u, st_on ? (c->heavy_ok ? 2u : 1u) : 0u, st_on ? c->nb_cap : 0u, st_on ? c->gbits : 0u,
-                           grid_on(c) ? (c->hook2 ? 2u : 1u) : 0u, grid_on(c) ? c->ctiles : 0u, (c->sbox_batch ? 3u : 0u) | (c->stream_chk ? 16u : 0u)};
+                           grid_on(c) ? (c->hook2 ? 2u : 1u) : 0u, grid_on(c) ? c->ctiles : 0u, (c->sbox_batch ? 3u : 0u) | (c->stream_chk ? 16u : 0u)
+#if PCOP_DIAG_REUSE_PLAN
+                           | (c->diag_reuse ? 32u : 0u)
+#endif
+                           };
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -648,6 +684,9 @@ int finish_batch(pcop_ctx* c, pcop_result* out, uint32_t nout) {
             // (every adaptive piece may have to move once for a cloud unlike the last: bins, buckets, heavy bins, voxel path,
             //  pass counts, occupancy tiles, cell path, CSR form - each moves towards "larger" only, so the loop ends)
             ++c->replans;
+#if PCOP_DIAG_REUSE_PLAN
+            c->diag_same = 0; c->diag_last_src.clear();   // (no carried tables after a batch that had to be run again)
+#endif
             // A frame given up half-way may have marked cells beyond the tiles its occupancy scan was launched with (kErrReplanCtiles),
             // and the re-run need not mark the same cells again: a batch that leaves the host's box for the bounds pass sets its cell
             // grid up from other bounds.  Flags nobody consumes would sit there until some later frame's grid covers them - cells

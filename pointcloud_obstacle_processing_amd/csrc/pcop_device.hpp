@@ -57,6 +57,9 @@ constexpr int kNarrowBits = 8;                   // digit limit of the small-LDS
 #ifndef PCOP_ITEMS
 #define PCOP_ITEMS 8
 #endif
+#ifndef PCOP_DIAG_REUSE_PLAN
+#define PCOP_DIAG_REUSE_PLAN 0   // 1: diagnostic build, see pcop_ctx::diag_reuse in pcop_capi.hip (never the product: it reuses a slot's bucket plan when the same resident cloud comes back)
+#endif
 constexpr int kItems = PCOP_ITEMS;               // records per thread in the partition kernels
 constexpr int kTile = kBlock * kItems;           // records per partition block
 constexpr int kMaxPasses = 4;                    // 4 x 8 bits = 3 x 11 bits >= 32-bit keys

@@ -61,8 +61,15 @@ __global__ __launch_bounds__(kBlock) void k_box_setup(Frame* frames, uint32_t np
     Frame& F = frames[blockIdx.y];
     DevState* st = &F.st;
     if (threadIdx.x == 0) {
+#if PCOP_DIAG_REUSE_PLAN
+        // diagnostic build: what the skipped histogram pass and k_bin_plan would have left in DevState (the last batch's values: same cloud, same box, same bins)
+        const uint32_t keep_nb = st->nbuckets, keep_valid = st->n_valid, keep_maxbin = st->maxbin, keep_nonfinite = st->box_nonfinite;
+#endif
         frame_init(F);
         const FrameArgs a = *F.args;
+#if PCOP_DIAG_REUSE_PLAN
+        if (a.pad1 == 1u && mode == 2u) { st->nbuckets = keep_nb; st->n_valid = keep_valid; st->maxbin = keep_maxbin; st->box_nonfinite = keep_nonfinite; }
+#endif
         st->sbox = 1u; st->vpath = mode == 3u ? 0u : 1u;
         st->box_tile = mode == 2u ? st->tile : (uint32_t)kTile;
         uint64_t cells = 1;
