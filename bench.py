@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=32, help="frames per context, processed in the same launches (32: + 6 %% over 16 in one run on one box, for twice a batch's latency; BASELINE.md 5)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) in flight per GPU")
     ap.add_argument("--feeders", default="threads", choices=["threads", "loop"], help="one host thread per context (default) or one loop over the contexts")
+    ap.add_argument("--rotate", action="store_true", help="hand a context's resident clouds to its slots shifted by one every round (default: a slot sees the same cloud every round); "
+                                                      "for measurements of anything that carries state in a slot from batch to batch (DESIGN.md 7.6)")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and the parity check that uses its results)")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -288,8 +290,9 @@ def worker(args):
         def feed(ci):
             try:
                 c, (pp, nn) = ctxs[ci], ptrs[ci]
-                for _ in range(nrounds):
-                    c.submit_batch_device(pp, nn)
+                for r_ in range(nrounds):
+                    k_ = r_ % len(pp) if args.rotate else 0
+                    c.submit_batch_device(pp[k_:] + pp[:k_], nn[k_:] + nn[:k_])
                     outs[ci] = c.wait_batch(want_arrays=False)[-1]
             except Exception as ex:   # (reported by the main thread)
                 errs.append(ex)
@@ -423,7 +426,7 @@ def worker(args):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-pt ground-plane + 20 boxes (L=4.5 m), leaf %g m, tol %g m, clusters %d..%d"
                        % (args.config, n0, p["leaf"], p["tol"], p["min_cluster"], p["max_cluster"]),
-                       "frames_in_flight_per_gpu": F, "batch_per_launch": B, "contexts_per_gpu": NC, "host_feeders": ("one thread per context" if args.feeders == "threads" and NC > 1 else "one loop"), "rounds_per_step": args.rounds, "cpus_bound_near_gpu": bound_cpus,
+                       "frames_in_flight_per_gpu": F, "batch_per_launch": B, "contexts_per_gpu": NC, "host_feeders": ("one thread per context" if args.feeders == "threads" and NC > 1 else "one loop"), "rounds_per_step": args.rounds, "clouds_rotate_through_slots": bool(args.rotate), "cpus_bound_near_gpu": bound_cpus,
                        "frames_per_step": F * world * args.rounds, "timed_region_s": dt, "voxels_per_frame": int(m_vox),
                        "input": "XYZ SoA resident in HBM", "parallelism": "frame-sharded, %d rank(s)" % world},
             "latency_ms_single_frame": lat_ms,
