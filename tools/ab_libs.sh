@@ -1,7 +1,7 @@
 # A/B of compile-time variants in ONE run on one box WITHOUT building there: the variants are built here (make EXTRA=...) into
 # variants/libpcop_<tag>.so, travel with the snapshot, and bench.py picks each through PCOP_LIB.
 #   build (here):  tools/ab_libs.sh build tag1 "-DFLAG1" tag2 "-DFLAG2" ...
-#   run (box):     tools/ab_libs.sh run [kernel pattern] [bench args]     every library under variants, twice, default first and last
+#   run (box):     [PARITY=1] tools/ab_libs.sh run [kernel pattern] [bench args]     every library under variants, twice, default first and last
 cmd=$1; shift
 C=pointcloud_obstacle_processing_amd/csrc
 if [ "$cmd" = build ]; then
@@ -15,11 +15,13 @@ fi
 pat=${1:-reduce}; shift
 EXTRA_ARGS="$*"
 run() {  # tag lib
-  PCOP_LIB=$2 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --no-secondary $EXTRA_ARGS > gpurun_out/abl_$1.json 2> gpurun_out/abl_$1.err || { echo "bench failed ($1)"; tail -3 gpurun_out/abl_$1.err; return 0; }
+  # PARITY=1: two frames of the timed batch are compared with the CPU restatement in every run (a variant nobody has run yet); default: no CPU leg
+  local cpu="--no-cpu-baseline"; [ -n "$PARITY" ] && cpu="--cpu-frames 2"
+  PCOP_LIB=$2 python bench.py --steps 8 --warmup 2 $cpu --no-end-to-end --no-secondary $EXTRA_ARGS > gpurun_out/abl_$1.json 2> gpurun_out/abl_$1.err || { echo "bench failed ($1)"; tail -3 gpurun_out/abl_$1.err; return 0; }
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/abl_$1.json").read().strip().splitlines()[-1])
-print("$1: %.0f frames/s" % d["value"])
+print("$1: %.0f frames/s" % d["value"], "| parity_checked", d.get("parity_checked"), "|", d.get("parity", "no parity leg in this run"))
 PY
   python tools/kernel_table.py gpurun_out/abl_$1.json | grep -E "$pat" || true
 }
