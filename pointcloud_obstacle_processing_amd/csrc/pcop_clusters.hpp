@@ -348,6 +348,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_onepass(const Frame* frames) {
 // ------------------------------------------------------------------------------------------
 // end of frame: results -> pinned host memory (zero-copy stores), hash table reset
 // ------------------------------------------------------------------------------------------
+#ifndef PCOP_DIAG_NO_INDEX_COPY
+#define PCOP_DIAG_NO_INDEX_COPY 0
+#endif
 #ifndef PCOP_EMIT_VEC
 #define PCOP_EMIT_VEC 0   // 1 (tuning build, tools/ab_libs.sh): k_emit copies the cluster indices to the host 16 bytes a lane - built at the end of round 4, not measured yet
 #endif
@@ -398,7 +401,10 @@ __global__ __launch_bounds__(kBlock) void k_emit(const Frame* frames, uint32_t n
     if (st->kind != kFrameVoxelOnly && !st->trivial) {
         const uint32_t k = st->n_kept, np = st->n_kept_pts;
         for (uint32_t i = tid; i <= k; i += nth) out.offsets[i] = d_offsets[i];
-#if PCOP_EMIT_VEC
+#if PCOP_DIAG_NO_INDEX_COPY
+        // diagnostic build (never the product; results are WRONG on the host: run without PARITY): the cluster indices stay on the device - what the zero-copy
+        // stores over the bus cost the bench line, i.e. the most any other way of getting them to the host could win
+#elif PCOP_EMIT_VEC
         {   // tuning build: four indices a lane (1 KB a wave instruction on the bus instead of 256 bytes); both arrays are allocations of their own, 16-byte aligned
             const uint32_t np4 = np / 4u;
             const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(d_indices);
