@@ -96,3 +96,19 @@ def test_numa_binding_without_a_device_changes_nothing(lib):
     lib.pcop_bind_thread_near_device.restype = C.c_int
     assert lib.pcop_bind_thread_near_device(0) == -3
     assert os.sched_getaffinity(0) == before
+
+
+@pytest.mark.parametrize("flags", [["-DPCOP_REDUCE_AOS=1", "-DPCOP_EMIT_VEC=1", "-DPCOP_DIAG_REUSE_PLAN=1"], ["-DPCOP_DIAG_NO_INDEX_COPY=1"]],
+                         ids=["aos+emitvec+reuse", "noidx"])
+def test_the_tuning_and_diagnostic_builds_still_parse(flags):
+    """The build switches of README.md (tuning / diagnostic builds for tools/ab_libs.sh) are dead text in the default build: a change
+    to the kernels around them would otherwise rot them unnoticed.  hipcc -fsyntax-only over both passes, two seconds."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pointcloud_obstacle_processing_amd", "csrc", "pcop_capi.hip")
+    out = subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", "-Wno-unused-value", "-Wno-unused-result"] + flags + [src],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and " error" not in out.stderr, out.stderr[-2000:]
