@@ -1,0 +1,16 @@
+#!/bin/bash
+# The CPU suite with the oracle and the host library (yaml / PointCloud2 / C hooks) built with AddressSanitizer + UndefinedBehaviorSanitizer
+# (GPU sanitizers are not available on this pool: the CPU build is where they run).  Restores the normal builds at the end.
+# usage: tools/sanitize_cpu.sh        (from the repository root; ~2 minutes)
+set -u
+SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined"
+H=pointcloud_obstacle_processing_amd/host
+make -s -C oracle clean && make -s -C oracle CXXFLAGS="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $SAN" || exit 3
+make -s -C $H clean && make -s -C $H libpcop_host.so CXXFLAGS="-O1 -g -std=c++17 -fPIC $SAN" || exit 3
+echo "instrumented symbols: oracle $(nm -D oracle/libpcop_oracle.so | grep -c '__asan\|__ubsan'), host $(nm -D $H/libpcop_host.so | grep -c '__asan\|__ubsan')"
+LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 \
+  python -m pytest tests/ -x -q -m "not gpu" -p no:cacheprovider --deselect tests/test_sharding_gloo.py --deselect tests/test_ros_adapter_syntax.py
+rc=$?
+make -s -C oracle clean && make -s -C oracle
+make -s -C $H clean && make -s -C $H
+exit $rc
