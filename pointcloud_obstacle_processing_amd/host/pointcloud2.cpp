@@ -18,7 +18,8 @@ bool find_xyz_fields(const PointCloud2& msg, uint32_t* off_x, uint32_t* off_y, u
         if (error) *error = "PointCloud2 has no FLOAT32 x/y/z fields";
         return false;
     }
-    if (*off_x + 4 > msg.point_step || *off_y + 4 > msg.point_step || *off_z + 4 > msg.point_step) {
+    // (written so that an offset near 2^32 cannot wrap past the test: the same form as stage_pointcloud2 in csrc/pcop_capi.hip)
+    if (msg.point_step < 4 || *off_x > msg.point_step - 4 || *off_y > msg.point_step - 4 || *off_z > msg.point_step - 4) {
         if (error) *error = "x/y/z offsets exceed point_step";
         return false;
     }
@@ -105,10 +106,20 @@ bool read_pointcloud2_file(const std::string& path, PointCloud2* msg, std::strin
     f >> key >> msg->point_step >> key >> msg->row_step;
     f >> key >> b; msg->is_dense = b != 0;
     f >> key >> nfields;
+    // a count no file of this format can hold is a corrupt header, not an allocation to attempt
+    if (!f || nfields > 4096) { if (error) *error = "corrupt header in " + path; return false; }
     msg->fields.resize(nfields);
     for (PointField& pf : msg->fields) { int dt = 0; f >> pf.name >> pf.offset >> dt >> pf.count; pf.datatype = (uint8_t)dt; }
     f >> key >> nbytes;
     f.get();   // the newline after the byte count
+    if (!f) { if (error) *error = "corrupt header in " + path; return false; }
+    {   // the blob cannot be longer than what is left of the file
+        const std::streampos here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const std::streampos end = f.tellg();
+        f.seekg(here);
+        if (here < 0 || end < here || nbytes > (size_t)(end - here)) { if (error) *error = "truncated file " + path; return false; }
+    }
     msg->data.resize(nbytes);
     f.read(reinterpret_cast<char*>(msg->data.data()), (std::streamsize)nbytes);
     if (!f) { if (error) *error = "truncated file " + path; return false; }

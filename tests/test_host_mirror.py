@@ -94,3 +94,22 @@ def test_missing_xyz_field_is_rejected(hostlib, tmp_path):
     open(path, "wb").write(raw)
     out = np.zeros(30, dtype=np.float32)
     assert hostlib.pcop_host_read_cloud_xyz(path.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), 10, None, None) == -2
+
+
+def test_corrupt_cloud_files_are_refused_not_followed(hostlib, tmp_path):
+    """A field offset near 2^32 must not wrap past the offset check (off + 4 did), and counts in the header that no file can hold
+    are a corrupt header, not an allocation to attempt."""
+    path = str(tmp_path / "cloud.pc2")
+    pc2io.write_pointcloud2(path, synth.uniform_field(10, 1))
+    good = open(path, "rb").read()
+    out = np.zeros(30, dtype=np.float32)
+    outp = out.ctypes.data_as(C.POINTER(C.c_float))
+    assert hostlib.pcop_host_read_cloud_xyz(path.encode(), outp, 10, None, None) == 10
+    for patch, want in (((b"\nz 8 7 1\n", b"\nz 4294967294 7 1\n"), -2),          # offset + 4 wraps to 2
+                        ((b"\nz 8 7 1\n", b"\nz 4294967293 7 1\n"), -2),
+                        ((b"\nfields 3\n", b"\nfields 99999999999999\n"), -1),
+                        ((b"\ndata 160\n", b"\ndata 999999999999999\n"), -1),
+                        ((b"\ndata 160\n", b"\ndata 161\n"), -1)):                 # one byte more than the file holds
+        assert patch[0] in good, patch[0]
+        open(path, "wb").write(good.replace(*patch))
+        assert hostlib.pcop_host_read_cloud_xyz(path.encode(), outp, 10, None, None) == want, patch[1]
