@@ -78,7 +78,8 @@ struct Reader {
             // roscpp's getImpl(int) accepts a double and rounds it: fmod(d,1) < 0.5 ? floor : ceil
             double d = std::strtod(v.c_str(), nullptr);
             d = (std::fmod(d, 1.0) < 0.5) ? std::floor(d) : std::ceil(d);
-            *var = static_cast<int>(d);
+            if (std::isnan(d)) return;                                   // (the conversion of a NaN or of a value beyond int is undefined: clamped, a NaN leaves the default)
+            *var = d >= 2147483647.0 ? 2147483647 : d <= -2147483648.0 ? (-2147483647 - 1) : static_cast<int>(d);
             return;
         }
         *var = static_cast<int>(std::strtol(v.c_str(), nullptr, 10));
