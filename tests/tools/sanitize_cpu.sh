@@ -1,7 +1,7 @@
 #!/bin/bash
 # The CPU suite with the oracle and the host library (yaml / PointCloud2 / C hooks) built with AddressSanitizer + UndefinedBehaviorSanitizer
 # (GPU sanitizers are not available on this pool: the CPU build is where they run).  Restores the normal builds at the end.
-# usage: tools/sanitize_cpu.sh        (from the repository root; ~2 minutes)
+# usage: tests/tools/sanitize_cpu.sh        (from the repository root; ~2 minutes)
 set -u
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined"
 H=pointcloud_obstacle_processing_amd/host
